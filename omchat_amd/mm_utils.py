@@ -1,0 +1,89 @@
+"""Host-side (CPU, integer/PIL) helpers on the caller side of the hot path; counterparts of the reference's
+omchat/mm_utils.py.  They decide the ViT batch shape (tile count + order) and the `-200` sentinel layout."""
+import math
+from .constants import IMAGE_TOKEN_INDEX
+
+
+def select_best_resolution(original_size, possible_resolutions):
+    """Counterpart of mm_utils.py:12-39: maximise the effective (downscaled) resolution, then minimise waste;
+    first candidate wins ties."""
+    ow, oh = original_size
+    best, best_eff, best_waste = None, 0, float("inf")
+    for w, h in possible_resolutions:
+        s = min(w / ow, h / oh)
+        dw, dh = int(ow * s), int(oh * s)
+        eff = min(dw * dh, ow * oh)
+        waste = w * h - eff
+        if eff > best_eff or (eff == best_eff and waste < best_waste):
+            best, best_eff, best_waste = (w, h), eff, waste
+    return best
+
+
+def padded_size(original_size, target_resolution):
+    """Size of the aspect-preserving resize inside resize_and_pad_image (mm_utils.py:42-74)."""
+    ow, oh = original_size
+    tw, th = target_resolution
+    sw, sh = tw / ow, th / oh
+    if sw < sh:
+        return tw, min(math.ceil(oh * sw), th)
+    return min(math.ceil(ow * sh), tw), th
+
+
+def resize_and_pad_image(image, target_resolution):
+    """mm_utils.py:42-74 (PIL): resize keeping aspect, paste centred on a black canvas."""
+    from PIL import Image
+    tw, th = target_resolution
+    nw, nh = padded_size(image.size, target_resolution)
+    canvas = Image.new("RGB", (tw, th), (0, 0, 0))
+    canvas.paste(image.resize((nw, nh)), ((tw - nw) // 2, (th - nh) // 2))
+    return canvas
+
+
+def divide_to_patches(image, patch_size):
+    """mm_utils.py:77-96: row-major crops."""
+    w, h = image.size
+    return [image.crop((j, i, j + patch_size, i + patch_size)) for i in range(0, h, patch_size) for j in range(0, w, patch_size)]
+
+
+def anyres_tile_count(image_size, grid_pinpoints, tile=448):
+    w, h = select_best_resolution(image_size, grid_pinpoints)
+    return 1 + (w // tile) * (h // tile)
+
+
+def process_anyres_image(image, processor, grid_pinpoints, return_type_list=False, return_best_res=False):
+    """mm_utils.py:119-158: [thumbnail] + tiles of the resized/padded canvas, each through `processor.preprocess`."""
+    import torch
+    best = select_best_resolution(image.size, grid_pinpoints)
+    padded = resize_and_pad_image(image, best)
+    edge = processor.crop_size["height"] if hasattr(processor, "crop_size") else processor.size["height"]
+    patches = divide_to_patches(padded, edge)
+    thumb = image.resize((edge, edge))
+    tiles = [processor.preprocess(p, return_tensors="pt")["pixel_values"][0] for p in [thumb] + patches]
+    out = tiles if return_type_list else torch.stack(tiles, dim=0)
+    return (out, best) if return_best_res else out
+
+
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
+    """mm_utils.py:197-230 (the `<image>` branch): tokenise the chunks between `<image>` markers and join them
+    with the sentinel; a leading BOS (none for Qwen2) is kept once."""
+    chunks = [tokenizer(c).input_ids for c in prompt.split("<image>")]
+    ids, offset = [], 0
+    if chunks and chunks[0] and chunks[0][0] == getattr(tokenizer, "bos_token_id", None):
+        offset = 1
+        ids.append(chunks[0][0])
+    for i, c in enumerate(chunks):
+        ids.extend(c[offset:])
+        if i < len(chunks) - 1:
+            ids.append(image_token_index)
+    if return_tensors == "pt":
+        import torch
+        return torch.tensor(ids, dtype=torch.long)
+    if return_tensors is not None:
+        raise ValueError(f"Unsupported tensor type: {return_tensors}")
+    return ids
+
+
+def get_model_name_from_path(model_path):
+    """mm_utils.py:233-239."""
+    parts = model_path.strip("/").split("/")
+    return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]
