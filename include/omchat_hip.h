@@ -1,0 +1,142 @@
+/* omchat_hip.h -- C ABI of libomchat_hip.so: the MI355X (gfx950) implementation of the OmChat inference hot path
+ * (InternViT vision tower -> mlp2x_gelu projector -> image-token splice -> Qwen2 prefill -> greedy decode).
+ *
+ * The reference (om-ai-lab/OmChat) has no FFI of its own: its seams are Python class boundaries.  Each entry point
+ * below names the reference interface it stands behind (file:line relative to the reference repo; Qwen2 lines refer
+ * to transformers/models/qwen2/modeling_qwen2.py which the reference inherits at
+ * omchat/model/language_model/omchat_qwen2.py:7,22,29).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: plain pointers + sizes, no framework types.  Device pointers unless stated.  All 16-bit tensors use
+ * the context's compute dtype (OMCHAT_F16 / OMCHAT_BF16), row-major.  `stream` is a hipStream_t (NULL = default
+ * stream); every call only enqueues work on it.  Return 0 on success; otherwise omchat_last_error() (thread-local)
+ * explains, and the Python mirror re-raises ValueError / RuntimeError like the reference does.
+ */
+#ifndef OMCHAT_HIP_H
+#define OMCHAT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMCHAT_F16 0
+#define OMCHAT_BF16 1
+#define OMCHAT_F32 2            /* accepted as a SOURCE dtype by omchat_load_tensor only */
+#define OMCHAT_PAD_ROW INT32_MIN /* splice index: zero row */
+
+typedef struct omchat_ctx omchat_ctx;
+
+/* Per-rank (already tensor-parallel-local) model geometry.  Field names follow InternVisionConfig
+ * (multimodal_encoder/intern_vit_6b/configuration_intern_vit.py:63-83) and Qwen2Config. */
+typedef struct {
+  /* vision tower */
+  int v_hidden;        /* hidden_size (3200) */
+  int v_heads;         /* LOCAL attention heads (25 at TP=1; zero-padded shards otherwise), head_dim is 128 */
+  int v_qk_channels;   /* divisor of the joint q/k RMSNorm = full hidden_size (3200) (modeling_intern_vit.py:143-146) */
+  int v_mlp;           /* LOCAL intermediate_size (12800 / tp) */
+  int v_layers;        /* num_hidden_layers (45) */
+  int v_patch;         /* 14 */
+  int v_image;         /* 448 */
+  float v_eps;         /* layer_norm_eps 1e-6 */
+  /* decoder */
+  int t_hidden;        /* 3584 */
+  int t_layers;        /* 28 */
+  int t_heads;         /* LOCAL query heads */
+  int t_kv_heads;      /* LOCAL kv heads */
+  int t_mlp;           /* LOCAL intermediate_size */
+  int t_vocab;         /* LOCAL lm_head rows */
+  int t_vocab_total;   /* embed_tokens rows (replicated) */
+  float t_eps;         /* rms_norm_eps */
+  float rope_theta;    /* 1e6 */
+  /* capacities */
+  int max_seq;         /* KV positions per sequence */
+  int max_batch;       /* sequences */
+  int max_tiles;       /* ViT tiles per launch batch */
+  int max_prefill_rows;/* b * S rows of one prefill call */
+  int dtype;           /* OMCHAT_F16 | OMCHAT_BF16 */
+} omchat_config;
+
+const char* omchat_last_error(void);
+const char* omchat_version(void);
+
+/* ---- loader: stands behind load_pretrained_model (omchat/model/builder.py:22-35) -------------------------------- */
+/* rccl_comm: ncclComm_t of the tensor-parallel group or NULL (tp_size == 1). */
+int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_size, void* rccl_comm, omchat_ctx** out);
+void omchat_ctx_destroy(omchat_ctx* ctx);
+/* name: omchat-native checkpoint key, e.g. "model.layers.3.mlp.gate_proj.weight";
+ * data: host OR device pointer to the (rank-local) tensor, contiguous; src_dtype: ctx dtype or OMCHAT_F32. */
+int omchat_load_tensor(omchat_ctx* ctx, const char* name, const void* data, const int64_t* shape, int ndim, int src_dtype);
+/* fills every weight with omchat_amd/synth.py's deterministic generator (same values as the host generator). */
+int omchat_fill_synthetic(omchat_ctx* ctx, uint64_t seed);
+/* number of tensors still missing (0 = ready); names of missing tensors are put in omchat_last_error(). */
+int omchat_weights_missing(omchat_ctx* ctx);
+size_t omchat_device_bytes(omchat_ctx* ctx);
+
+/* ---- tower: InternVITVisionTower.forward + feature_select (internVIT_encoder.py:35-56) -------------------------- */
+/* pixels [n_tiles,3,v_image,v_image]; out [n_tiles, ntok, v_hidden], ntok = patches (+1 when keep_cls).
+ * select_layer indexes hidden_states like the reference (0 = embeddings, -1 = last layer). */
+int omchat_vit_forward(omchat_ctx* ctx, const void* pixels, int n_tiles, int select_layer, int keep_cls, void* out, void* stream);
+/* ---- projector: build_vision_projector('mlp2x_gelu').forward (multimodal_projector/builder.py:54-61) ------------ */
+int omchat_projector_forward(omchat_ctx* ctx, const void* in, int rows, void* out, void* stream);
+/* ---- encode_images (omchat_arch.py:50-53): tower (select_layer, patch features) then projector ------------------ */
+int omchat_encode_images(omchat_ctx* ctx, const void* pixels, int n_tiles, int select_layer, void* out, void* stream);
+
+/* ---- splice: prepare_inputs_labels_for_multimodal (omchat_arch.py:55-209) --------------------------------------- */
+/* Host-side plan (integers only).  ids int64 [b,T] with -200 sentinels; mask uint8 [b,T] or NULL; n_tok rows per
+ * tile; padding_side 0 = right, 1 = left; max_length <= 0 = none.  Writes src_index int32 [b * S_out] (>= 0: token
+ * id, <= -1: feature row -1-k, OMCHAT_PAD_ROW: zero row), lengths int32 [b]; returns S_out via *S_out.
+ * Call with src_index == NULL to size the output.  n_tiles_avail is checked like the reference's running index. */
+int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b, int T, int n_tok, int n_tiles_avail,
+                       int padding_side, int max_length, int32_t* src_index, int32_t* lengths, int* S_out);
+/* Device gather: embeds[r] = embed_tokens[idx] | feats[row] | 0.  src_index device int32 [rows]. */
+int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, const void* feats, void* embeds, int rows, void* stream);
+
+/* ---- decoder: OmChatQwen2ForCausalLM.forward (omchat_qwen2.py:45-89) -> Qwen2ForCausalLM.forward --------------- */
+/* Prefill step 0: embeds [b, S, t_hidden] (right-padded rows), lengths host int32 [b].  Resets the KV cache of
+ * sequences 0..b-1.  logits_last: device fp32 [b, t_vocab] for the last valid position of each sequence (or NULL).
+ * hidden_out: optional [b, S, t_hidden] post-final-norm hidden states (test hook).  */
+int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last,
+                   void* hidden_out, void* stream);
+/* Decode step >= 1 (omchat_qwen2.py:92-111, omchat_arch.py:61-70): one token per sequence, appended at kv_len.
+ * tokens device int32 [b]; logits device fp32 [b, t_vocab] or NULL; next_tokens device int32 [b] (greedy argmax,
+ * first index wins) or NULL. */
+int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream);
+/* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
+int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
+int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
+
+/* ---- the one native op seam of the reference: FlashAttention.forward (intern_vit_6b/flash_attention.py:30-75) --- */
+/* qkv packed [B, S, 3, H, 128] -> out [B, S, H, 128]; softmax_scale <= 0 means 1/sqrt(128). */
+int omchat_mha_fwd(const void* qkv, int B, int S, int H, float softmax_scale, int causal, void* out, int dtype, void* stream);
+
+/* ---- op-level entry points (unit parity tests, benches) --------------------------------------------------------- */
+int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                   const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream);
+int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
+                   const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream);
+int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream);
+int omchat_op_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total,
+                         float eps, float q_scale, void* stream);
+/* q [b,Sq,Hq,128], k/v [b,Hkv,Skv,128] (cache layout), out [b,Sq,Hq,128]; kv_len device int32 [b] or NULL */
+int omchat_op_attn_prefill(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Sq, int Skv,
+                           int Hq, int Hkv, const int32_t* kv_len, int causal, int q_pos0, float scale, void* stream);
+/* q [b,Hq,128], k/v [b,Hkv,cap,128]; kv_len device int32 [b] or NULL (-> L); ws from omchat_op_attn_decode_ws */
+size_t omchat_op_attn_decode_ws(int b, int Hq, int L);
+int omchat_op_attn_decode(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Hq, int Hkv,
+                          int cap, int L, const int32_t* kv_len, float scale, void* ws, size_t ws_bytes, void* stream);
+/* qkv [rows, (Hq+2Hkv)*128]; rows = b*S; positions pos0 + s; caches [b,Hkv,cap,128]; theta: rope base */
+int omchat_op_rope_kv(int dtype, void* qkv, int b, int S, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache,
+                      int cap, void* stream);
+int omchat_op_argmax(const float* logits, int b, int V, int32_t* out, void* stream);
+int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, void* stream);
+
+/* ---- tensor-parallel bootstrap (RCCL over xGMI; one process per GPU) -------------------------------------------- */
+int omchat_comm_unique_id(char id[128]);
+int omchat_comm_init(const char id[128], int rank, int size, void** comm_out);
+void omchat_comm_destroy(void* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,51 @@
+"""Build libomchat_hip.so for gfx950 with hipcc (in-tree: omchat_amd/lib/).  `python -m omchat_amd.build`."""
+import os, subprocess, sys, hashlib, concurrent.futures as cf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libomchat_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "model.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stamp(path):
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(SRC)) + ["../../include/omchat_hip.h"]:
+        with open(os.path.join(SRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp_file = os.path.join(LIBDIR, "stamp")
+    stamp = _stamp(SRC)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    objs = []
+
+    def cc(src):
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(SRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB)/1e6:.1f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,310 @@
+// Flash attention for gfx950, head_dim 128, "query on the lane" formulation.
+//
+// Replaces flash_attn_varlen_qkvpacked_func / _naive_attn in the ViT (intern_vit_6b/flash_attention.py:51-54,
+// modeling_intern_vit.py:148-152: non-causal MHA, S = 1025) and eager_attention_forward in the Qwen2 decoder
+// (modeling_qwen2.py:150-172: causal GQA with KV cache) for prefill AND decode.
+//
+// Everything is computed transposed so that no lane shuffles and no LDS round trip sit between the two MFMA chains:
+//   S^T[key][q] = K[key][:] . Q[q][:]      A = K rows (ds_read_b128 from the K tile), B = Q^T (registers, loaded once)
+//       -> lane (g = lane>>4, c = lane&15) holds scores of query c for keys 16*kt + 4*g + r   (MFMA 16x16x32 C/D map)
+//   softmax over keys = over the lane's 16 registers + xor-16/xor-32 shuffles; running max / sum per lane (= per query)
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q]  B = P^T: the score registers themselves, packed to 16 bit (k-slot j of lane
+//       group g <-> key 32*ks + 16*(j>>2) + 4*g + (j&3)), A = V^T fetched with ds_read_b64_tr_b16 in the SAME key order
+//   -> O^T accumulator has the query on the lane again, so the rescale by alpha needs no cross-lane traffic.
+// K tile LDS image: 256-B rows, 16-B chunk' = chunk ^ (row & 15)      (conflict-free ds_read_b128 operand reads)
+// V tile LDS image: 256-B rows, 16-B chunk' = chunk ^ ((row & 7) << 1) (conflict-free transposed reads)
+//
+// Prefill: workgroup = 4 waves x 32 queries (2 query tiles per wave share every K/V fragment), KV tile = 64 keys,
+// next tile's global loads are issued before the MFMA work of the current one (register staged).
+// Decode: one wave per (sequence, kv head, 64-key split); the "queries" are the n_rep heads sharing that kv head;
+// partial (m, l, O) go to a workspace and a merge kernel normalises.
+#include "kernels.h"
+
+namespace {
+
+struct AttnP {
+  const void* Q; const void* K; const void* V; void* O;
+  int64_t q_sb, q_sh, q_sr, k_sb, k_sh, k_sr, v_sb, v_sh, v_sr, o_sb, o_sh, o_sr;
+  const int* kv_len;
+  int q_heads, kv_heads, Sq, Skv, causal, q_pos0, nsplit;
+  float c;      // scale * log2(e)
+  float* ws;
+};
+
+constexpr int KV_TILE = 64;
+constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
+constexpr float NEG_BIG = -1e30f;
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
+}
+
+template <typename T, int NW, int NQ, bool DECODE>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  constexpr int NT = NW * 64;
+  constexpr int CH = 1024 / NT;            // 16-B chunks per thread per tile (K and V each)
+  __shared__ __attribute__((aligned(256))) char smem[2 * KV_TILE * 256];
+  char* const Ks = smem;
+  char* const Vs = smem + KV_TILE * 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fc = lane & 15, fg = lane >> 4;
+
+  int b, hq0, kvh, n_rep, q0 = 0, t_begin, t_end, split = 0;
+  n_rep = p.q_heads / p.kv_heads;
+  if constexpr (DECODE) {
+    split = blockIdx.x; kvh = blockIdx.y; b = blockIdx.z; hq0 = kvh * n_rep;
+  } else {
+    const int nqb = gridDim.x;
+    const int qb = p.causal ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;     // heaviest causal blocks first
+    hq0 = blockIdx.y; kvh = hq0 / n_rep; b = blockIdx.z;
+    q0 = qb * (NW * NQ * 16);
+  }
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  if constexpr (DECODE) {
+    t_begin = split; t_end = split + 1;
+    if (t_begin * KV_TILE >= kv_len) t_end = t_begin;      // empty split: writes l = 0, m = NEG_BIG
+  } else {
+    int kmax = kv_len;
+    if (p.causal) { const int lim = q0 + NW * NQ * 16 + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
+    t_begin = 0; t_end = (kmax + KV_TILE - 1) / KV_TILE;
+  }
+
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+
+  // ---- Q fragments (B operand of S^T): lane holds Q[query fc][d = 32*ds + 8*fg + j]
+  frag_t qf[NQ][4];
+  int qrow[NQ];                 // prefill: global query row of this lane's column; decode: head index in the group
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    const T* qp;
+    if constexpr (DECODE) {
+      qrow[qt] = fc;
+      const int hh = fc < n_rep ? fc : n_rep - 1;
+      qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+    } else {
+      qrow[qt] = q0 + (wave * NQ + qt) * 16 + fc;
+      const int rr = qrow[qt] < p.Sq ? qrow[qt] : p.Sq - 1;
+      qp = (const T*)p.Q + b * p.q_sb + hq0 * p.q_sh + rr * p.q_sr;
+    }
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = ld8<T>(qp + ds * 32 + fg * 8);
+  }
+
+  f32x4 o[NQ][8];
+  float m_run[NQ], l_run[NQ];
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) o[qt][dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging: thread handles chunks idx = i*NT + tid -> row = idx >> 4, ch = idx & 15
+  constexpr int PF = DECODE ? 4 : CH;      // chunks held in registers at a time
+  frag_t kreg[PF], vreg[PF];
+  auto load_part = [&](int t, int i0) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
+      int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;     // clamp: masked keys must still be finite
+      kreg[i] = ld8<T>(Kg + kr * p.k_sr + ch * 8);
+      vreg[i] = ld8<T>(Vg + kr * p.v_sr + ch * 8);
+    }
+  };
+  auto write_part = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
+      *reinterpret_cast<frag_t*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<frag_t*>(Vs + row * 256 + ((ch ^ ((row & 7) << 1)) << 4)) = vreg[i];
+    }
+  };
+  auto load_tile = [&](int t) { if constexpr (!DECODE) load_part(t, 0); };
+  auto write_tile = [&](int t) {
+    if constexpr (DECODE) {
+#pragma unroll
+      for (int i0 = 0; i0 < CH; i0 += PF) { load_part(t, i0); write_part(i0); }
+    } else {
+      write_part(0);
+    }
+  };
+
+  // per-lane LDS read offsets
+  // K operand: row = 16*kt + fc, chunk = 4*ds + fg -> phys = chunk ^ fc
+  // V^T operand (transposed read): lane fc = 4*tq + tp supplies row 32*ks + 4*fg + tq (+16), chunk 2*dn + (tp>>1), +8*(tp&1)
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;                       // (+32*ks, +16 for the second read)
+  const int vswz = ((vrow_lo & 7) << 1);                 // rows +16 / +32 keep (row & 7)
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                 // everyone is done reading the previous tile
+    write_tile(t);
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);     // in flight during the MFMA work below
+
+    // ---- S^T = K Q^T
+    f32x4 s[NQ][4];
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + (kt * 16 + fc) * 256 + (((ds * 4 + fg) ^ fc) << 4));
+#pragma unroll
+        for (int qt = 0; qt < NQ; ++qt) s[qt][kt] = mfma16(kf, qf[qt][ds], s[qt][kt]);
+      }
+
+    // ---- mask + online softmax (per lane = per query column)
+    const int key0 = t * KV_TILE + 4 * fg;
+    frag_t pf[NQ][2];
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt) {
+      int lim = kv_len;                                   // keys < lim are visible
+      if constexpr (!DECODE) {
+        if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = key0 + kt * 16 + r;
+          float v = s[qt][kt][r];
+          v = kj < lim ? v : NEG_BIG;
+          s[qt][kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = exp2f((m_run[qt] - m_new) * p.c);
+      m_run[qt] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = rnd<T>(exp2f((s[qt][kt][r] - m_new) * p.c));
+          psum += pv;
+          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)pv;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) o[qt][dn] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) {
+        const int ch = (2 * dn + (tp >> 1)) ^ vswz;
+        const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+        const s16x4 lo = tr_read(a0);
+        const s16x4 hi = tr_read(a0 + 16 * 256);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const frag_t vf = __builtin_bit_cast(frag_t, cat);
+#pragma unroll
+        for (int qt = 0; qt < NQ; ++qt) o[qt][dn] = mfma16(vf, pf[qt][ks], o[qt][dn]);
+      }
+  }
+
+  // ---- finalize.  o[qt][dn][r] = O^T[d = 16*dn + 4*fg + r][query fc]
+#pragma unroll
+  for (int qt = 0; qt < NQ; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if constexpr (DECODE) {
+      if (fc < n_rep) {
+        float* w = p.ws + ((size_t)(b * p.q_heads + hq0 + fc) * p.nsplit + split) * WS_STRIDE;
+#pragma unroll
+        for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(w + dn * 16 + fg * 4) = o[qt][dn];
+        if (fg == 0) { w[128] = m_run[qt]; w[129] = l; }
+      }
+    } else {
+      if (qrow[qt] < p.Sq) {
+        const float inv = 1.f / l;
+        T* op = (T*)p.O + b * p.o_sb + hq0 * p.o_sh + qrow[qt] * p.o_sr + fg * 4;
+#pragma unroll
+        for (int dn = 0; dn < 8; ++dn) {
+          typename V8<T>::half_type h4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h4[r] = fromf<T>(o[qt][dn][r] * inv);
+          *reinterpret_cast<typename V8<T>::half_type*>(op + dn * 16) = h4;
+        }
+      }
+    }
+  }
+}
+
+// merge split-KV partials: one 128-thread block per (sequence, head)
+template <typename T>
+__global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
+                                                         T* O, int64_t o_sb, int64_t o_sh) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int len = kv_len ? kv_len[b] : L;
+  int ns = (len + KV_TILE - 1) / KV_TILE;
+  ns = ns < nsplit ? ns : nsplit;
+  const float* w = ws + (size_t)(b * q_heads + h) * nsplit * WS_STRIDE;
+  float m = NEG_BIG;
+  for (int s = 0; s < ns; ++s) m = fmaxf(m, w[s * WS_STRIDE + 128]);
+  float acc = 0.f, l = 0.f;
+  for (int s = 0; s < ns; ++s) {
+    const float f = exp2f((w[s * WS_STRIDE + 128] - m) * c);
+    acc += f * w[s * WS_STRIDE + d];
+    l += f * w[s * WS_STRIDE + 129];
+  }
+  O[b * o_sb + h * o_sh + d] = fromf<T>(acc / l);
+}
+
+}  // namespace
+
+int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
+  OM_CHECK(a.q_heads % a.kv_heads == 0, "q_heads must be a multiple of kv_heads");
+  OM_CHECK(a.Sq > 0 && a.Skv > 0 && a.batch > 0, "empty attention");
+  OM_CHECK(a.q_sr % 8 == 0 && a.k_sr % 8 == 0 && a.v_sr % 8 == 0 && a.o_sr % 4 == 0, "row strides must keep 16-B alignment");
+  AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
+          a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr};
+  dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, false>), grid, dim3(256), 0, s, p);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, false>), grid, dim3(256), 0, s, p);
+  else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len) {
+  return (size_t)batch * q_heads * cdiv(max_len, KV_TILE) * WS_STRIDE * sizeof(float);
+}
+
+int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
+  OM_CHECK(a.q_heads % a.kv_heads == 0 && a.q_heads / a.kv_heads <= 16, "group size must be <= 16");
+  OM_CHECK(a.L > 0 && a.batch > 0, "empty attention");
+  const int nsplit = cdiv(a.L, KV_TILE);
+  OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
+  AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
+          a.kv_len, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws};
+  dim3 grid(nsplit, a.kv_heads, a.batch);
+  dim3 mgrid(a.q_heads, a.batch);
+  if (dtype == OMCHAT_F16) {
+    hipLaunchKernelGGL((attn_kernel<f16, 1, 1, true>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh);
+  } else if (dtype == OMCHAT_BF16) {
+    hipLaunchKernelGGL((attn_kernel<bf16, 1, 1, true>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh);
+  } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,97 @@
+// Op-level C ABI entry points (unit parity tests / micro benches) and the FlashAttention-shaped seam.
+#include "kernels.h"
+#include "../../include/omchat_hip.h"
+#include <math.h>
+#include <vector>
+
+#define S(x) ((hipStream_t)(x))
+
+extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                              const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream) {
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, force_tile};
+  return launch_gemm(dtype, g, S(stream));
+}
+
+extern "C" int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
+                              const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream) {
+  GemvArgs g{X, ldx, W, ldw, Y, ldy, b, N, K, bias, resid, ldr, epi, out_f32};
+  return launch_gemv(dtype, g, S(stream));
+}
+
+extern "C" int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream) {
+  return launch_rmsnorm(dtype, x, H, w, y, H, rows, H, eps, S(stream));
+}
+
+extern "C" int omchat_op_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total, float eps,
+                                    float q_scale, void* stream) {
+  return launch_vit_qknorm(dtype, qkv, ld, wq, wk, rows, C, C_total, eps, q_scale, nullptr, S(stream));
+}
+
+extern "C" int omchat_op_attn_prefill(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Sq, int Skv, int Hq,
+                                      int Hkv, const int32_t* kv_len, int causal, int q_pos0, float scale, void* stream) {
+  AttnArgs a{};
+  a.Q = q; a.q_sb = (int64_t)Sq * Hq * 128; a.q_sh = 128; a.q_sr = (int64_t)Hq * 128;
+  a.K = k; a.k_sb = (int64_t)Hkv * Skv * 128; a.k_sh = (int64_t)Skv * 128; a.k_sr = 128;
+  a.V = v; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+  a.O = out; a.o_sb = a.q_sb; a.o_sh = 128; a.o_sr = a.q_sr;
+  a.batch = b; a.q_heads = Hq; a.kv_heads = Hkv; a.Sq = Sq; a.Skv = Skv; a.kv_len = kv_len; a.causal = causal; a.q_pos0 = q_pos0; a.scale = scale;
+  return launch_attn_prefill(dtype, a, S(stream));
+}
+
+extern "C" size_t omchat_op_attn_decode_ws(int b, int Hq, int L) { return attn_decode_ws_bytes(b, Hq, L); }
+
+extern "C" int omchat_op_attn_decode(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Hq, int Hkv, int cap, int L,
+                                     const int32_t* kv_len, float scale, void* ws, size_t ws_bytes, void* stream) {
+  AttnDecodeArgs a{};
+  a.Q = q; a.q_sb = (int64_t)Hq * 128; a.q_sh = 128;
+  a.K = k; a.k_sb = (int64_t)Hkv * cap * 128; a.k_sh = (int64_t)cap * 128; a.k_sr = 128;
+  a.V = v; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+  a.O = out; a.o_sb = a.q_sb; a.o_sh = 128;
+  a.batch = b; a.q_heads = Hq; a.kv_heads = Hkv; a.L = L; a.kv_len = kv_len; a.scale = scale; a.ws = (float*)ws; a.ws_bytes = ws_bytes;
+  return launch_attn_decode(dtype, a, S(stream));
+}
+
+extern "C" int omchat_op_rope_kv(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
+                                 void* stream) {
+  OM_CHECK(pos0 + Sq <= cap, "positions exceed cache capacity");
+  const int max_pos = pos0 + Sq;
+  std::vector<float> tab((size_t)max_pos * 128);
+  for (int i = 0; i < 64; ++i) {
+    const float inv = (float)(1.0 / pow((double)theta, (double)((float)(2 * i) / 128.0f)));
+    for (int p = 0; p < max_pos; ++p) {
+      const float ang = (float)p * inv;
+      tab[((size_t)p * 64 + i) * 2] = (float)cos((double)ang);
+      tab[((size_t)p * 64 + i) * 2 + 1] = (float)sin((double)ang);
+    }
+  }
+  float* d = nullptr;
+  OM_HIP(hipMalloc(&d, tab.size() * 4));
+  OM_HIP(hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  RopeArgs r{qkv, (Hq + 2 * Hkv) * 128, b * Sq, Sq, Hq, Hkv, nullptr, pos0, d, max_pos, kcache, vcache, (int64_t)Hkv * cap * 128, (int64_t)cap * 128};
+  int rc = launch_rope_kv(dtype, r, S(stream));
+  hipStreamSynchronize(S(stream));
+  hipFree(d);
+  return rc;
+}
+
+extern "C" int omchat_op_argmax(const float* logits, int b, int V, int32_t* out, void* stream) {
+  return launch_argmax(logits, V, b, V, out, S(stream));
+}
+
+extern "C" int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, void* stream) {
+  return launch_fill_uniform(dtype, dst, n, key, scale, offset, S(stream));
+}
+
+// FlashAttention.forward(qkv[B,S,3,H,D]) -> out[B,S,H,D]  (intern_vit_6b/flash_attention.py:30-75); D = 128 only.
+extern "C" int omchat_mha_fwd(const void* qkv, int B, int Sq, int H, float softmax_scale, int causal, void* out, int dtype, void* stream) {
+  OM_CHECK(qkv && out, "null argument");
+  AttnArgs a{};
+  const int64_t row = (int64_t)3 * H * 128;
+  a.Q = qkv; a.q_sb = Sq * row; a.q_sh = 128; a.q_sr = row;
+  a.K = (const char*)qkv + (size_t)H * 128 * 2; a.k_sb = a.q_sb; a.k_sh = 128; a.k_sr = row;
+  a.V = (const char*)qkv + (size_t)2 * H * 128 * 2; a.v_sb = a.q_sb; a.v_sh = 128; a.v_sr = row;
+  a.O = out; a.o_sb = (int64_t)Sq * H * 128; a.o_sh = 128; a.o_sr = (int64_t)H * 128;
+  a.batch = B; a.q_heads = H; a.kv_heads = H; a.Sq = Sq; a.Skv = Sq; a.kv_len = nullptr; a.causal = causal; a.q_pos0 = 0;
+  a.scale = softmax_scale > 0.f ? softmax_scale : 0.08838834764831845f;
+  return launch_attn_prefill(dtype, a, S(stream));
+}

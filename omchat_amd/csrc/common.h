@@ -1,0 +1,83 @@
+// Common device/host helpers for the OmChat gfx950 kernels.  MI355X (CDNA4) only: wave = 64 lanes,
+// MFMA 16x16x32 f16/bf16, 160 KiB LDS per CU.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+enum { OMCHAT_F16 = 0, OMCHAT_BF16 = 1 };
+
+template <typename T> struct V8;
+template <> struct V8<f16> { typedef f16x8 type; typedef f16x4 half_type; };
+template <> struct V8<bf16> { typedef bf16x8 type; typedef bf16x4 half_type; };
+
+// D[16x16] += A[16x32] * B[32x16].  Lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15],
+// D[row 4(l>>4)+r][col l&15]  (cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float tof(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T fromf(float x) { return (T)x; }
+// round a float through the storage type (the reference rounds after every op in fp16)
+template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)((T)x); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 16-byte global load / store of 8 16-bit elements
+template <typename T> __device__ __forceinline__ typename V8<T>::type ld8(const T* p) {
+  return *reinterpret_cast<const typename V8<T>::type*>(p);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, typename V8<T>::type v) {
+  *reinterpret_cast<typename V8<T>::type*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+void omchat_set_error(const std::string& s);
+#define OM_CHECK(cond, msg)                                                         \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      omchat_set_error(std::string(__func__) + ": " + (msg));                       \
+      return 1;                                                                     \
+    }                                                                               \
+  } while (0)
+#define OM_HIP(call)                                                                \
+  do {                                                                              \
+    hipError_t e_ = (call);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      omchat_set_error(std::string(__func__) + ": " #call " -> " + hipGetErrorString(e_)); \
+      return 2;                                                                     \
+    }                                                                               \
+  } while (0)
+#define OM_LAUNCH_CHECK() OM_HIP(hipGetLastError())
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,404 @@
+// HBM-bound row kernels of the hot path: RMSNorm, ViT joint-head q/k norm, RoPE + KV-cache append, patch im2col,
+// CLS/pos-embed assembly, splice gather, argmax, synthetic fill.  All 16-bit traffic is 16 B per lane.
+#include "kernels.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int NORM_THREADS = 256;
+constexpr int NORM_MAXC = 8;     // chunks of 8 elements per thread -> H <= 256*8*8 = 16384
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NORM_THREADS / 64; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RMSNorm: InternRMSNorm.forward (modeling_intern_vit.py:39-44) == Qwen2RMSNorm.forward (modeling_qwen2.py:247-252)
+// fp32 statistics, y = T( w * T(x * rsqrt(mean(x^2) + eps)) )   (two roundings, N2)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int ldx, const T* w, T* y, int ldy, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  const T* xr = x + (size_t)row * ldx;
+  T* yr = y + (size_t)row * ldy;
+  const int nchunk = H >> 3;
+  v8 xv[NORM_MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      xv[i] = ld8<T>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = tof(xv[i][j]); ss += f * f; }
+    }
+  }
+  const float inv = rsqrtf(block_sum(ss, red) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 wv = ld8<T>(w + c * 8);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(tof(xv[i][j]) * inv));
+      st8<T>(yr + c * 8, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ViT q/k norm over ALL heads of a token (modeling_intern_vit.py:143-146), in place on the fused qkv row, followed by
+// q * head_dim^-0.5 rounded in the storage type exactly where _naive_attn does it (:148).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void vit_qknorm_kernel(T* qkv, int ld, const T* wq, const T* wk, int C, int C_total,
+                                                                  float eps, float q_scale, const float* sumsq_in) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  const int nchunk = C >> 3;
+#pragma unroll 1
+  for (int part = 0; part < 2; ++part) {       // 0 = q, 1 = k
+    T* xr = qkv + (size_t)row * ld + part * C;
+    const T* w = part == 0 ? wq : wk;
+    v8 xv[NORM_MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+        xv[i] = ld8<T>(xr + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = tof(xv[i][j]); ss += f * f; }
+      }
+    }
+    float tot = sumsq_in ? sumsq_in[row * 2 + part] : block_sum(ss, red);
+    const float inv = rsqrtf(tot / (float)C_total + eps);
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+        const v8 wv = ld8<T>(w + c * 8);
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = rnd<T>(tof(wv[j]) * rnd<T>(tof(xv[i][j]) * inv));
+          if (part == 0) v = v * q_scale;
+          o[j] = fromf<T>(v);
+        }
+        st8<T>(xr + c * 8, o);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv, int ld, int C, float* out) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  for (int part = 0; part < 2; ++part) {
+    const T* xr = qkv + (size_t)row * ld + part * C;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < (C >> 3); c += NORM_THREADS) {
+      const v8 v = ld8<T>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = tof(v[j]); ss += f * f; }
+    }
+    const float tot = block_sum(ss, red);
+    if (threadIdx.x == 0) out[row * 2 + part] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RoPE (rotate-half, modeling_qwen2.py:105-135; cos/sin fp32 table cast to T before the multiply, N11) on q (in place)
+// and k (written to the cache, N14), raw v copied to the cache.  One 16-lane group per (row, head): lane c owns
+// elements [8c, 8c+8) and pairs with the chunk 64 elements away.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, int S, int nq, int nkv, const int* pos, int pos0,
+                                                      const float* cos_sin, int max_pos, T* kc, T* vc, int64_t c_sb, int64_t c_sh) {
+  typedef typename V8<T>::type v8;
+  const int nh = nq + 2 * nkv;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long item = gid >> 4;                       // (row, head)
+  const int c = gid & 15;                           // 8-element chunk inside the head
+  if (item >= (long)rows * nh) return;
+  const int row = (int)(item / nh), h = (int)(item % nh);
+  const int bi = row / S;
+  int pp = pos ? pos[row] : pos0 + (row % S);
+  T* src = qkv + (size_t)row * ld + h * 128;
+  if (h >= nq + nkv) {                              // v: plain copy into the cache
+    const int kvh = h - nq - nkv;
+    st8<T>(vc + bi * c_sb + kvh * c_sh + (int64_t)pp * 128 + c * 8, ld8<T>(src + c * 8));
+    return;
+  }
+  const int pt = pp < max_pos ? pp : max_pos - 1;
+  const v8 x = ld8<T>(src + c * 8);
+  const v8 o = ld8<T>(src + ((c + 8) & 15) * 8);    // partner chunk (d +- 64)
+  const float sgn = c < 8 ? -1.f : 1.f;             // rotate_half: first half gets -x2, second half +x1
+  const float* cs = cos_sin + ((size_t)pt * 64 + (c & 7) * 8) * 2;
+  v8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
+    const float a = rnd<T>(tof(x[j]) * co);
+    const float b = rnd<T>(sgn * tof(o[j]) * si);
+    r[j] = fromf<T>(a + b);
+  }
+  if (h < nq) {
+    // every lane of the 16-lane group has read both chunks before anyone writes (same wave, program order)
+    st8<T>(src + c * 8, r);
+  } else {
+    const int kvh = h - nq;
+    st8<T>(kc + bi * c_sb + kvh * c_sh + (int64_t)pp * 128 + c * 8, r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// patch embed helpers (InternVisionEmbeddings.forward, modeling_intern_vit.py:90-102)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_kernel(const T* px, T* cols, int B, int HW, int patch, int Kpad) {
+  const int g = HW / patch;
+  const long n = (long)B * g * g * Kpad;
+  const int K = 3 * patch * patch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kpad);
+    const long m = i / Kpad;
+    T v = (T)0.f;
+    if (k < K) {
+      const int b = (int)(m / (g * g)), pp = (int)(m % (g * g)), py = pp / g, pxx = pp % g;
+      const int ch = k / (patch * patch), kk = k % (patch * patch), ky = kk / patch, kx = kk % patch;
+      v = px[(((size_t)b * 3 + ch) * HW + py * patch + ky) * HW + pxx * patch + kx];
+    }
+    cols[i] = v;
+  }
+}
+
+template <typename T>
+__global__ void vit_assemble_kernel(const T* pe, const T* cls, const T* pos, T* x, int B, int np, int C) {
+  typedef typename V8<T>::type v8;
+  const int cc = C >> 3;
+  const long n = (long)B * (np + 1) * cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc);
+    const long rt = i / cc;
+    const int t = (int)(rt % (np + 1)), b = (int)(rt / (np + 1));
+    const v8 a = t == 0 ? ld8<T>(cls + c * 8) : ld8<T>(pe + ((size_t)b * np + (t - 1)) * C + c * 8);
+    const v8 p = ld8<T>(pos + (size_t)t * C + c * 8);
+    v8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(a[j]) + tof(p[j]));
+    st8<T>(x + ((size_t)b * (np + 1) + t) * C + c * 8, o);
+  }
+}
+
+// splice gather (omchat_arch.py:133-158,172-195): pure row copies
+template <typename T>
+__global__ void gather_rows_kernel(const int* idx, const T* table, const T* feats, T* out, int rows, int H) {
+  typedef typename V8<T>::type v8;
+  const int cc = H >> 3;
+  const long n = (long)rows * cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc);
+    const int r = (int)(i / cc);
+    const int id = idx[r];
+    v8 v;
+    if (id == INT_MIN) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    } else if (id >= 0) {
+      v = ld8<T>(table + (size_t)id * H + c * 8);
+    } else {
+      v = ld8<T>(feats + (size_t)(-1 - id) * H + c * 8);
+    }
+    st8<T>(out + (size_t)r * H + c * 8, v);
+  }
+}
+
+template <typename T>
+__global__ void copy_rows_kernel(const T* src, int64_t src_ld, T* dst, int64_t dst_ld, int rows, int H, int group, int skip) {
+  typedef typename V8<T>::type v8;
+  const int cc = H >> 3;
+  const long n = (long)rows * cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc);
+    const long r = i / cc;
+    const long sr = (r / group) * (group + skip) + skip + r % group;
+    st8<T>(dst + r * dst_ld + c * 8, ld8<T>(src + sr * src_ld + c * 8));
+  }
+}
+
+// greedy argmax over fp32 logits, first index wins ties (torch.argmax semantics)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* logits, int ld, int V, int* out) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const float* row = logits + (size_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int besti = INT_MAX;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    const float v = row[i];
+    if (v > best || (v == best && i < besti) || besti == INT_MAX) { best = v; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+    out[blockIdx.x] = besti;
+  }
+}
+
+// omchat_amd/synth.py::uniform, bit for bit
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+template <typename T>
+__global__ void fill_uniform_kernel(T* dst, int64_t n, uint64_t key, float mul, float offset) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t h = splitmix64(key + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+    const int iv = (int)(h >> 40) - (1 << 23);
+    float v = __fmul_rn((float)iv, mul);
+    if (offset != 0.f) v = __fadd_rn(v, offset);
+    // round to bf16 (RNE), keep only values exact in fp16
+    uint32_t u = __float_as_uint(v);
+    u = ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16) << 16;
+    float f = __uint_as_float(u);
+    if ((float)((f16)f) != f) f = 0.f;
+    dst[i] = (T)f;
+  }
+}
+
+template <typename T>
+__global__ void cast_f32_kernel(const T* src, float* dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = tof(src[i]);
+}
+
+inline int grid_for(long n, int threads) {
+  long g = (n + threads - 1) / threads;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL)                                        \
+  if ((dtype) == OMCHAT_F16) { typedef f16 T; CALL; }                \
+  else if ((dtype) == OMCHAT_BF16) { typedef bf16 T; CALL; }         \
+  else { omchat_set_error("bad dtype"); return 1; }
+
+int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, H, eps));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total, float eps,
+                      float q_scale, const float* sumsq_in, hipStream_t s) {
+  OM_CHECK(C % 8 == 0 && C <= NORM_THREADS * NORM_MAXC * 8 && ld % 8 == 0, "C % 8, C <= 16384, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
+                                     C, C_total, eps, q_scale, sumsq_in));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vit_qk_sumsq(int dtype, const void* qkv, int ld, int rows, int C, float* out, hipStream_t s) {
+  OM_CHECK(C % 8 == 0 && ld % 8 == 0, "C % 8, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_qk_sumsq_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)qkv, ld, C, out));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s) {
+  OM_CHECK(a.ld % 8 == 0 && a.cos_sin && a.kcache && a.vcache, "bad args");
+  if (a.rows == 0) return 0;
+  const long items = (long)a.rows * (a.nq + 2 * a.nkv) * 16;
+  DISPATCH(dtype, hipLaunchKernelGGL(rope_kv_kernel<T>, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, s, (T*)a.qkv, a.ld, a.rows, a.S,
+                                     a.nq, a.nkv, a.pos, a.pos0, a.cos_sin, a.max_pos, (T*)a.kcache, (T*)a.vcache, a.c_sb, a.c_sh));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_im2col(int dtype, const void* pixels, void* cols, int B, int HW, int patch, int Kpad, hipStream_t s) {
+  OM_CHECK(HW % patch == 0 && Kpad >= 3 * patch * patch, "bad geometry");
+  const int g = HW / patch;
+  const long n = (long)B * g * g * Kpad;
+  if (n == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const T*)pixels, (T*)cols, B, HW, patch, Kpad));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vit_assemble(int dtype, const void* pe, const void* cls, const void* pos, void* x, int B, int np, int C, hipStream_t s) {
+  OM_CHECK(C % 8 == 0, "C % 8");
+  const long n = (long)B * (np + 1) * (C / 8);
+  if (n == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_assemble_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const T*)pe, (const T*)cls, (const T*)pos, (T*)x, B, np, C));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gather_rows(int dtype, const int* idx, const void* table, const void* feats, void* out, int rows, int H, hipStream_t s) {
+  OM_CHECK(H % 8 == 0, "H % 8");
+  const long n = (long)rows * (H / 8);
+  if (n == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, idx, (const T*)table, (const T*)feats, (T*)out, rows, H));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int rows, int H, int group, int skip, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && src_ld % 8 == 0 && dst_ld % 8 == 0 && group > 0, "H/ld % 8, group > 0");
+  const long n = (long)rows * (H / 8);
+  if (n == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const T*)src, src_ld, (T*)dst, dst_ld, rows, H, group, skip));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_argmax(const float* logits, int ld, int b, int V, int* out, hipStream_t s) {
+  if (b == 0) return 0;
+  hipLaunchKernelGGL(argmax_kernel, dim3(b), dim3(1024), 0, s, logits, ld, V, out);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, hipStream_t s) {
+  if (n == 0) return 0;
+  const float mul = scale / 8388608.0f;
+  DISPATCH(dtype, hipLaunchKernelGGL(fill_uniform_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, (T*)dst, n, key, mul, offset));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cast_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(cast_f32_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const T*)src, dst, n));
+  OM_LAUNCH_CHECK();
+  return 0;
+}

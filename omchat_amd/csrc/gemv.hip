@@ -1,0 +1,171 @@
+// Weight-streaming skinny GEMM for decode:  Y[b,N] = epi(X[b,K] @ W[N,K]^T), b <= 16.  HBM-bound: every weight byte
+// is read exactly once, straight from global memory into MFMA A-operand registers (no LDS round trip:
+// cdna_hip_programming.md §5 "GEMV / M <= 16 decode weights").
+//
+// Replaces the decode-step `nn.Linear`s of transformers' Qwen2 (q/k/v/o/gate/up/down/lm_head with M = batch).
+//
+// One workgroup = 8 waves = NTILE*16 weight rows.  Wave w walks 64-wide K chunks w, w+8, w+16, ... : per chunk a
+// lane loads 2 x 16 B of its weight row (A operand, row = lane&15, k = 8*(lane>>4)+j) and 2 x 16 B of x (B operand,
+// column = batch row = lane&15; lanes >= b feed zeros), then 2 MFMA 16x16x32.  UNROLL chunks are in flight per wave
+// (8 waves x UNROLL x 2 KiB per workgroup).  The 8 partial 16x16 fp32 tiles are summed through LDS in a fixed order
+// (deterministic, no atomics), and wave 0 applies the epilogue.
+#include "kernels.h"
+
+namespace {
+
+struct GemvP {
+  const void* X; const void* W; void* Y; const void* bias; const void* resid;
+  int ldx, ldw, ldy, ldr, b, N, K, out_f32;
+};
+
+constexpr int GV_WAVES = 8;
+constexpr int GV_UNROLL = 4;
+
+template <typename T, int NTILE, int EPI>
+__global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ float red[GV_WAVES][NTILE][256];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * (NTILE * 16);
+
+  const T* W = (const T*)p.W;
+  const T* X = (const T*)p.X;
+  const T* wrow[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    int r = n0 + t * 16 + fr; r = r < p.N ? r : p.N - 1;
+    wrow[t] = W + (size_t)r * p.ldw + fg * 8;
+  }
+  const bool xvalid = fr < p.b;
+  const T* xrow = X + (size_t)(xvalid ? fr : 0) * p.ldx + fg * 8;
+
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = p.K / 64;
+  frag_t zero;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+
+  int c0 = wave;
+  // full groups: no per-load predicate (a runtime select around each load would serialise them)
+  for (; c0 + (GV_UNROLL - 1) * GV_WAVES < nchunk; c0 += GV_WAVES * GV_UNROLL) {
+    frag_t wf[GV_UNROLL][NTILE][2], xf[GV_UNROLL][2];
+#pragma unroll
+    for (int u = 0; u < GV_UNROLL; ++u) {
+      const int k = (c0 + u * GV_WAVES) * 64;
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        wf[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k));
+        wf[u][t][1] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k + 32));
+      }
+      xf[u][0] = ld8<T>(xrow + k);
+      xf[u][1] = ld8<T>(xrow + k + 32);
+    }
+#pragma unroll
+    for (int u = 0; u < GV_UNROLL; ++u) {
+      if (!xvalid) { xf[u][0] = zero; xf[u][1] = zero; }
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        acc[t] = mfma16(wf[u][t][0], xf[u][0], acc[t]);
+        acc[t] = mfma16(wf[u][t][1], xf[u][1], acc[t]);
+      }
+    }
+  }
+  for (; c0 < nchunk; c0 += GV_WAVES) {
+    const int k = c0 * 64;
+    frag_t x0 = ld8<T>(xrow + k), x1 = ld8<T>(xrow + k + 32);
+    if (!xvalid) { x0 = zero; x1 = zero; }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      acc[t] = mfma16(ld8<T>(wrow[t] + k), x0, acc[t]);
+      acc[t] = mfma16(ld8<T>(wrow[t] + k + 32), x1, acc[t]);
+    }
+  }
+
+  // acc[t][r] = Y^T[n = n0 + t*16 + 4*fg + r][batch = fr]
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][(fg * 4 + r) * 16 + fr] = acc[t][r];
+  __syncthreads();
+  if (wave != 0) return;
+
+  // wave 0: lane -> 4 (n, batch) pairs per tile; element e = lane + 64*i : n_local = e >> 4, batch = e & 15
+  float v[NTILE][4];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < GV_WAVES; ++w) s += red[w][t][lane + 64 * i];
+      v[t][i] = s;
+    }
+  const T* bias = (const T*)p.bias;
+  const T* R = (const T*)p.resid;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = lane + 64 * i, nl = e >> 4, bi = e & 15;
+    if (bi >= p.b) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      // tile 0 = 16 gate rows, tile 1 = the matching 16 up rows
+      const int n = (n0 >> 1) + nl;
+      if (n0 + 16 + nl < p.N) {
+        const float g = rnd<T>(v[0][i]), u = rnd<T>(v[1][i]);
+        ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(rnd<T>(silu(g)) * u);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = n0 + t * 16 + nl;
+        if (n >= p.N) continue;
+        float y = v[t][i] + (bias ? tof(bias[n]) : 0.f);
+        if (p.out_f32) {
+          ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
+        } else {
+          y = rnd<T>(y);
+          if constexpr (EPI == EPI_RESID) y = tof(R[(size_t)bi * p.ldr + n]) + y;
+          ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_t(const GemvArgs& a, hipStream_t s) {
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32};
+  if (a.epi == EPI_SWIGLU) {
+    hipLaunchKernelGGL((gemv_kernel<T, 2, EPI_SWIGLU>), dim3(cdiv(a.N, 32)), dim3(GV_WAVES * 64), 0, s, p);
+  } else if (a.epi == EPI_RESID) {
+    hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_RESID>), dim3(cdiv(a.N, 16)), dim3(GV_WAVES * 64), 0, s, p);
+  } else {
+    // wide outputs (lm_head, fused qkv): 2 tiles per workgroup halves the x re-reads
+    if (a.N >= 16384)
+      hipLaunchKernelGGL((gemv_kernel<T, 2, EPI_NONE>), dim3(cdiv(a.N, 32)), dim3(GV_WAVES * 64), 0, s, p);
+    else
+      hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_NONE>), dim3(cdiv(a.N, 16)), dim3(GV_WAVES * 64), 0, s, p);
+  }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
+  OM_CHECK(a.b >= 1 && a.b <= 16, "batch must be 1..16 per call");
+  OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
+  OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU, "bad epilogue");
+  OM_CHECK(a.epi != EPI_RESID || a.resid, "resid missing");
+  OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU needs N % 32 == 0");
+  OM_CHECK(!(a.out_f32 && a.epi != EPI_NONE), "fp32 output only with EPI_NONE");
+  if (dtype == OMCHAT_F16) return launch_t<f16>(a, s);
+  if (dtype == OMCHAT_BF16) return launch_t<bf16>(a, s);
+  omchat_set_error("launch_gemv: bad dtype");
+  return 1;
+}

@@ -1,0 +1,113 @@
+// Internal launcher interface (C++) shared by the op-level C ABI (capi.cpp) and the model loops (model.cpp).
+// Every launcher enqueues on `stream` and returns 0 / sets omchat_last_error().  dtype: OMCHAT_F16 | OMCHAT_BF16.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// C[M,N] = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulate on MFMA.  K % 64 == 0, lda/ldw % 8 == 0.
+enum {
+  EPI_NONE = 0,      // C = T(acc + bias?)
+  EPI_GELU = 1,      // C = T(gelu_erf(T(acc + bias?)))                       (InternMLP fc1, projector linear_1)
+  EPI_LS_RESID = 2,  // C = T(resid + T(T(acc + bias?) * ls))                 (ViT: x + branch * ls)
+  EPI_RESID = 3,     // C = T(resid + T(acc + bias?))                         (decoder o_proj / down_proj)
+  EPI_SWIGLU = 4,    // W rows interleaved [16 gate | 16 up]: C[M,N/2] = T(T(silu(T(g))) * T(u))
+};
+struct GemmArgs {
+  const void* A; int lda;
+  const void* W; int ldw;
+  void* C; int ldc;
+  int M, N, K;
+  const void* bias;   // [N] or null
+  const void* ls;     // [N] layer-scale (EPI_LS_RESID)
+  const void* resid;  // [M, ldr] (EPI_LS_RESID / EPI_RESID); may alias C
+  int ldr;
+  int epi;
+  int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256
+};
+int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------ skinny GEMM (decode)
+// Y[b,N] = epilogue(X[b,K] @ W[N,K]^T) for b <= 16: weight-streaming, HBM-bound.  K % 64 == 0.
+struct GemvArgs {
+  const void* X; int ldx;
+  const void* W; int ldw;
+  void* Y; int ldy;         // T, or float when out_f32
+  int b, N, K;
+  const void* bias;
+  const void* resid; int ldr;
+  int epi;                  // EPI_NONE | EPI_RESID | EPI_SWIGLU
+  int out_f32;
+};
+int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------ norms
+// y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)
+int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s);
+// ViT joint-head q/k RMSNorm in place on the fused qkv buffer [rows, 3C] (q = cols [0,C), k = [C,2C)); q is also
+// multiplied by q_scale with the reference's rounding (modeling_intern_vit.py:143-148).
+// sumsq_in: optional [rows,2] fp32 externally reduced sum of squares (tensor parallel); C_total = divisor.
+int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total,
+                      float eps, float q_scale, const float* sumsq_in, hipStream_t s);
+int launch_vit_qk_sumsq(int dtype, const void* qkv, int ld, int rows, int C, float* sumsq_out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ attention
+struct AttnArgs {
+  const void* Q; int64_t q_sb, q_sh, q_sr;     // strides in elements: batch, head, row(token)
+  const void* K; int64_t k_sb, k_sh, k_sr;
+  const void* V; int64_t v_sb, v_sh, v_sr;
+  void* O; int64_t o_sb, o_sh, o_sr;
+  int batch, q_heads, kv_heads;
+  int Sq, Skv;              // common lengths; per-batch overrides below
+  const int* kv_len;        // optional device [batch] (valid keys per sequence), null -> Skv
+  int causal;               // key j visible to query i iff j < kv_len and (!causal or j <= i + q_pos0)
+  int q_pos0;               // absolute position of query row 0 (0 for a fresh prefill)
+  float scale;              // applied to scores in fp32
+};
+int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s);
+
+// decode: one query token per sequence, q heads grouped per kv head; split-KV partials + merge.
+struct AttnDecodeArgs {
+  const void* Q; int64_t q_sb, q_sh;            // [b, q_heads, 128]
+  const void* K; int64_t k_sb, k_sh, k_sr;      // cache [b, kv_heads, L, 128]
+  const void* V; int64_t v_sb, v_sh, v_sr;
+  void* O; int64_t o_sb, o_sh;                  // [b, q_heads, 128]
+  int batch, q_heads, kv_heads;
+  int L;                                        // kv length used when kv_len == null
+  const int* kv_len;                            // optional device [batch]
+  float scale;
+  float* ws; size_t ws_bytes;                   // workspace for partials
+};
+size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len);
+int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ RoPE + KV append
+// qkv [rows, (nq + 2 nkv) * 128] post-bias; rotate q in place, write rotated k and raw v into the caches at
+// position pos[row] of sequence seq[row] (rows are b-major: row = b_idx * S + s).
+struct RopeArgs {
+  void* qkv; int ld;
+  int rows, S;                 // rows = b * S
+  int nq, nkv;
+  const int* pos;              // device [rows] absolute positions, or null -> pos0 + (row % S)
+  int pos0;
+  const float* cos_sin;        // table [max_pos][64][2] fp32 (cos, sin)
+  int max_pos;
+  void* kcache; void* vcache;  // [b, nkv, cap, 128]
+  int64_t c_sb, c_sh;          // cache strides (elements); row stride 128
+};
+int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------ data movement
+// im2col for Conv2d(3->C, k=p, s=p): pixels [B,3,HW,HW] -> cols [B*g*g, Kpad] (zero padded K)
+int launch_im2col(int dtype, const void* pixels, void* cols, int B, int HW, int patch, int Kpad, hipStream_t s);
+// x[b, 0] = cls + pos[0];  x[b, 1+p] = pe[b*np + p] + pos[1+p]
+int launch_vit_assemble(int dtype, const void* pe, const void* cls, const void* pos, void* x, int B, int np, int C, hipStream_t s);
+// out[r] = table[idx[r]] (idx >= 0) | feats[-1 - idx[r]] (idx <= -1, > PAD) | 0 (idx == INT_MIN)
+int launch_gather_rows(int dtype, const int* idx, const void* table, const void* feats, void* out, int rows, int H, hipStream_t s);
+// strided row copy (drop CLS etc.): dst[r] = src[map(r)]
+int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int rows, int H,
+                     int group, int skip, hipStream_t s);   // src row = (r / group) * (group + skip) + skip + r % group
+// argmax over fp32 logits [b, V] -> int32 [b] (first index wins ties)
+int launch_argmax(const float* logits, int ld, int b, int V, int* out, hipStream_t s);
+// deterministic synthetic fill (bit-identical to omchat_amd/synth.py::uniform)
+int launch_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, hipStream_t s);
+int launch_cast_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);

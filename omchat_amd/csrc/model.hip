@@ -1,0 +1,738 @@
+// Model-level loops of the OmChat hot path on one GPU (one tensor-parallel rank): context, weight routing, workspaces,
+// KV cache, and the kernel sequences for the vision tower, projector, prefill and decode.  Host C++; every FLOP runs
+// in the HIP kernels of this directory.
+#include "kernels.h"
+#include "../../include/omchat_hip.h"
+#include <rccl/rccl.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local std::string g_err;
+void omchat_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* omchat_last_error(void) { return g_err.c_str(); }
+extern "C" const char* omchat_version(void) { return "omchat_hip 0.1 (gfx950)"; }
+
+namespace {
+
+__global__ void cast_from_f32_f16(const float* s, f16* d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (f16)s[i];
+}
+__global__ void cast_from_f32_bf16(const float* s, bf16* d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (bf16)s[i];
+}
+__global__ void advance_lens_kernel(int* pos, int* len, int b) {
+  const int i = threadIdx.x;
+  if (i < b) { pos[i] += 1; len[i] += 1; }
+}
+__global__ void last_row_index_kernel(const int* len, int S, int b, int* idx) {
+  const int i = threadIdx.x;
+  if (i < b) idx[i] = i * S + len[i] - 1;
+}
+
+enum RouteKind { R_PLAIN = 0, R_GATE = 1, R_UP = 2, R_PATCH = 3 };
+struct Route {
+  void* dst = nullptr;
+  int64_t rows = 0, cols = 0;     // logical source shape (2-D view)
+  int64_t dst_ld = 0;             // destination row stride (elements)
+  int kind = R_PLAIN;
+  bool loaded = false;
+  float synth_std = 0.02f, synth_off = 0.f;
+};
+
+}  // namespace
+
+struct omchat_ctx {
+  omchat_config c;
+  int dt = OMCHAT_BF16;
+  int tp_rank = 0, tp_size = 1;
+  ncclComm_t comm = nullptr;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  std::unordered_map<std::string, Route> routes;
+
+  // derived geometry
+  int v_np = 0, v_ntok = 0, v_Cq = 0, v_kpad = 0;
+  int t_qdim = 0, t_kvdim = 0, t_qkvdim = 0;
+
+  // weights (device, compute dtype)
+  struct VitLayer { void *ls1, *ls2, *n1, *n2, *wqkv, *qn, *kn, *wproj, *bproj, *w1, *b1, *w2, *b2; };
+  struct DecLayer { void *ln1, *ln2, *wqkv, *bqkv, *wo, *wgu, *wd; };
+  void *v_cls = nullptr, *v_pos = nullptr, *v_wpatch = nullptr, *v_bpatch = nullptr;
+  std::vector<VitLayer> vl;
+  void *p_w0 = nullptr, *p_b0 = nullptr, *p_w2 = nullptr, *p_b2 = nullptr;
+  void *t_embed = nullptr, *t_norm = nullptr, *t_lm = nullptr;
+  std::vector<DecLayer> dl;
+  float* rope = nullptr;          // [max_seq][64][2]
+
+  // workspaces
+  void *vw_cols = nullptr, *vw_pe = nullptr, *vw_x = nullptr, *vw_x2 = nullptr, *vw_xn = nullptr, *vw_qkv = nullptr, *vw_ao = nullptr,
+       *vw_h = nullptr, *vw_feat = nullptr, *vw_proj = nullptr;
+  float* vw_sumsq = nullptr;
+  void *tw_x = nullptr, *tw_x2 = nullptr, *tw_xn = nullptr, *tw_qkv = nullptr, *tw_ao = nullptr, *tw_act = nullptr, *tw_last = nullptr;
+  float* tw_logits = nullptr;
+  float* tw_attn_ws = nullptr;
+  size_t tw_attn_ws_bytes = 0;
+  int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr;
+  void *kcache = nullptr, *vcache = nullptr;   // [layers][max_batch][kv_heads][max_seq][128]
+  std::vector<int> h_len;
+  void* stage_f32 = nullptr; size_t stage_f32_bytes = 0;
+  void* stage_t = nullptr; size_t stage_t_bytes = 0;
+
+  int alloc(void** p, size_t n) {
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess) { omchat_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e)); return 2; }
+    allocs.push_back(*p);
+    bytes += n;
+    return 0;
+  }
+  size_t esz() const { return 2; }
+  int64_t cache_layer_stride() const { return (int64_t)c.max_batch * c.t_kv_heads * c.max_seq * 128; }
+  int64_t cache_sb() const { return (int64_t)c.t_kv_heads * c.max_seq * 128; }
+  int64_t cache_sh() const { return (int64_t)c.max_seq * 128; }
+
+  int allreduce(void* buf, size_t count, hipStream_t s) {
+    if (tp_size == 1) return 0;
+    ncclResult_t r = ncclAllReduce(buf, buf, count, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, ncclSum, comm, s);
+    if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
+    return 0;
+  }
+  int allreduce_f32(float* buf, size_t count, hipStream_t s) {
+    if (tp_size == 1) return 0;
+    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, s);
+    if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
+    return 0;
+  }
+};
+
+namespace {
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int add_route(omchat_ctx* ctx, const std::string& name, void** slot, int64_t rows, int64_t cols, float std_, float off,
+              int kind = R_PLAIN, void* dst_override = nullptr, int64_t dst_ld = -1) {
+  Route r;
+  r.rows = rows; r.cols = cols; r.kind = kind; r.synth_std = std_; r.synth_off = off;
+  if (dst_override) {
+    r.dst = dst_override;
+  } else {
+    TRY(ctx->alloc(&r.dst, (size_t)rows * cols * 2));
+    if (slot) *slot = r.dst;
+  }
+  r.dst_ld = dst_ld < 0 ? cols : dst_ld;
+  ctx->routes[name] = r;
+  return 0;
+}
+
+int build(omchat_ctx* ctx) {
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, I = c.v_mlp;
+  ctx->v_np = (c.v_image / c.v_patch) * (c.v_image / c.v_patch);
+  ctx->v_ntok = ctx->v_np + 1;
+  ctx->v_Cq = c.v_heads * 128;
+  const int K = 3 * c.v_patch * c.v_patch;
+  ctx->v_kpad = cdiv(K, 64) * 64;
+  const std::string TW = "model.vision_tower.vision_tower.";
+
+  // ---- vision tower weights
+  if (c.v_layers > 0) {
+    TRY(add_route(ctx, TW + "embeddings.class_embedding", &ctx->v_cls, 1, C, 0.02f, 0.f));
+    TRY(add_route(ctx, TW + "embeddings.position_embedding", &ctx->v_pos, ctx->v_ntok, C, 0.02f, 0.f));
+    TRY(ctx->alloc(&ctx->v_wpatch, (size_t)C * ctx->v_kpad * 2));
+    OM_HIP(hipMemset(ctx->v_wpatch, 0, (size_t)C * ctx->v_kpad * 2));
+    TRY(add_route(ctx, TW + "embeddings.patch_embedding.weight", nullptr, C, K, 0.02f, 0.f, R_PATCH, ctx->v_wpatch, ctx->v_kpad));
+    TRY(add_route(ctx, TW + "embeddings.patch_embedding.bias", &ctx->v_bpatch, 1, C, 0.02f, 0.f));
+    ctx->vl.resize(c.v_layers);
+    for (int j = 0; j < c.v_layers; ++j) {
+      const std::string P = TW + "encoder.layers." + std::to_string(j) + ".";
+      auto& L = ctx->vl[j];
+      TRY(add_route(ctx, P + "ls1", &L.ls1, 1, C, 0.02f, 0.1f));
+      TRY(add_route(ctx, P + "ls2", &L.ls2, 1, C, 0.02f, 0.1f));
+      TRY(add_route(ctx, P + "norm1.weight", &L.n1, 1, C, 0.05f, 1.f));
+      TRY(add_route(ctx, P + "norm2.weight", &L.n2, 1, C, 0.05f, 1.f));
+      TRY(add_route(ctx, P + "attn.qkv.weight", &L.wqkv, 3 * ctx->v_Cq, C, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "attn.q_norm.weight", &L.qn, 1, ctx->v_Cq, 0.05f, 1.f));
+      TRY(add_route(ctx, P + "attn.k_norm.weight", &L.kn, 1, ctx->v_Cq, 0.05f, 1.f));
+      TRY(add_route(ctx, P + "attn.proj.weight", &L.wproj, C, ctx->v_Cq, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "attn.proj.bias", &L.bproj, 1, C, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "mlp.fc1.weight", &L.w1, I, C, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "mlp.fc1.bias", &L.b1, 1, I, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "mlp.fc2.weight", &L.w2, C, I, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "mlp.fc2.bias", &L.b2, 1, C, 0.02f, 0.f));
+    }
+    const int H = c.t_hidden;
+    TRY(add_route(ctx, "model.mm_projector.0.weight", &ctx->p_w0, H, C, 0.02f, 0.f));
+    TRY(add_route(ctx, "model.mm_projector.0.bias", &ctx->p_b0, 1, H, 0.02f, 0.f));
+    TRY(add_route(ctx, "model.mm_projector.2.weight", &ctx->p_w2, H, H, 0.02f, 0.f));
+    TRY(add_route(ctx, "model.mm_projector.2.bias", &ctx->p_b2, 1, H, 0.02f, 0.f));
+  }
+
+  // ---- decoder weights (q/k/v fused; gate/up interleaved in 16-row blocks for the SwiGLU epilogue)
+  const int H = c.t_hidden, It = c.t_mlp;
+  ctx->t_qdim = c.t_heads * 128; ctx->t_kvdim = c.t_kv_heads * 128; ctx->t_qkvdim = ctx->t_qdim + 2 * ctx->t_kvdim;
+  if (c.t_layers > 0) {
+    OM_CHECK(It % 16 == 0, "t_mlp must be a multiple of 16");
+    TRY(add_route(ctx, "model.embed_tokens.weight", &ctx->t_embed, c.t_vocab_total, H, 0.02f, 0.f));
+    TRY(add_route(ctx, "model.norm.weight", &ctx->t_norm, 1, H, 0.05f, 1.f));
+    TRY(add_route(ctx, "lm_head.weight", &ctx->t_lm, c.t_vocab, H, 0.02f, 0.f));
+    ctx->dl.resize(c.t_layers);
+    for (int i = 0; i < c.t_layers; ++i) {
+      const std::string P = "model.layers." + std::to_string(i) + ".";
+      auto& L = ctx->dl[i];
+      TRY(ctx->alloc(&L.wqkv, (size_t)ctx->t_qkvdim * H * 2));
+      TRY(ctx->alloc(&L.bqkv, (size_t)ctx->t_qkvdim * 2));
+      TRY(ctx->alloc(&L.wgu, (size_t)2 * It * H * 2));
+      char* wq = (char*)L.wqkv; char* bq = (char*)L.bqkv;
+      TRY(add_route(ctx, P + "self_attn.q_proj.weight", nullptr, ctx->t_qdim, H, 0.02f, 0.f, R_PLAIN, wq));
+      TRY(add_route(ctx, P + "self_attn.k_proj.weight", nullptr, ctx->t_kvdim, H, 0.02f, 0.f, R_PLAIN, wq + (size_t)ctx->t_qdim * H * 2));
+      TRY(add_route(ctx, P + "self_attn.v_proj.weight", nullptr, ctx->t_kvdim, H, 0.02f, 0.f, R_PLAIN, wq + (size_t)(ctx->t_qdim + ctx->t_kvdim) * H * 2));
+      TRY(add_route(ctx, P + "self_attn.q_proj.bias", nullptr, 1, ctx->t_qdim, 0.02f, 0.f, R_PLAIN, bq));
+      TRY(add_route(ctx, P + "self_attn.k_proj.bias", nullptr, 1, ctx->t_kvdim, 0.02f, 0.f, R_PLAIN, bq + (size_t)ctx->t_qdim * 2));
+      TRY(add_route(ctx, P + "self_attn.v_proj.bias", nullptr, 1, ctx->t_kvdim, 0.02f, 0.f, R_PLAIN, bq + (size_t)(ctx->t_qdim + ctx->t_kvdim) * 2));
+      TRY(add_route(ctx, P + "self_attn.o_proj.weight", &L.wo, H, ctx->t_qdim, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "mlp.gate_proj.weight", nullptr, It, H, 0.02f, 0.f, R_GATE, L.wgu));
+      TRY(add_route(ctx, P + "mlp.up_proj.weight", nullptr, It, H, 0.02f, 0.f, R_UP, L.wgu));
+      TRY(add_route(ctx, P + "mlp.down_proj.weight", &L.wd, H, It, 0.02f, 0.f));
+      TRY(add_route(ctx, P + "input_layernorm.weight", &L.ln1, 1, H, 0.05f, 1.f));
+      TRY(add_route(ctx, P + "post_attention_layernorm.weight", &L.ln2, 1, H, 0.05f, 1.f));
+    }
+    // RoPE table: Qwen2RotaryEmbedding (modeling_qwen2.py:64-102): inv_freq and angles in fp32, cos/sin fp32
+    std::vector<float> tab((size_t)c.max_seq * 128);
+    for (int i = 0; i < 64; ++i) {
+      const float inv = (float)(1.0 / pow((double)c.rope_theta, (double)((float)(2 * i) / 128.0f)));
+      for (int pos = 0; pos < c.max_seq; ++pos) {
+        const float ang = (float)pos * inv;
+        tab[((size_t)pos * 64 + i) * 2] = (float)cos((double)ang);
+        tab[((size_t)pos * 64 + i) * 2 + 1] = (float)sin((double)ang);
+      }
+    }
+    TRY(ctx->alloc((void**)&ctx->rope, tab.size() * 4));
+    OM_HIP(hipMemcpy(ctx->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
+
+  // ---- workspaces
+  if (c.v_layers > 0) {
+    const size_t Bm = (size_t)c.max_tiles, M = Bm * ctx->v_ntok;
+    TRY(ctx->alloc(&ctx->vw_cols, Bm * ctx->v_np * ctx->v_kpad * 2));
+    TRY(ctx->alloc(&ctx->vw_pe, Bm * ctx->v_np * C * 2));
+    TRY(ctx->alloc(&ctx->vw_x, M * C * 2));
+    TRY(ctx->alloc(&ctx->vw_x2, M * C * 2));
+    TRY(ctx->alloc(&ctx->vw_xn, M * C * 2));
+    TRY(ctx->alloc(&ctx->vw_qkv, M * 3 * ctx->v_Cq * 2));
+    TRY(ctx->alloc(&ctx->vw_ao, M * ctx->v_Cq * 2));
+    TRY(ctx->alloc(&ctx->vw_h, M * I * 2));
+    TRY(ctx->alloc(&ctx->vw_feat, M * C * 2));
+    TRY(ctx->alloc(&ctx->vw_proj, M * c.t_hidden * 2));
+    TRY(ctx->alloc((void**)&ctx->vw_sumsq, M * 2 * 4));
+  }
+  if (c.t_layers > 0) {
+    const size_t R = (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch);
+    TRY(ctx->alloc(&ctx->tw_x, R * H * 2));
+    TRY(ctx->alloc(&ctx->tw_x2, R * H * 2));
+    TRY(ctx->alloc(&ctx->tw_xn, R * H * 2));
+    TRY(ctx->alloc(&ctx->tw_qkv, R * ctx->t_qkvdim * 2));
+    TRY(ctx->alloc(&ctx->tw_ao, R * ctx->t_qdim * 2));
+    TRY(ctx->alloc(&ctx->tw_act, R * It * 2));
+    TRY(ctx->alloc(&ctx->tw_last, (size_t)c.max_batch * H * 2));
+    TRY(ctx->alloc((void**)&ctx->tw_logits, (size_t)c.max_batch * c.t_vocab * 4));
+    ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
+    TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
+    TRY(ctx->alloc((void**)&ctx->d_pos, (size_t)c.max_batch * 4));
+    TRY(ctx->alloc((void**)&ctx->d_len, (size_t)c.max_batch * 4));
+    TRY(ctx->alloc((void**)&ctx->d_idx, (size_t)c.max_batch * 4));
+    const size_t cache = (size_t)c.t_layers * ctx->cache_layer_stride() * 2;
+    TRY(ctx->alloc(&ctx->kcache, cache));
+    TRY(ctx->alloc(&ctx->vcache, cache));
+    OM_HIP(hipMemset(ctx->kcache, 0, cache));
+    OM_HIP(hipMemset(ctx->vcache, 0, cache));
+    ctx->h_len.assign(c.max_batch, 0);
+  }
+  return 0;
+}
+
+int ensure_stage(omchat_ctx* ctx, size_t f32_bytes, size_t t_bytes) {
+  if (f32_bytes > ctx->stage_f32_bytes) {
+    if (ctx->stage_f32) hipFree(ctx->stage_f32);
+    OM_HIP(hipMalloc(&ctx->stage_f32, f32_bytes));
+    ctx->stage_f32_bytes = f32_bytes;
+  }
+  if (t_bytes > ctx->stage_t_bytes) {
+    if (ctx->stage_t) hipFree(ctx->stage_t);
+    OM_HIP(hipMalloc(&ctx->stage_t, t_bytes));
+    ctx->stage_t_bytes = t_bytes;
+  }
+  return 0;
+}
+
+// copy a contiguous [rows, cols] T tensor (host or device) into its routed destination
+int place(omchat_ctx* ctx, Route& r, const void* src_t) {
+  const size_t rowb = (size_t)r.cols * 2;
+  if (r.kind == R_PLAIN || r.kind == R_PATCH) {
+    OM_HIP(hipMemcpy2D(r.dst, (size_t)r.dst_ld * 2, src_t, rowb, rowb, (size_t)r.rows, hipMemcpyDefault));
+  } else {
+    // gate block j (16 rows) -> fused rows [32j, 32j+16); up block j -> [32j+16, 32j+32)
+    char* d = (char*)r.dst + (r.kind == R_UP ? 16 * rowb : 0);
+    OM_HIP(hipMemcpy2D(d, 32 * rowb, src_t, 16 * rowb, 16 * rowb, (size_t)r.rows / 16, hipMemcpyDefault));
+  }
+  r.loaded = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_size, void* rccl_comm, omchat_ctx** out) {
+  OM_CHECK(cfg && out, "null argument");
+  OM_CHECK(cfg->dtype == OMCHAT_F16 || cfg->dtype == OMCHAT_BF16, "dtype must be OMCHAT_F16 or OMCHAT_BF16");
+  OM_CHECK(tp_size >= 1 && tp_rank >= 0 && tp_rank < tp_size, "bad tensor-parallel rank/size");
+  OM_CHECK(tp_size == 1 || rccl_comm, "tp_size > 1 needs an RCCL communicator");
+  OM_CHECK(cfg->v_layers == 0 || (cfg->v_hidden % 64 == 0 && cfg->v_mlp % 64 == 0 && cfg->v_image % cfg->v_patch == 0),
+           "vision dims: hidden/mlp % 64, image % patch");
+  OM_CHECK(cfg->t_layers == 0 || (cfg->t_hidden % 64 == 0 && cfg->t_mlp % 64 == 0 && cfg->t_heads % cfg->t_kv_heads == 0),
+           "text dims: hidden/mlp % 64, heads % kv_heads");
+  OM_CHECK(cfg->t_layers == 0 || cfg->t_heads / cfg->t_kv_heads <= 16, "GQA group must be <= 16");
+  int dev_count = 0;
+  if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) {
+    omchat_set_error("omchat_ctx_create: no HIP device (the HIP path has no CPU fallback)");
+    return 2;
+  }
+  omchat_ctx* ctx = new omchat_ctx();
+  ctx->c = *cfg; ctx->dt = cfg->dtype; ctx->tp_rank = tp_rank; ctx->tp_size = tp_size; ctx->comm = (ncclComm_t)rccl_comm;
+  int rc = build(ctx);
+  if (rc) { omchat_ctx_destroy(ctx); return rc; }
+  *out = ctx;
+  return 0;
+}
+
+extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
+  if (!ctx) return;
+  for (void* p : ctx->allocs) hipFree(p);
+  if (ctx->stage_f32) hipFree(ctx->stage_f32);
+  if (ctx->stage_t) hipFree(ctx->stage_t);
+  delete ctx;
+}
+
+extern "C" size_t omchat_device_bytes(omchat_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+
+extern "C" int omchat_load_tensor(omchat_ctx* ctx, const char* name, const void* data, const int64_t* shape, int ndim, int src_dtype) {
+  OM_CHECK(ctx && name && data && shape, "null argument");
+  auto it = ctx->routes.find(name);
+  OM_CHECK(it != ctx->routes.end(), std::string("unknown tensor name: ") + name);
+  Route& r = it->second;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= shape[i];
+  OM_CHECK(n == r.rows * r.cols, std::string("shape mismatch for ") + name + ": expected " + std::to_string(r.rows * r.cols) +
+                                     " elements, got " + std::to_string(n));
+  if (src_dtype == ctx->dt) return place(ctx, r, data);
+  OM_CHECK(src_dtype == OMCHAT_F32, "source dtype must be the context dtype or OMCHAT_F32");
+  TRY(ensure_stage(ctx, (size_t)n * 4, (size_t)n * 2));
+  OM_HIP(hipMemcpy(ctx->stage_f32, data, (size_t)n * 4, hipMemcpyDefault));
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (ctx->dt == OMCHAT_F16) hipLaunchKernelGGL(cast_from_f32_f16, dim3(grid), dim3(256), 0, 0, (const float*)ctx->stage_f32, (f16*)ctx->stage_t, n);
+  else hipLaunchKernelGGL(cast_from_f32_bf16, dim3(grid), dim3(256), 0, 0, (const float*)ctx->stage_f32, (bf16*)ctx->stage_t, n);
+  OM_LAUNCH_CHECK();
+  OM_HIP(hipDeviceSynchronize());
+  return place(ctx, r, ctx->stage_t);
+}
+
+static uint64_t fnv1a64(const std::string& s) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (unsigned char ch : s) { h ^= ch; h *= 0x100000001B3ull; }
+  return h;
+}
+
+extern "C" int omchat_fill_synthetic(omchat_ctx* ctx, uint64_t seed) {
+  OM_CHECK(ctx, "null ctx");
+  OM_CHECK(ctx->tp_size == 1, "synthetic fill generates unsharded tensors; shard on the host for tp_size > 1");
+  size_t maxn = 0;
+  for (auto& kv : ctx->routes) maxn = std::max(maxn, (size_t)(kv.second.rows * kv.second.cols));
+  TRY(ensure_stage(ctx, 16, maxn * 2));
+  for (auto& kv : ctx->routes) {
+    Route& r = kv.second;
+    const int64_t n = r.rows * r.cols;
+    const float scale = (float)((double)r.synth_std * sqrt(3.0));
+    TRY(launch_fill_uniform(ctx->dt, ctx->stage_t, n, fnv1a64(kv.first) ^ seed, scale, r.synth_off, 0));
+    OM_HIP(hipDeviceSynchronize());
+    TRY(place(ctx, r, ctx->stage_t));
+  }
+  return 0;
+}
+
+extern "C" int omchat_weights_missing(omchat_ctx* ctx) {
+  int miss = 0;
+  std::string names;
+  for (auto& kv : ctx->routes)
+    if (!kv.second.loaded) { if (miss < 8) names += kv.first + " "; ++miss; }
+  if (miss) omchat_set_error("missing tensors: " + names + (miss > 8 ? "..." : ""));
+  return miss;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vision tower
+// ---------------------------------------------------------------------------------------------------------
+static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias,
+                const void* ls, const void* resid, int ldr, int epi, hipStream_t s) {
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, 0};
+  return launch_gemm(ctx->dt, g, s);
+}
+
+static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hipStream_t s, void** x_out) {
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, I = c.v_mlp, Cq = ctx->v_Cq, np = ctx->v_np, ntok = ctx->v_ntok, M = B * ntok;
+  const bool lead = ctx->tp_rank == 0;
+  // InternVisionEmbeddings.forward (modeling_intern_vit.py:90-102)
+  TRY(launch_im2col(ctx->dt, pixels, ctx->vw_cols, B, c.v_image, c.v_patch, ctx->v_kpad, s));
+  TRY(gemm(ctx, ctx->vw_cols, ctx->v_kpad, ctx->v_wpatch, ctx->v_kpad, ctx->vw_pe, C, B * np, C, ctx->v_kpad, ctx->v_bpatch, nullptr, nullptr, 0, EPI_NONE, s));
+  TRY(launch_vit_assemble(ctx->dt, ctx->vw_pe, ctx->v_cls, ctx->v_pos, ctx->vw_x, B, np, C, s));
+  void* x = ctx->vw_x;
+  void* y = ctx->vw_x2;
+  for (int j = 0; j < n_layers; ++j) {
+    auto& L = ctx->vl[j];
+    // InternVisionEncoderLayer.forward (modeling_intern_vit.py:210-222)
+    TRY(launch_rmsnorm(ctx->dt, x, C, L.n1, ctx->vw_xn, C, M, C, c.v_eps, s));
+    TRY(gemm(ctx, ctx->vw_xn, C, L.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, nullptr, nullptr, 0, EPI_NONE, s));
+    const float* sumsq = nullptr;
+    if (ctx->tp_size > 1) {     // joint-head norm: sum of squares over ALL ranks' heads
+      TRY(launch_vit_qk_sumsq(ctx->dt, ctx->vw_qkv, 3 * Cq, M, Cq, ctx->vw_sumsq, s));
+      TRY(ctx->allreduce_f32(ctx->vw_sumsq, (size_t)M * 2, s));
+      sumsq = ctx->vw_sumsq;
+    }
+    TRY(launch_vit_qknorm(ctx->dt, ctx->vw_qkv, 3 * Cq, L.qn, L.kn, M, Cq, c.v_qk_channels, c.v_eps, 0.08838834764831845f, sumsq, s));
+    AttnArgs a{};
+    a.Q = ctx->vw_qkv; a.q_sb = (int64_t)ntok * 3 * Cq; a.q_sh = 128; a.q_sr = 3 * Cq;
+    a.K = (const char*)ctx->vw_qkv + (size_t)Cq * 2; a.k_sb = a.q_sb; a.k_sh = 128; a.k_sr = 3 * Cq;
+    a.V = (const char*)ctx->vw_qkv + (size_t)2 * Cq * 2; a.v_sb = a.q_sb; a.v_sh = 128; a.v_sr = 3 * Cq;
+    a.O = ctx->vw_ao; a.o_sb = (int64_t)ntok * Cq; a.o_sh = 128; a.o_sr = Cq;
+    a.batch = B; a.q_heads = c.v_heads; a.kv_heads = c.v_heads; a.Sq = ntok; a.Skv = ntok; a.kv_len = nullptr; a.causal = 0; a.q_pos0 = 0;
+    a.scale = 1.0f;     // q was pre-scaled by the q/k norm kernel (reference order, modeling_intern_vit.py:148)
+    TRY(launch_attn_prefill(ctx->dt, a, s));
+    if (ctx->tp_size == 1) {
+      TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID, s));
+    } else {
+      TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, C, Cq, lead ? L.bproj : nullptr, L.ls1, lead ? x : nullptr, C, EPI_LS_RESID, s));
+      TRY(ctx->allreduce(y, (size_t)M * C, s));
+      std::swap(x, y);
+    }
+    TRY(launch_rmsnorm(ctx->dt, x, C, L.n2, ctx->vw_xn, C, M, C, c.v_eps, s));
+    TRY(gemm(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, s));
+    if (ctx->tp_size == 1) {
+      TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, EPI_LS_RESID, s));
+    } else {
+      TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, y, C, M, C, I, lead ? L.b2 : nullptr, L.ls2, lead ? x : nullptr, C, EPI_LS_RESID, s));
+      TRY(ctx->allreduce(y, (size_t)M * C, s));
+      std::swap(x, y);
+    }
+  }
+  *x_out = x;
+  return 0;
+}
+
+static int resolve_layer(omchat_ctx* ctx, int select_layer, int* idx) {
+  const int L = ctx->c.v_layers;
+  const int i = select_layer >= 0 ? select_layer : L + 1 + select_layer;
+  OM_CHECK(i >= 0 && i <= L, "select_layer out of range");
+  *idx = i;
+  return 0;
+}
+
+extern "C" int omchat_vit_forward(omchat_ctx* ctx, const void* pixels, int n_tiles, int select_layer, int keep_cls, void* out, void* stream) {
+  OM_CHECK(ctx && pixels && out, "null argument");
+  OM_CHECK(ctx->c.v_layers > 0, "context has no vision tower");
+  OM_CHECK(n_tiles >= 0, "negative tile count");
+  OM_CHECK(omchat_weights_missing(ctx) == 0, std::string(omchat_last_error()));
+  int idx; TRY(resolve_layer(ctx, select_layer, &idx));
+  hipStream_t s = (hipStream_t)stream;
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, np = ctx->v_np, ntok = ctx->v_ntok;
+  const size_t px_tile = (size_t)3 * c.v_image * c.v_image * 2;
+  const int out_tok = keep_cls ? ntok : np;
+  for (int t0 = 0; t0 < n_tiles; t0 += c.max_tiles) {
+    const int B = std::min(c.max_tiles, n_tiles - t0);
+    void* x;
+    TRY(vit_run(ctx, (const char*)pixels + t0 * px_tile, B, idx, s, &x));
+    // feature_select (internVIT_encoder.py:35-43): 'patch' drops CLS, 'cls_patch' keeps it
+    char* o = (char*)out + (size_t)t0 * out_tok * C * 2;
+    if (keep_cls) TRY(launch_copy_rows(ctx->dt, x, C, o, C, B * ntok, C, ntok, 0, s));
+    else TRY(launch_copy_rows(ctx->dt, x, C, o, C, B * np, C, np, 1, s));
+  }
+  return 0;
+}
+
+extern "C" int omchat_projector_forward(omchat_ctx* ctx, const void* in, int rows, void* out, void* stream) {
+  OM_CHECK(ctx && in && out, "null argument");
+  OM_CHECK(ctx->c.v_layers > 0, "context has no projector");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = ctx->c.v_hidden, H = ctx->c.t_hidden;
+  const int cap = ctx->c.max_tiles * ctx->v_ntok;
+  for (int r0 = 0; r0 < rows; r0 += cap) {
+    const int R = std::min(cap, rows - r0);
+    const char* a = (const char*)in + (size_t)r0 * C * 2;
+    char* o = (char*)out + (size_t)r0 * H * 2;
+    // Linear + GELU + Linear (multimodal_projector/builder.py:57-61)
+    TRY(gemm(ctx, a, C, ctx->p_w0, C, ctx->vw_proj, H, R, H, C, ctx->p_b0, nullptr, nullptr, 0, EPI_GELU, s));
+    TRY(gemm(ctx, ctx->vw_proj, H, ctx->p_w2, H, o, H, R, H, H, ctx->p_b2, nullptr, nullptr, 0, EPI_NONE, s));
+  }
+  return 0;
+}
+
+extern "C" int omchat_encode_images(omchat_ctx* ctx, const void* pixels, int n_tiles, int select_layer, void* out, void* stream) {
+  OM_CHECK(ctx && pixels && out, "null argument");
+  OM_CHECK(ctx->c.v_layers > 0, "context has no vision tower");
+  OM_CHECK(omchat_weights_missing(ctx) == 0, std::string(omchat_last_error()));
+  int idx; TRY(resolve_layer(ctx, select_layer, &idx));
+  hipStream_t s = (hipStream_t)stream;
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, H = c.t_hidden, np = ctx->v_np;
+  const size_t px_tile = (size_t)3 * c.v_image * c.v_image * 2;
+  for (int t0 = 0; t0 < n_tiles; t0 += c.max_tiles) {
+    const int B = std::min(c.max_tiles, n_tiles - t0);
+    void* x;
+    TRY(vit_run(ctx, (const char*)pixels + t0 * px_tile, B, idx, s, &x));
+    TRY(launch_copy_rows(ctx->dt, x, C, ctx->vw_feat, C, B * np, C, np, 1, s));
+    TRY(omchat_projector_forward(ctx, ctx->vw_feat, B * np, (char*)out + (size_t)t0 * np * H * 2, s));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// splice
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b, int T, int n_tok, int n_tiles_avail, int padding_side,
+                                  int max_length, int32_t* src_index, int32_t* lengths, int* S_out) {
+  OM_CHECK(ids && S_out && b > 0 && T > 0 && n_tok >= 0, "bad argument");
+  // pass 1: lengths (omchat_arch.py:115-164); a row without sentinels still consumes one tile slot (:122-129)
+  std::vector<int> len(b);
+  int cur = 0, S = 0;
+  for (int i = 0; i < b; ++i) {
+    int n = 0, n_img = 0;
+    for (int t = 0; t < T; ++t) {
+      if (mask && !mask[(size_t)i * T + t]) continue;
+      if (ids[(size_t)i * T + t] == -200) { n += n_tok; ++n_img; } else ++n;
+    }
+    cur += n_img == 0 ? 1 : n_img;
+    if (max_length > 0 && n > max_length) n = max_length;
+    len[i] = n;
+    S = std::max(S, n);
+  }
+  OM_CHECK(cur <= n_tiles_avail || n_tok == 0, "more <image> sentinels than image tiles (reference: IndexError on image_features)");
+  *S_out = S;
+  if (lengths) for (int i = 0; i < b; ++i) lengths[i] = len[i];
+  if (!src_index) return 0;
+  cur = 0;
+  for (int i = 0; i < b; ++i) {
+    int32_t* row = src_index + (size_t)i * S;
+    const int off = padding_side == 1 ? S - len[i] : 0;       // left padding (:176-184) vs right (:185-193)
+    for (int s = 0; s < S; ++s) row[s] = INT32_MIN;
+    int w = 0, n_img = 0;
+    for (int t = 0; t < T; ++t) {
+      if (mask && !mask[(size_t)i * T + t]) continue;
+      const int64_t id = ids[(size_t)i * T + t];
+      if (id == -200) {
+        for (int k = 0; k < n_tok; ++k, ++w)
+          if (w < len[i]) row[off + w] = -1 - (cur * n_tok + k);
+        ++cur; ++n_img;
+      } else {
+        if (w < len[i]) row[off + w] = (int32_t)id;
+        ++w;
+      }
+    }
+    if (n_img == 0) ++cur;
+  }
+  return 0;
+}
+
+extern "C" int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, const void* feats, void* embeds, int rows, void* stream) {
+  OM_CHECK(ctx && src_index && embeds, "null argument");
+  OM_CHECK(ctx->t_embed, "context has no decoder");
+  return launch_gather_rows(ctx->dt, src_index, ctx->t_embed, feats, embeds, rows, ctx->c.t_hidden, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------------------------
+static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s) {
+  const int H = ctx->c.t_hidden, V = ctx->c.t_vocab;
+  for (int r0 = 0; r0 < n; r0 += 16) {
+    const int R = std::min(16, n - r0);
+    GemvArgs g{(const char*)hidden + (size_t)r0 * H * 2, H, ctx->t_lm, H, logits + (size_t)r0 * V, V, R, V, H, nullptr, nullptr, 0, EPI_NONE, 1};
+    TRY(launch_gemv(ctx->dt, g, s));
+  }
+  return 0;
+}
+
+extern "C" int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream) {
+  OM_CHECK(ctx && hidden && logits, "null argument");
+  return lm_head_rows(ctx, hidden, n, logits, (hipStream_t)stream);
+}
+
+extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last, void* hidden_out,
+                              void* stream) {
+  OM_CHECK(ctx && embeds && lengths, "null argument");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
+  OM_CHECK(S >= 1 && S <= c.max_seq, "sequence exceeds max_seq");
+  OM_CHECK((int64_t)b * S <= c.max_prefill_rows, "b * S exceeds max_prefill_rows");
+  OM_CHECK(omchat_weights_missing(ctx) == 0, std::string(omchat_last_error()));
+  for (int i = 0; i < b; ++i) OM_CHECK(lengths[i] >= 1 && lengths[i] <= S, "lengths must be in [1, S]");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = c.t_hidden, It = c.t_mlp, rows = b * S, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
+  const bool lead = ctx->tp_rank == 0;
+
+  std::vector<int> pos(b), len1(b);
+  for (int i = 0; i < b; ++i) { ctx->h_len[i] = lengths[i]; pos[i] = lengths[i]; len1[i] = lengths[i] + 1; }
+  // d_len holds the valid lengths during prefill; switched to (len + 1, pos = len) for the decode steps at the end
+  OM_HIP(hipMemcpyAsync(ctx->d_len, lengths, (size_t)b * 4, hipMemcpyHostToDevice, s));
+
+  void* x = ctx->tw_x;
+  void* y = ctx->tw_x2;
+  OM_HIP(hipMemcpyAsync(x, embeds, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, s));
+  for (int i = 0; i < c.t_layers; ++i) {
+    auto& L = ctx->dl[i];
+    char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
+    char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
+    // Qwen2DecoderLayer.forward (modeling_qwen2.py:269-298)
+    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, rows, H, c.t_eps, s));
+    TRY(gemm(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, nullptr, nullptr, 0, EPI_NONE, s));
+    RopeArgs r{ctx->tw_qkv, qkvd, rows, S, c.t_heads, c.t_kv_heads, nullptr, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
+    TRY(launch_rope_kv(ctx->dt, r, s));
+    AttnArgs a{};
+    a.Q = ctx->tw_qkv; a.q_sb = (int64_t)S * qkvd; a.q_sh = 128; a.q_sr = qkvd;
+    a.K = kc; a.k_sb = ctx->cache_sb(); a.k_sh = ctx->cache_sh(); a.k_sr = 128;
+    a.V = vc; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+    a.O = ctx->tw_ao; a.o_sb = (int64_t)S * qd; a.o_sh = 128; a.o_sr = qd;
+    a.batch = b; a.q_heads = c.t_heads; a.kv_heads = c.t_kv_heads; a.Sq = S; a.Skv = S; a.kv_len = ctx->d_len; a.causal = 1; a.q_pos0 = 0;
+    a.scale = 0.08838834764831845f;
+    TRY(launch_attn_prefill(ctx->dt, a, s));
+    if (ctx->tp_size == 1) {
+      TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, x, H, rows, H, qd, nullptr, nullptr, x, H, EPI_RESID, s));
+    } else {
+      TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, H, qd, nullptr, nullptr, lead ? x : nullptr, H, EPI_RESID, s));
+      TRY(ctx->allreduce(y, (size_t)rows * H, s));
+      std::swap(x, y);
+    }
+    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
+    TRY(gemm(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, nullptr, nullptr, 0, EPI_SWIGLU, s));
+    if (ctx->tp_size == 1) {
+      TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
+    } else {
+      TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, H, It, nullptr, nullptr, lead ? x : nullptr, H, EPI_RESID, s));
+      TRY(ctx->allreduce(y, (size_t)rows * H, s));
+      std::swap(x, y);
+    }
+  }
+  if (hidden_out) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, hidden_out, H, rows, H, c.t_eps, s));
+  if (logits_last) {
+    // only the last valid position feeds generation (Qwen2ForCausalLM.forward :462-465 projects all; same values)
+    hipLaunchKernelGGL(last_row_index_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_len, S, b, ctx->d_idx);
+    TRY(launch_gather_rows(ctx->dt, ctx->d_idx, x, nullptr, ctx->tw_last, b, H, s));
+    TRY(launch_rmsnorm(ctx->dt, ctx->tw_last, H, ctx->t_norm, ctx->tw_last, H, b, H, c.t_eps, s));
+    TRY(lm_head_rows(ctx, ctx->tw_last, b, logits_last, s));
+  }
+  OM_HIP(hipMemcpyAsync(ctx->d_pos, pos.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  OM_HIP(hipMemcpyAsync(ctx->d_len, len1.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  OM_HIP(hipStreamSynchronize(s));     // pos/len1 are stack vectors
+  return 0;
+}
+
+extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && tokens, "null argument");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
+  int Lmax = 0;
+  for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
+  OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
+  const bool lead = ctx->tp_rank == 0;
+  void* x = ctx->tw_x;
+  void* y = ctx->tw_x2;
+  TRY(launch_gather_rows(ctx->dt, tokens, ctx->t_embed, nullptr, x, b, H, s));      // embed_tokens
+  auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi) -> int {
+    for (int r0 = 0; r0 < b; r0 += 16) {
+      const int R = std::min(16, b - r0);
+      GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
+                 resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0};
+      TRY(launch_gemv(ctx->dt, g, s));
+    }
+    return 0;
+  };
+  for (int i = 0; i < c.t_layers; ++i) {
+    auto& L = ctx->dl[i];
+    char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
+    char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
+    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
+    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE));
+    RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
+    TRY(launch_rope_kv(ctx->dt, r, s));
+    AttnDecodeArgs a{};
+    a.Q = ctx->tw_qkv; a.q_sb = qkvd; a.q_sh = 128;
+    a.K = kc; a.k_sb = ctx->cache_sb(); a.k_sh = ctx->cache_sh(); a.k_sr = 128;
+    a.V = vc; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+    a.O = ctx->tw_ao; a.o_sb = qd; a.o_sh = 128;
+    a.batch = b; a.q_heads = c.t_heads; a.kv_heads = c.t_kv_heads; a.L = Lmax; a.kv_len = ctx->d_len; a.scale = 0.08838834764831845f;
+    a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
+    TRY(launch_attn_decode(ctx->dt, a, s));
+    if (ctx->tp_size == 1) {
+      TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
+    } else {
+      TRY(gemv(ctx->tw_ao, qd, L.wo, qd, y, H, H, nullptr, lead ? x : nullptr, lead ? EPI_RESID : EPI_NONE));
+      TRY(ctx->allreduce(y, (size_t)b * H, s));
+      std::swap(x, y);
+    }
+    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
+    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU));
+    if (ctx->tp_size == 1) {
+      TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
+    } else {
+      TRY(gemv(ctx->tw_act, It, L.wd, It, y, H, H, nullptr, lead ? x : nullptr, lead ? EPI_RESID : EPI_NONE));
+      TRY(ctx->allreduce(y, (size_t)b * H, s));
+      std::swap(x, y);
+    }
+  }
+  TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
+  float* lg = logits ? logits : ctx->tw_logits;
+  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s));
+  if (next_tokens) TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, s));
+  hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
+  OM_LAUNCH_CHECK();
+  for (int i = 0; i < b; ++i) ctx->h_len[i] += 1;
+  return 0;
+}
+
+extern "C" int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b) {
+  OM_CHECK(ctx && out && b <= (int)ctx->h_len.size(), "bad argument");
+  for (int i = 0; i < b; ++i) out[i] = ctx->h_len[i];
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tensor-parallel bootstrap
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int omchat_comm_unique_id(char id[128]) {
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than 128 bytes");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) { omchat_set_error(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); return 3; }
+  memset(id, 0, 128);
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+extern "C" int omchat_comm_init(const char id[128], int rank, int size, void** comm_out) {
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclComm_t comm;
+  ncclResult_t r = ncclCommInitRank(&comm, size, u, rank);
+  if (r != ncclSuccess) { omchat_set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return 3; }
+  *comm_out = comm;
+  return 0;
+}
+extern "C" void omchat_comm_destroy(void* comm) {
+  if (comm) ncclCommDestroy((ncclComm_t)comm);
+}

@@ -1,0 +1,191 @@
+"""Engine: owns one `omchat_ctx` (one GPU / one tensor-parallel rank) and exposes the hot path on torch CUDA tensors.
+
+torch is plumbing here (device memory for inputs/outputs, the current HIP stream); all arithmetic happens inside
+libomchat_hip.so.  There is no CPU fallback: constructing an Engine without a GPU raises."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import OmchatConfig, check, ptr, cur_stream
+from .config import OmChatConfig
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine:
+    def __init__(self, cfg: OmChatConfig, dtype="bf16", max_seq=4096, max_batch=1, max_tiles=4, max_prefill_rows=None,
+                 tp_rank=0, tp_size=1, comm=None, device=None, vision=True, text=True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.OmchatError("omchat_amd.Engine needs a HIP device: the HIP path has no CPU fallback")
+        self.lib = _lib.lib()
+        self.cfg = cfg
+        self.dtype_code = {"f16": _lib.F16, "fp16": _lib.F16, "bf16": _lib.BF16}[dtype] if isinstance(dtype, str) else _lib.dtype_code(dtype)
+        self.torch_dtype = _lib.torch_dtype(self.dtype_code)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.tp_rank, self.tp_size = tp_rank, tp_size
+        v, t = cfg.vision, cfg.text
+        from .tp import local_dims
+        ld = local_dims(cfg, tp_rank, tp_size)
+        self.local = ld
+        c = OmchatConfig()
+        c.v_hidden = v["hidden_size"]; c.v_heads = ld["v_heads"]; c.v_qk_channels = v["hidden_size"]; c.v_mlp = ld["v_mlp"]
+        c.v_layers = v["num_hidden_layers"] if vision else 0
+        c.v_patch = v["patch_size"]; c.v_image = v["image_size"]; c.v_eps = v["layer_norm_eps"]
+        c.t_hidden = t["hidden_size"]; c.t_layers = t["num_hidden_layers"] if text else 0
+        c.t_heads = ld["t_heads"]; c.t_kv_heads = ld["t_kv_heads"]; c.t_mlp = ld["t_mlp"]; c.t_vocab = ld["t_vocab"]
+        c.t_vocab_total = t["vocab_size"]; c.t_eps = t["rms_norm_eps"]; c.rope_theta = t["rope_theta"]
+        c.max_seq = max_seq; c.max_batch = max_batch; c.max_tiles = max_tiles
+        c.max_prefill_rows = max_prefill_rows if max_prefill_rows is not None else max_seq * max_batch
+        c.dtype = self.dtype_code
+        self.c = c
+        self.ntok = cfg.num_image_tokens
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.omchat_ctx_create(C.byref(c), tp_rank, tp_size, comm, C.byref(h)))
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.omchat_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_tensor(self, name, t):
+        """t: torch tensor (CPU or CUDA; fp32 or the engine dtype) or numpy fp32 array, already rank-local."""
+        torch = _torch()
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t))
+        if t.dtype not in (torch.float32, self.torch_dtype):
+            t = t.to(torch.float32)
+        t = t.contiguous()
+        shape = (C.c_int64 * max(t.dim(), 1))(*(list(t.shape) or [1]))
+        check(self.lib.omchat_load_tensor(self.h, name.encode(), ptr(t), shape, max(t.dim(), 1), _lib.dtype_code(t.dtype)))
+
+    def load_state_dict(self, sd, strict=True):
+        """sd: omchat-native keys -> full (unsharded) tensors; sharded here for tp_size > 1."""
+        from .tp import shard_tensor
+        from .weights import prepare_state_dict
+        sd = prepare_state_dict(sd, self.cfg, self.c.v_layers > 0, self.c.t_layers > 0)
+        for k, v in sd.items():
+            self.load_tensor(k, shard_tensor(k, v, self.cfg, self.tp_rank, self.tp_size))
+        if strict:
+            n = self.lib.omchat_weights_missing(self.h)
+            if n:
+                raise KeyError(self.lib.omchat_last_error().decode())
+
+    def fill_synthetic(self, seed=0):
+        check(self.lib.omchat_fill_synthetic(self.h, seed))
+
+    def device_bytes(self):
+        return int(self.lib.omchat_device_bytes(self.h))
+
+    # ------------------------------------------------------------------ vision
+    def _px(self, pixels):
+        torch = _torch()
+        if pixels.dim() != 4 or pixels.shape[1] != 3:
+            raise ValueError(f"wrong pixel_values size: {tuple(pixels.shape)}")      # modeling_intern_vit.py:337-338
+        s = self.cfg.vision["image_size"]
+        if pixels.shape[2] != s or pixels.shape[3] != s:
+            raise ValueError(f"expected {s}x{s} tiles, got {tuple(pixels.shape[2:])}")
+        return pixels.to(device=self.device, dtype=self.torch_dtype).contiguous()
+
+    def vit_forward(self, pixels, select_layer=-1, select_feature="patch"):
+        torch = _torch()
+        if select_feature not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {select_feature}")           # internVIT_encoder.py:42
+        px = self._px(pixels)
+        n = px.shape[0]
+        keep = select_feature == "cls_patch"
+        out = torch.empty(n, self.ntok + (1 if keep else 0), self.cfg.vision["hidden_size"], dtype=self.torch_dtype, device=self.device)
+        check(self.lib.omchat_vit_forward(self.h, ptr(px), n, select_layer, int(keep), ptr(out), cur_stream()))
+        return out
+
+    def projector_forward(self, x):
+        torch = _torch()
+        x = x.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        rows = x.numel() // x.shape[-1]
+        out = torch.empty(*x.shape[:-1], self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device)
+        check(self.lib.omchat_projector_forward(self.h, ptr(x), rows, ptr(out), cur_stream()))
+        return out
+
+    def encode_images(self, pixels, select_layer=-1):
+        torch = _torch()
+        px = self._px(pixels)
+        n = px.shape[0]
+        out = torch.empty(n, self.ntok, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device)
+        check(self.lib.omchat_encode_images(self.h, ptr(px), n, select_layer, ptr(out), cur_stream()))
+        return out
+
+    # ------------------------------------------------------------------ splice
+    def splice(self, input_ids, attention_mask, feats, padding_side="right", max_length=None):
+        """input_ids int64 [b,T] (CPU or CUDA), attention_mask [b,T] or None, feats [n_tiles, ntok, H] CUDA or None.
+        Returns (inputs_embeds [b,S,H] CUDA, lengths list, valid-mask bool [b,S] CPU)."""
+        torch = _torch()
+        ids = input_ids.detach().to("cpu", torch.int64).contiguous()
+        b, T = ids.shape
+        m = None if attention_mask is None else attention_mask.detach().to("cpu").ne(0).to(torch.uint8).contiguous()
+        n_tiles = 0 if feats is None else feats.shape[0]
+        ntok = self.ntok if feats is None else feats.shape[1]
+        side = 1 if padding_side == "left" else 0
+        ml = -1 if max_length is None else int(max_length)
+        S = C.c_int(0)
+        lens = torch.zeros(b, dtype=torch.int32)
+        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, None, ptr(lens), C.byref(S)))
+        idx = torch.empty(b, S.value, dtype=torch.int32)
+        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, ptr(idx), ptr(lens), C.byref(S)))
+        idx_d = idx.to(self.device)
+        f = None if feats is None else feats.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        out = torch.empty(b, S.value, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device)
+        check(self.lib.omchat_splice_gather(self.h, ptr(idx_d), ptr(f), ptr(out), b * S.value, cur_stream()))
+        return out, [int(x) for x in lens], idx.ne(_lib.PAD_ROW)
+
+    # ------------------------------------------------------------------ decoder
+    def prefill(self, embeds, lengths=None, want_hidden=False, want_logits=True):
+        torch = _torch()
+        e = embeds.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        b, S, _ = e.shape
+        lens = torch.tensor(lengths if lengths is not None else [S] * b, dtype=torch.int32)
+        logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        hidden = torch.empty(b, S, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device) if want_hidden else None
+        check(self.lib.omchat_prefill(self.h, ptr(e), b, S, ptr(lens), ptr(logits), ptr(hidden), cur_stream()))
+        return logits, hidden
+
+    def decode_step(self, tokens, want_logits=False):
+        torch = _torch()
+        tk = tokens.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+        b = tk.shape[0]
+        logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        nxt = torch.empty(b, dtype=torch.int32, device=self.device)
+        check(self.lib.omchat_decode_step(self.h, ptr(tk), b, ptr(logits), ptr(nxt), cur_stream()))
+        return nxt, logits
+
+    def lm_head(self, hidden):
+        torch = _torch()
+        h = hidden.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        n = h.numel() // h.shape[-1]
+        out = torch.empty(*h.shape[:-1], self.c.t_vocab, dtype=torch.float32, device=self.device)
+        check(self.lib.omchat_lm_head(self.h, ptr(h), n, ptr(out), cur_stream()))
+        return out
+
+    def kv_lengths(self, b):
+        torch = _torch()
+        out = torch.zeros(b, dtype=torch.int32)
+        check(self.lib.omchat_kv_lengths(self.h, ptr(out), b))
+        return [int(x) for x in out]
+
+    def argmax(self, logits):
+        torch = _torch()
+        out = torch.empty(logits.shape[0], dtype=torch.int32, device=self.device)
+        check(self.lib.omchat_op_argmax(ptr(logits), logits.shape[0], logits.shape[1], ptr(out), cur_stream()))
+        return out

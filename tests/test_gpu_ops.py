@@ -1,0 +1,266 @@
+"""GPU parity: every HIP kernel through the C ABI against a plain fp32 restatement on the same (16-bit rounded) inputs."""
+import ctypes as C
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+from gpu_util import DT, CODE, TOL, dev, rnd, rel, ptr, sync, randn
+from omchat_amd import _lib, synth
+import oracle
+
+DTS = ["bf16", "f16"]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_fill_uniform_bit_exact_with_host_generator(gpu_lib, dt):
+    for name, n, std, off in [("a.weight", 100003, 0.02, 0.0), ("b.norm", 4099, 0.05, 1.0)]:
+        out = torch.empty(n, dtype=DT[dt], device="cuda")
+        key = synth.fnv1a64(name) ^ 7
+        scale = float(np.float32(std * np.sqrt(3.0)))
+        _lib.check(gpu_lib.omchat_op_fill_uniform(CODE[dt], ptr(out), n, key, scale, off, None))
+        sync()
+        ref = synth.uniform(name, (n,), 7, std, off)
+        assert np.array_equal(out.float().cpu().numpy(), ref)
+
+
+def _gemm_ref(A, W, bias, ls, resid, epi, dt):
+    y = A @ W.t()
+    if epi == _lib.EPI_SWIGLU:
+        N = W.shape[0]
+        blocks = y.reshape(y.shape[0], N // 32, 2, 16)
+        g, u = rnd(blocks[:, :, 0], dt), rnd(blocks[:, :, 1], dt)
+        return (rnd(F.silu(g), dt) * u).reshape(y.shape[0], N // 2)
+    if bias is not None:
+        y = y + bias
+    y = rnd(y, dt)
+    if epi == _lib.EPI_GELU:
+        y = F.gelu(y)
+    elif epi == _lib.EPI_LS_RESID:
+        y = resid + rnd(y * ls, dt)
+    elif epi == _lib.EPI_RESID:
+        y = resid + y
+    return y
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(300, 224, 128), (1025, 416, 320), (64, 3200, 640), (515, 512, 1024)])
+def test_gemm_epilogues(gpu_lib, dt, tile, M, N, K):
+    A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2, 0.05), dt)
+    bias = rnd(randn((N,), 3, 0.1), dt); ls = rnd(randn((N,), 4, 0.1) + 0.1, dt); resid = rnd(randn((M, N), 5), dt)
+    for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_LS_RESID, _lib.EPI_RESID, _lib.EPI_SWIGLU):
+        if epi == _lib.EPI_SWIGLU and N % 32:
+            continue
+        No = N // 2 if epi == _lib.EPI_SWIGLU else N
+        use_bias = epi != _lib.EPI_SWIGLU and epi != _lib.EPI_RESID
+        dA, dW, db, dl, dr = dev(A, dt), dev(W, dt), dev(bias, dt), dev(ls, dt), dev(resid, dt)
+        out = torch.full((M, No), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), No, M, N, K, ptr(db) if use_bias else None,
+                                          ptr(dl), ptr(dr), N, epi, tile, None))
+        sync()
+        ref = _gemm_ref(A, W, bias if use_bias else None, ls, resid, epi, dt)
+        assert torch.isfinite(out.float()).all(), (epi, "non-finite / unwritten outputs")
+        assert rel(out, ref) < TOL[dt], (epi, tile, rel(out, ref))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_identity_asymmetric(gpu_lib, dt):
+    """A = I against an asymmetric W catches a transposed C write (cdna_hip_programming.md §3)."""
+    K = 256
+    A = torch.eye(K); W = rnd(randn((192, K), 9), dt)
+    out = torch.empty(K, 192, dtype=DT[dt], device="cuda")
+    dA, dW = dev(A, dt), dev(W, dt)
+    _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), 192, K, 192, K, None, None, None, 0, 0, 0, None))
+    sync()
+    assert torch.equal(out.float().cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_in_place_residual(gpu_lib, dt):
+    M, N, K = 200, 256, 128
+    A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2, 0.05), dt); x = rnd(randn((M, N), 3), dt)
+    dA, dW, dx = dev(A, dt), dev(W, dt), dev(x, dt)
+    _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(dx), N, M, N, K, None, None, ptr(dx), N, _lib.EPI_RESID, 0, None))
+    sync()
+    assert rel(dx, x + rnd(A @ W.t(), dt)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,N,K", [(1, 100, 256), (5, 4608, 3584), (16, 320, 512), (1, 3584, 18944), (3, 160, 64)])
+def test_gemv(gpu_lib, dt, b, N, K):
+    X = rnd(randn((b, K), 1), dt); W = rnd(randn((N, K), 2, 0.03), dt)
+    bias = rnd(randn((N,), 3, 0.1), dt); resid = rnd(randn((b, N), 4), dt)
+    dX, dW, db, dr = dev(X, dt), dev(W, dt), dev(bias, dt), dev(resid, dt)
+    y = X @ W.t()
+    # plain + bias
+    out = torch.full((b, N), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dX), K, ptr(dW), K, ptr(out), N, b, N, K, ptr(db), None, 0, _lib.EPI_NONE, 0, None))
+    sync(); assert rel(out, rnd(y + bias, dt)) < TOL[dt]
+    # fp32 logits
+    outf = torch.full((b, N), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dX), K, ptr(dW), K, ptr(outf), N, b, N, K, None, None, 0, _lib.EPI_NONE, 1, None))
+    sync(); assert rel(outf, y) < 1e-4
+    # residual
+    out2 = torch.full((b, N), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dX), K, ptr(dW), K, ptr(out2), N, b, N, K, None, ptr(dr), N, _lib.EPI_RESID, 0, None))
+    sync(); assert rel(out2, resid + rnd(y, dt)) < TOL[dt]
+    if N % 32 == 0:
+        out3 = torch.full((b, N // 2), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dX), K, ptr(dW), K, ptr(out3), N // 2, b, N, K, None, None, 0, _lib.EPI_SWIGLU, 0, None))
+        sync(); assert rel(out3, _gemm_ref(X, W, None, None, None, _lib.EPI_SWIGLU, dt)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("H", [256, 3200, 3584])
+def test_rmsnorm(gpu_lib, dt, H):
+    x = rnd(randn((37, H), 1, 2.0), dt); w = rnd(randn((H,), 2, 0.1) + 1.0, dt)
+    dx, dw = dev(x, dt), dev(w, dt)
+    out = torch.empty_like(dx)
+    _lib.check(gpu_lib.omchat_op_rmsnorm(CODE[dt], ptr(dx), ptr(dw), ptr(out), 37, H, 1e-6, None))
+    sync()
+    ref = oracle.rms_norm(x.to(DT[dt]), w.to(DT[dt]), 1e-6).float()       # the reference's own rounding sequence
+    assert rel(out, ref) < 2e-3
+    # two-rounding semantics reproduced exactly on the vast majority of elements
+    assert (out.float().cpu() == ref).float().mean() > 0.98
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_vit_qknorm(gpu_lib, dt):
+    rows, C = 19, 384
+    qkv = rnd(randn((rows, 3 * C), 1), dt); wq = rnd(randn((C,), 2, 0.1) + 1, dt); wk = rnd(randn((C,), 3, 0.1) + 1, dt)
+    d = dev(qkv, dt)
+    scale = 128 ** -0.5
+    _lib.check(gpu_lib.omchat_op_vit_qknorm(CODE[dt], ptr(d), 3 * C, ptr(dev(wq, dt)), ptr(dev(wk, dt)), rows, C, C, 1e-6, scale, None))
+    sync()
+    T = DT[dt]
+    q = (oracle.rms_norm(qkv[:, :C].to(T), wq.to(T), 1e-6) * scale).float()
+    k = oracle.rms_norm(qkv[:, C:2 * C].to(T), wk.to(T), 1e-6).float()
+    assert rel(d[:, :C], q) < 3e-3 and rel(d[:, C:2 * C], k) < 3e-3
+    assert torch.equal(d[:, 2 * C:].float().cpu(), qkv[:, 2 * C:])
+
+
+def _attn_ref(q, k, v, scale, causal, q_pos0, kv_len):
+    """q [b,Sq,Hq,D], k/v [b,Hkv,Skv,D] fp32"""
+    b, Sq, Hq, D = q.shape
+    Hkv, Skv = k.shape[1], k.shape[2]
+    rep = Hq // Hkv
+    kk = k[:, :, None].expand(b, Hkv, rep, Skv, D).reshape(b, Hq, Skv, D)
+    vv = v[:, :, None].expand(b, Hkv, rep, Skv, D).reshape(b, Hq, Skv, D)
+    s = torch.einsum("bqhd,bhkd->bhqk", q, kk) * scale
+    kpos = torch.arange(Skv)[None, None, None, :]
+    allowed = kpos < torch.tensor(kv_len)[:, None, None, None]
+    if causal:
+        allowed = allowed & (kpos <= (torch.arange(Sq)[None, None, :, None] + q_pos0))
+    s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhqk,bhkd->bqhd", p, vv)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Sq,Skv,Hq,Hkv,causal,lens", [
+    (2, 1025, 1025, 3, 3, 0, None),          # ViT shape: ragged 1024+1 tail
+    (1, 300, 300, 7, 1, 1, None),            # GQA group 7, causal
+    (2, 200, 200, 4, 2, 1, [200, 77]),       # right-padded batch
+    (1, 17, 17, 2, 2, 0, None),
+    (1, 129, 129, 2, 1, 1, None),
+])
+def test_attn_prefill(gpu_lib, dt, b, Sq, Skv, Hq, Hkv, causal, lens):
+    q = rnd(randn((b, Sq, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, Skv, 128), 2), dt); v = rnd(randn((b, Hkv, Skv, 128), 3), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    out = torch.full((b, Sq, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
+    dl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    scale = 128 ** -0.5
+    _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Sq, Skv, Hq, Hkv, ptr(dl), causal, 0, scale, None))
+    sync()
+    ref = _attn_ref(q, k, v, scale, causal, 0, lens or [Skv] * b)
+    for i in range(b):
+        n = Sq if lens is None else lens[i]
+        assert torch.isfinite(out[i, :n].float()).all()
+        assert rel(out[i, :n], ref[i, :n]) < TOL[dt], rel(out[i, :n], ref[i, :n])
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attn_prefill_softmax_spike(gpu_lib, dt):
+    """forces the running max to jump late (online-softmax rescale path, cdna guide rule 26)"""
+    Sq = Skv = 256
+    q = rnd(randn((1, Sq, 1, 128), 1, 0.3), dt); k = rnd(randn((1, 1, Skv, 128), 2, 0.3), dt); v = rnd(randn((1, 1, Skv, 128), 3), dt)
+    k[0, 0, 200] = q[0, 5, 0] * 40.0                # key 200 spikes for query 5 in the 4th kv tile
+    k = rnd(k, dt)
+    out = torch.empty((1, Sq, 1, 128), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dev(q, dt)), ptr(dev(k, dt)), ptr(dev(v, dt)), ptr(out), 1, Sq, Skv, 1, 1, None, 0, 0, 1.0, None))
+    sync()
+    ref = _attn_ref(q, k, v, 1.0, 0, 0, [Skv])
+    assert rel(out, ref) < TOL[dt]
+    assert rel(out[0, 5], ref[0, 5]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_mha_fwd_packed_qkv(gpu_lib, dt):
+    """the reference's one native seam: FlashAttention.forward(qkv[B,S,3,H,D]) (flash_attention.py:30-75)"""
+    B, S, H = 2, 65, 3
+    qkv = rnd(randn((B, S, 3, H, 128), 4), dt)
+    out = torch.empty((B, S, H, 128), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_mha_fwd(ptr(dev(qkv, dt)), B, S, H, 0.0, 0, ptr(out), CODE[dt], None))
+    sync()
+    q, k, v = qkv.unbind(2)
+    ref = _attn_ref(q, k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), 128 ** -0.5, 0, 0, [S] * B)
+    assert rel(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Hq,Hkv,cap,lens", [(1, 7, 1, 64, [1]), (1, 28, 4, 800, [700]), (3, 4, 2, 256, [63, 64, 65]), (2, 7, 1, 4096, [3585, 17])])
+def test_attn_decode(gpu_lib, dt, b, Hq, Hkv, cap, lens):
+    q = rnd(randn((b, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3), dt)
+    for i, n in enumerate(lens):                      # poison the unused tail: must never leak
+        k[i, :, n:] = float("nan"); v[i, :, n:] = float("nan")
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
+    L = max(lens)
+    wsb = gpu_lib.omchat_op_attn_decode_ws(b, Hq, L)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    scale = 128 ** -0.5
+    _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), scale, ptr(ws), wsb, None))
+    sync()
+    kk = torch.nan_to_num(k); vv = torch.nan_to_num(v)
+    ref = _attn_ref(q[:, None], kk, vv, scale, 0, 0, lens)[:, 0]
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, ref) < TOL[dt], rel(out, ref)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_rope_kv(gpu_lib, dt):
+    b, S, Hq, Hkv, cap, pos0 = 2, 9, 4, 2, 32, 5
+    qkv = rnd(randn((b * S, (Hq + 2 * Hkv) * 128), 1), dt)
+    d = dev(qkv, dt)
+    kc = torch.zeros(b, Hkv, cap, 128, dtype=DT[dt], device="cuda"); vc = torch.zeros_like(kc)
+    _lib.check(gpu_lib.omchat_op_rope_kv(CODE[dt], ptr(d), b, S, Hq, Hkv, pos0, 1e6, ptr(kc), ptr(vc), cap, None))
+    sync()
+    T = DT[dt]
+    x = qkv.to(T).view(b, S, Hq + 2 * Hkv, 128)
+    q = x[:, :, :Hq].transpose(1, 2); k = x[:, :, Hq:Hq + Hkv].transpose(1, 2); v = x[:, :, Hq + Hkv:].transpose(1, 2)
+    pos = (pos0 + torch.arange(S))[None].expand(b, S)
+    cos, sin = oracle.rope_cos_sin(pos, 128, 1e6, T)
+    qr, kr = oracle.apply_rope(q, k, cos, sin)
+    got_q = d.view(b, S, Hq + 2 * Hkv, 128)[:, :, :Hq].transpose(1, 2)
+    assert rel(got_q, qr.float()) < 3e-3
+    assert rel(kc[:, :, pos0:pos0 + S], kr.float()) < 3e-3
+    assert torch.equal(vc[:, :, pos0:pos0 + S].float().cpu(), v.float())
+    assert float(kc[:, :, :pos0].abs().max()) == 0.0 and float(kc[:, :, pos0 + S:].abs().max()) == 0.0
+
+
+def test_argmax_first_index_wins(gpu_lib):
+    x = torch.zeros(3, 152064); x[0, 7] = 5; x[0, 90000] = 5; x[1, 152063] = 1; x[2, :] = -1; x[2, 4000] = -0.5
+    d = x.cuda(); out = torch.empty(3, dtype=torch.int32, device="cuda")
+    _lib.check(gpu_lib.omchat_op_argmax(ptr(d), 3, 152064, ptr(out), None))
+    sync()
+    assert out.cpu().tolist() == [7, 152063, 4000]
+
+
+def test_errors_are_raised(gpu_lib):
+    a = torch.zeros(64, 100, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        _lib.check(gpu_lib.omchat_op_gemm(_lib.BF16, ptr(a), 100, ptr(a), 100, ptr(a), 64, 64, 64, 100, None, None, None, 0, 0, 0, None))
