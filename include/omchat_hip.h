@@ -106,6 +106,15 @@ int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* log
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
 int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
 
+/* ---- measurement: HIP-event timing of the dominant kernel classes, recorded on the launch stream ------------------ */
+#define OMCHAT_PROF_DECODE_GATEUP 0   /* decode gate|up weight-streaming GEMV (+SwiGLU), one launch per layer per token */
+#define OMCHAT_PROF_PREFILL_GATEUP 1  /* decoder prefill gate|up MFMA GEMM (+SwiGLU), one launch per layer */
+#define OMCHAT_PROF_VIT_FC1 2         /* ViT fc1 MFMA GEMM (+bias+GELU), one launch per layer */
+#define OMCHAT_PROF_CATS 3
+int omchat_prof_enable(omchat_ctx* ctx, int on);
+/* synchronises the device, folds the recorded event pairs into (total_ms, launches) for `cat`; reset != 0 clears. */
+int omchat_prof_read(omchat_ctx* ctx, int cat, double* total_ms, long* launches, int reset);
+
 /* ---- the one native op seam of the reference: FlashAttention.forward (intern_vit_6b/flash_attention.py:30-75) --- */
 /* qkv packed [B, S, 3, H, 128] -> out [B, S, H, 128]; softmax_scale <= 0 means 1/sqrt(128). */
 int omchat_mha_fwd(const void* qkv, int B, int S, int H, float softmax_scale, int causal, void* out, int dtype, void* stream);

@@ -10,6 +10,7 @@ _lib = None
 F16, BF16, F32 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_LS_RESID, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3, 4
 PAD_ROW = -(2 ** 31)
+PROF_DECODE_GATEUP, PROF_PREFILL_GATEUP, PROF_VIT_FC1 = 0, 1, 2
 
 
 class OmchatConfig(C.Structure):
@@ -45,6 +46,8 @@ _SIGS = {
     "omchat_decode_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "omchat_lm_head": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_kv_lengths": (_i, [_vp, _vp, _i]),
+    "omchat_prof_enable": (_i, [_vp, _i]),
+    "omchat_prof_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
     "omchat_mha_fwd": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "omchat_op_gemm": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_gemv": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -81,6 +81,16 @@ struct omchat_ctx {
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr;
   void *kcache = nullptr, *vcache = nullptr;   // [layers][max_batch][kv_heads][max_seq][128]
   std::vector<int> h_len;
+  // optional per-kernel-class HIP-event timing (bench.py roofline): category -> event pairs recorded on the launch stream
+  struct Prof { std::vector<hipEvent_t> ev; size_t used = 0; double ms = 0; long count = 0; };
+  bool prof_on = false;
+  Prof prof[OMCHAT_PROF_CATS];
+  void prof_mark(int cat, hipStream_t s) {
+    if (!prof_on) return;
+    Prof& p = prof[cat];
+    if (p.used == p.ev.size()) { hipEvent_t e; hipEventCreate(&e); p.ev.push_back(e); }
+    hipEventRecord(p.ev[p.used++], s);
+  }
   void* stage_f32 = nullptr; size_t stage_f32_bytes = 0;
   void* stage_t = nullptr; size_t stage_t_bytes = 0;
 
@@ -312,6 +322,7 @@ extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_s
 extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
   if (!ctx) return;
   for (void* p : ctx->allocs) hipFree(p);
+  for (auto& pr : ctx->prof) for (hipEvent_t e : pr.ev) hipEventDestroy(e);
   if (ctx->stage_f32) hipFree(ctx->stage_f32);
   if (ctx->stage_t) hipFree(ctx->stage_t);
   delete ctx;
@@ -348,7 +359,7 @@ static uint64_t fnv1a64(const std::string& s) {
 
 extern "C" int omchat_fill_synthetic(omchat_ctx* ctx, uint64_t seed) {
   OM_CHECK(ctx, "null ctx");
-  OM_CHECK(ctx->tp_size == 1, "synthetic fill generates unsharded tensors; shard on the host for tp_size > 1");
+  // tp_size > 1: every rank fills its LOCAL shapes (right geometry for benches; not a sharding of the TP=1 values)
   size_t maxn = 0;
   for (auto& kv : ctx->routes) maxn = std::max(maxn, (size_t)(kv.second.rows * kv.second.cols));
   TRY(ensure_stage(ctx, 16, maxn * 2));
@@ -419,7 +430,9 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
       std::swap(x, y);
     }
     TRY(launch_rmsnorm(ctx->dt, x, C, L.n2, ctx->vw_xn, C, M, C, c.v_eps, s));
+    ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
     TRY(gemm(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, s));
+    ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, EPI_LS_RESID, s));
     } else {
@@ -617,7 +630,9 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
       std::swap(x, y);
     }
     TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
+    ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
     TRY(gemm(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, nullptr, nullptr, 0, EPI_SWIGLU, s));
+    ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
@@ -687,7 +702,9 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
       std::swap(x, y);
     }
     TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
+    ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU));
+    ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -703,6 +720,27 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
   for (int i = 0; i < b; ++i) ctx->h_len[i] += 1;
+  return 0;
+}
+
+extern "C" int omchat_prof_enable(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null ctx");
+  ctx->prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int omchat_prof_read(omchat_ctx* ctx, int cat, double* total_ms, long* launches, int reset) {
+  OM_CHECK(ctx && cat >= 0 && cat < OMCHAT_PROF_CATS && total_ms && launches, "bad argument");
+  omchat_ctx::Prof& p = ctx->prof[cat];
+  OM_HIP(hipDeviceSynchronize());
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float ms = 0.f;
+    OM_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+    p.ms += ms; p.count += 1;
+  }
+  p.used = 0;
+  *total_ms = p.ms; *launches = p.count;
+  if (reset) { p.ms = 0; p.count = 0; }
   return 0;
 }
 

@@ -87,6 +87,14 @@ class Engine:
     def fill_synthetic(self, seed=0):
         check(self.lib.omchat_fill_synthetic(self.h, seed))
 
+    def prof_enable(self, on=True):
+        check(self.lib.omchat_prof_enable(self.h, int(on)))
+
+    def prof_read(self, cat, reset=True):
+        ms, n = C.c_double(0), C.c_long(0)
+        check(self.lib.omchat_prof_read(self.h, cat, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
     def device_bytes(self):
         return int(self.lib.omchat_device_bytes(self.h))
 

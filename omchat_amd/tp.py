@@ -112,3 +112,23 @@ def _shard_np(name, x, cfg, rank, size):
     if name == "lm_head.weight":
         return x[sl(t["vocab_size"])]
     return x
+
+
+def init_comm(rank, size):
+    """Create the RCCL communicator of the tensor-parallel group inside the library (one process per GPU).
+    The 128-byte unique id is created on rank 0 and shipped over the already-initialised torch.distributed group
+    (any backend; it is bootstrap plumbing only -- the data path all-reduces run on RCCL over xGMI in C++)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    lib = _lib.lib()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.omchat_comm_unique_id(buf))
+    t = torch.tensor(list(buf.raw), dtype=torch.uint8)
+    dist.broadcast(t, src=0)
+    raw = bytes(t.tolist())
+    comm = C.c_void_p()
+    _lib.check(lib.omchat_comm_init(raw, rank, size, C.byref(comm)))
+    return comm

@@ -131,9 +131,9 @@ def test_rmsnorm(gpu_lib, dt, H):
 def test_vit_qknorm(gpu_lib, dt):
     rows, C = 19, 384
     qkv = rnd(randn((rows, 3 * C), 1), dt); wq = rnd(randn((C,), 2, 0.1) + 1, dt); wk = rnd(randn((C,), 3, 0.1) + 1, dt)
-    d = dev(qkv, dt)
+    d = dev(qkv, dt); dwq = dev(wq, dt); dwk = dev(wk, dt)          # keep device tensors alive across the async launch
     scale = 128 ** -0.5
-    _lib.check(gpu_lib.omchat_op_vit_qknorm(CODE[dt], ptr(d), 3 * C, ptr(dev(wq, dt)), ptr(dev(wk, dt)), rows, C, C, 1e-6, scale, None))
+    _lib.check(gpu_lib.omchat_op_vit_qknorm(CODE[dt], ptr(d), 3 * C, ptr(dwq), ptr(dwk), rows, C, C, 1e-6, scale, None))
     sync()
     T = DT[dt]
     q = (oracle.rms_norm(qkv[:, :C].to(T), wq.to(T), 1e-6) * scale).float()
@@ -190,7 +190,8 @@ def test_attn_prefill_softmax_spike(gpu_lib, dt):
     k[0, 0, 200] = q[0, 5, 0] * 40.0                # key 200 spikes for query 5 in the 4th kv tile
     k = rnd(k, dt)
     out = torch.empty((1, Sq, 1, 128), dtype=DT[dt], device="cuda")
-    _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dev(q, dt)), ptr(dev(k, dt)), ptr(dev(v, dt)), ptr(out), 1, Sq, Skv, 1, 1, None, 0, 0, 1.0, None))
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), 1, Sq, Skv, 1, 1, None, 0, 0, 1.0, None))
     sync()
     ref = _attn_ref(q, k, v, 1.0, 0, 0, [Skv])
     assert rel(out, ref) < TOL[dt]
@@ -203,7 +204,8 @@ def test_mha_fwd_packed_qkv(gpu_lib, dt):
     B, S, H = 2, 65, 3
     qkv = rnd(randn((B, S, 3, H, 128), 4), dt)
     out = torch.empty((B, S, H, 128), dtype=DT[dt], device="cuda")
-    _lib.check(gpu_lib.omchat_mha_fwd(ptr(dev(qkv, dt)), B, S, H, 0.0, 0, ptr(out), CODE[dt], None))
+    dqkv = dev(qkv, dt)
+    _lib.check(gpu_lib.omchat_mha_fwd(ptr(dqkv), B, S, H, 0.0, 0, ptr(out), CODE[dt], None))
     sync()
     q, k, v = qkv.unbind(2)
     ref = _attn_ref(q, k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), 128 ** -0.5, 0, 0, [S] * B)
