@@ -104,6 +104,9 @@ int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int3
 int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream);
 /* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
+/* greedy pick (HF generate with do_sample=False: argmax of the last position, first index wins): logits fp32
+ * [b, t_vocab] (rank-local slice under tensor parallelism; the (max, index) pairs are exchanged) -> int32 [b] */
+int omchat_greedy(omchat_ctx* ctx, const float* logits, int b, int32_t* next_tokens, void* stream);
 int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
 
 /* ---- measurement: HIP-event timing of the dominant kernel classes, recorded on the launch stream ------------------ */
@@ -144,6 +147,12 @@ int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float 
 int omchat_comm_unique_id(char id[128]);
 int omchat_comm_init(const char id[128], int rank, int size, void** comm_out);
 void omchat_comm_destroy(void* comm);
+
+/* Test seam: replace the RCCL all-reduce of a tensor-parallel context by a caller-supplied function (sum over ranks,
+ * in place, `count` elements of dtype OMCHAT_F16/BF16/F32, ordered on `stream`).  Lets the whole TP dataflow be
+ * verified with several rank contexts on ONE GPU; production contexts never set it. */
+typedef int (*omchat_allreduce_fn)(void* user, void* buf, size_t count, int dtype, void* stream);
+int omchat_set_allreduce_hook(omchat_ctx* ctx, omchat_allreduce_fn fn, void* user);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,9 @@ _SIGS = {
     "omchat_prefill": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "omchat_decode_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "omchat_lm_head": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "omchat_greedy": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_kv_lengths": (_i, [_vp, _vp, _i]),
+    "omchat_set_allreduce_hook": (_i, [_vp, _vp, _vp]),
     "omchat_prof_enable": (_i, [_vp, _i]),
     "omchat_prof_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
     "omchat_mha_fwd": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
@@ -64,6 +66,9 @@ _SIGS = {
     "omchat_comm_destroy": (None, [_vp]),
 }
 EXPORTS = sorted(_SIGS)
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 def lib():

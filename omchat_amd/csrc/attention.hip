@@ -249,24 +249,56 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   }
 }
 
-// merge split-KV partials: one 128-thread block per (sequence, head)
+// merge split-KV partials: one 128-thread block per (sequence, head).  Phase 1: thread s owns split s (max, weight);
+// phase 2: thread d sums its column over the splits with independent (unrolled) loads.
 template <typename T>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
                                                          T* O, int64_t o_sb, int64_t o_sh) {
+  __shared__ float fw[1024];
+  __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const int len = kv_len ? kv_len[b] : L;
   int ns = (len + KV_TILE - 1) / KV_TILE;
   ns = ns < nsplit ? ns : nsplit;
   const float* w = ws + (size_t)(b * q_heads + h) * nsplit * WS_STRIDE;
-  float m = NEG_BIG;
-  for (int s = 0; s < ns; ++s) m = fmaxf(m, w[s * WS_STRIDE + 128]);
-  float acc = 0.f, l = 0.f;
-  for (int s = 0; s < ns; ++s) {
-    const float f = exp2f((w[s * WS_STRIDE + 128] - m) * c);
-    acc += f * w[s * WS_STRIDE + d];
-    l += f * w[s * WS_STRIDE + 129];
+  float acc = 0.f, ltot = 0.f, m_run = NEG_BIG;
+  for (int s0 = 0; s0 < ns; s0 += 1024) {                 // chunks of up to 1024 splits (64k keys)
+    const int n = ns - s0 < 1024 ? ns - s0 : 1024;
+    // phase 1
+    float mloc = NEG_BIG;
+    for (int s = d; s < n; s += 128) mloc = fmaxf(mloc, w[(size_t)(s0 + s) * WS_STRIDE + 128]);
+    mloc = wave_max(mloc);
+    if ((d & 63) == 0) red[d >> 6] = mloc;
+    __syncthreads();
+    const float m_new = fmaxf(m_run, fmaxf(red[0], red[1]));
+    __syncthreads();
+    float lloc = 0.f;
+    for (int s = d; s < n; s += 128) {
+      const float f = exp2f((w[(size_t)(s0 + s) * WS_STRIDE + 128] - m_new) * c);
+      fw[s] = f;
+      lloc += f * w[(size_t)(s0 + s) * WS_STRIDE + 129];
+    }
+    lloc = wave_sum(lloc);
+    if ((d & 63) == 0) red[2 + (d >> 6)] = lloc;
+    __syncthreads();
+    const float alpha = exp2f((m_run - m_new) * c);
+    ltot = ltot * alpha + red[2] + red[3];
+    acc *= alpha;
+    m_run = m_new;
+    // phase 2
+    const float* wd = w + (size_t)s0 * WS_STRIDE + d;
+    int s = 0;
+    for (; s + 8 <= n; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wd[(size_t)(s + u) * WS_STRIDE];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += fw[s + u] * v[u];
+    }
+    for (; s < n; ++s) acc += fw[s] * wd[(size_t)s * WS_STRIDE];
+    __syncthreads();
   }
-  O[b * o_sb + h * o_sh + d] = fromf<T>(acc / l);
+  O[b * o_sb + h * o_sh + d] = fromf<T>(acc / ltot);
 }
 
 }  // namespace

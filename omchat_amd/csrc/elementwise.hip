@@ -57,6 +57,57 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
   }
 }
 
+// decode tail of o_proj / down_proj: add the split-K fp32 slices (fixed order), round like the reference
+// (T(linear) then T(residual + .), modeling_qwen2.py:283-296), then the NEXT RMSNorm of the same row, in one pass.
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int ldx, const float* part, int ks, int rows, const T* w, T* xn,
+                                                                     int ldn, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  T* xr = x + (size_t)row * ldx;
+  const int nchunk = H >> 3;
+  float xv[NORM_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 xi = ld8<T>(xr + c * 8);
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      for (int s = 0; s < ks; ++s) {
+        const float* pp = part + ((size_t)s * rows + row) * H + c * 8;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += p0[j]; a[4 + j] += p1[j]; }
+      }
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rnd<T>(tof(xi[j]) + rnd<T>(a[j]));
+        xv[i][j] = v; o[j] = fromf<T>(v); ss += v * v;
+      }
+      st8<T>(xr + c * 8, o);
+    }
+  }
+  if (!w) return;
+  const float inv = rsqrtf(block_sum(ss, red) / (float)H + eps);
+  T* nr = xn + (size_t)row * ldn;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 wv = ld8<T>(w + c * 8);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(xv[i][j] * inv));
+      st8<T>(nr + c * 8, o);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ViT q/k norm over ALL heads of a token (modeling_intern_vit.py:143-146), in place on the fused qkv row, followed by
 // q * head_dim^-0.5 rounded in the storage type exactly where _naive_attn does it (:148).
@@ -241,31 +292,37 @@ __global__ void copy_rows_kernel(const T* src, int64_t src_ld, T* dst, int64_t d
   }
 }
 
-// greedy argmax over fp32 logits, first index wins ties (torch.argmax semantics)
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* logits, int ld, int V, int* out) {
-  __shared__ float bv[16];
-  __shared__ int bi[16];
-  const float* row = logits + (size_t)blockIdx.x * ld;
+// greedy argmax over fp32 logits, first index wins ties (torch.argmax semantics).  Two stages:
+// ARG_CHUNKS workgroups per row reduce a slice each, then one wave picks among the slice winners.
+constexpr int ARG_CHUNKS = 64;
+__device__ __forceinline__ void arg_better(float& best, int& besti, float v, int i) {
+  if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+}
+__global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* logits, int ld, int V, float* pv, int* pi) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const float* row = logits + (size_t)blockIdx.y * ld;
+  const int per = (V + ARG_CHUNKS - 1) / ARG_CHUNKS;
+  const int lo = blockIdx.x * per, hi = lo + per < V ? lo + per : V;
   float best = -INFINITY;
   int besti = INT_MAX;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) {
-    const float v = row[i];
-    if (v > best || (v == best && i < besti) || besti == INT_MAX) { best = v; besti = i; }
-  }
+  for (int i = lo + threadIdx.x; i < hi; i += 256) arg_better(best, besti, row[i], i);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(besti, o, 64);
-    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+  for (int o = 32; o > 0; o >>= 1) arg_better(best, besti, __shfl_xor(best, o, 64), __shfl_xor(besti, o, 64));
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-    out[blockIdx.x] = besti;
+    for (int w = 1; w < 4; ++w) arg_better(best, besti, bv[w], bi[w]);
+    pv[blockIdx.y * ARG_CHUNKS + blockIdx.x] = best;
+    pi[blockIdx.y * ARG_CHUNKS + blockIdx.x] = besti;
   }
+}
+__global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* pv, const int* pi, int* out) {
+  float best = pv[blockIdx.x * ARG_CHUNKS + threadIdx.x];
+  int besti = pi[blockIdx.x * ARG_CHUNKS + threadIdx.x];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) arg_better(best, besti, __shfl_xor(best, o, 64), __shfl_xor(besti, o, 64));
+  if (threadIdx.x == 0) out[blockIdx.x] = besti == INT_MAX ? 0 : besti;
 }
 
 // omchat_amd/synth.py::uniform, bit for bit
@@ -383,7 +440,26 @@ int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int6
 
 int launch_argmax(const float* logits, int ld, int b, int V, int* out, hipStream_t s) {
   if (b == 0) return 0;
-  hipLaunchKernelGGL(argmax_kernel, dim3(b), dim3(1024), 0, s, logits, ld, V, out);
+  static float* pv = nullptr;
+  static int* pi = nullptr;
+  static int cap = 0;
+  if (b > cap) {            // tiny scratch for the slice winners, grown on demand outside any capture
+    if (pv) { hipFree(pv); hipFree(pi); }
+    cap = b > 64 ? b : 64;
+    OM_HIP(hipMalloc(&pv, (size_t)cap * ARG_CHUNKS * 4));
+    OM_HIP(hipMalloc(&pi, (size_t)cap * ARG_CHUNKS * 4));
+  }
+  hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARG_CHUNKS, b), dim3(256), 0, s, logits, ld, V, pv, pi);
+  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(b), dim3(64), 0, s, pv, pi, out);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
+                         hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldn % 8 == 0 && ks >= 1, "H % 8, H <= 16384, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(resid_rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, part, ks, rows, (const T*)w, (T*)xn, ldn, H, eps));
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -188,7 +188,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
   int tile = a.force_tile;
   if (tile == 0) {
     const long big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-    tile = (big >= 208) ? 2 : 1;      // >= ~0.8 of the 256 CUs busy with 256^2 tiles, else more, smaller tiles
+    tile = (big >= 128) ? 2 : 1;      // measured (r01): the 256^2 kernel at half-filled CUs still beats the 128^2 one
   }
   if (tile == 2) return launch_cfg<T, 256, 256, 2, 4, EPI>(a, stream);
   return launch_cfg<T, 128, 128, 2, 2, EPI>(a, stream);

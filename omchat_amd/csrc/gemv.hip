@@ -15,7 +15,7 @@ namespace {
 
 struct GemvP {
   const void* X; const void* W; void* Y; const void* bias; const void* resid;
-  int ldx, ldw, ldy, ldr, b, N, K, out_f32;
+  int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
 };
 
 constexpr int GV_WAVES = 8;
@@ -46,12 +46,15 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = p.K / 64;
+  // K slice of this workgroup (blockIdx.y of ksplit): chunks [c_lo, c_hi)
+  const int nchunk_all = p.K / 64;
+  const int c_lo = (int)(((long)nchunk_all * blockIdx.y) / p.ksplit);
+  const int nchunk = (int)(((long)nchunk_all * (blockIdx.y + 1)) / p.ksplit);
   frag_t zero;
 #pragma unroll
   for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
 
-  int c0 = wave;
+  int c0 = c_lo + wave;
   // full groups: no per-load predicate (a runtime select around each load would serialise them)
   for (; c0 + (GV_UNROLL - 1) * GV_WAVES < nchunk; c0 += GV_WAVES * GV_UNROLL) {
     frag_t wf[GV_UNROLL][NTILE][2], xf[GV_UNROLL][2];
@@ -112,7 +115,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   for (int i = 0; i < 4; ++i) {
     const int e = lane + 64 * i, nl = e >> 4, bi = e & 15;
     if (bi >= p.b) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (EPI == EPI_PARTIAL) {
+      // raw fp32 K-slice sums, layout [ksplit][b][ldy]; the consumer (resid_rmsnorm) adds the slices in a fixed order
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = n0 + t * 16 + nl;
+        if (n < p.N) ((float*)p.Y)[((size_t)blockIdx.y * p.b + bi) * p.ldy + n] = v[t][i];
+      }
+    } else if constexpr (EPI == EPI_SWIGLU) {
       // tile 0 = 16 gate rows, tile 1 = the matching 16 up rows
       const int n = (n0 >> 1) + nl;
       if (n0 + 16 + nl < p.N) {
@@ -139,8 +149,11 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32};
-  if (a.epi == EPI_SWIGLU) {
+  const int ks = a.ksplit > 1 ? a.ksplit : 1;
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks};
+  if (a.epi == EPI_PARTIAL) {
+    hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_PARTIAL>), dim3(cdiv(a.N, 16), ks), dim3(GV_WAVES * 64), 0, s, p);
+  } else if (a.epi == EPI_SWIGLU) {
     hipLaunchKernelGGL((gemv_kernel<T, 2, EPI_SWIGLU>), dim3(cdiv(a.N, 32)), dim3(GV_WAVES * 64), 0, s, p);
   } else if (a.epi == EPI_RESID) {
     hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_RESID>), dim3(cdiv(a.N, 16)), dim3(GV_WAVES * 64), 0, s, p);
@@ -160,7 +173,9 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 16, "batch must be 1..16 per call");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
-  OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU, "bad epilogue");
+  OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU || a.epi == EPI_PARTIAL, "bad epilogue");
+  OM_CHECK(a.ksplit <= 1 || a.epi == EPI_PARTIAL, "ksplit > 1 only with EPI_PARTIAL (fp32 slices)");
+  OM_CHECK(a.ksplit <= a.K / 64, "ksplit exceeds the number of 64-wide K chunks");
   OM_CHECK(a.epi != EPI_RESID || a.resid, "resid missing");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU needs N % 32 == 0");
   OM_CHECK(!(a.out_f32 && a.epi != EPI_NONE), "fp32 output only with EPI_NONE");

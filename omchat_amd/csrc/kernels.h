@@ -11,6 +11,7 @@ enum {
   EPI_LS_RESID = 2,  // C = T(resid + T(T(acc + bias?) * ls))                 (ViT: x + branch * ls)
   EPI_RESID = 3,     // C = T(resid + T(acc + bias?))                         (decoder o_proj / down_proj)
   EPI_SWIGLU = 4,    // W rows interleaved [16 gate | 16 up]: C[M,N/2] = T(T(silu(T(g))) * T(u))
+  EPI_PARTIAL = 5,   // skinny GEMM only: raw fp32 K-slice sums Y[ksplit][b][ldy] (split-K across workgroups)
 };
 struct GemmArgs {
   const void* A; int lda;
@@ -35,14 +36,18 @@ struct GemvArgs {
   int b, N, K;
   const void* bias;
   const void* resid; int ldr;
-  int epi;                  // EPI_NONE | EPI_RESID | EPI_SWIGLU
+  int epi;                  // EPI_NONE | EPI_RESID | EPI_SWIGLU | EPI_PARTIAL
   int out_f32;
+  int ksplit;               // K slices across workgroups (EPI_PARTIAL), <= 1 = none
 };
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)
 int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s);
+// decode: x = T(x + T(sum_s part[s])) in place, then xn = rmsnorm(x) * w (w == null: skip the norm).  part fp32 [ks][rows][H]
+int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
+                         hipStream_t s);
 // ViT joint-head q/k RMSNorm in place on the fused qkv buffer [rows, 3C] (q = cols [0,C), k = [C,2C)); q is also
 // multiplied by q_scale with the reference's rounding (modeling_intern_vit.py:143-148).
 // sumsq_in: optional [rows,2] fp32 externally reduced sum of squares (tensor parallel); C_total = divisor.

@@ -35,6 +35,28 @@ __global__ void last_row_index_kernel(const int* len, int S, int b, int* idx) {
   if (i < b) idx[i] = i * S + len[i] - 1;
 }
 
+// vocab-parallel greedy: every rank contributes (max logit, global index) per sequence; summed into a zeroed table
+__global__ void tp_argmax_scatter_kernel(const float* logits, int ld, const int* local_idx, int b, int rank, int v_local, float* table) {
+  const int i = threadIdx.x;
+  if (i < b) {
+    table[((size_t)rank * b + i) * 2] = logits[(size_t)i * ld + local_idx[i]];
+    table[((size_t)rank * b + i) * 2 + 1] = (float)(rank * v_local + local_idx[i]);
+  }
+}
+__global__ void tp_argmax_pick_kernel(const float* table, int b, int size, int* out) {
+  const int i = threadIdx.x;
+  if (i < b) {
+    float best = table[(size_t)i * 2]; int bi = (int)table[(size_t)i * 2 + 1];
+    for (int r = 1; r < size; ++r) {            // ranks hold ascending index ranges: strict > keeps the first index on ties
+      const float v = table[((size_t)r * b + i) * 2];
+      if (v > best) { best = v; bi = (int)table[((size_t)r * b + i) * 2 + 1]; }
+    }
+    out[i] = bi;
+  }
+}
+
+constexpr int DEC_KS_MAX = 8;
+
 enum RouteKind { R_PLAIN = 0, R_GATE = 1, R_UP = 2, R_PATCH = 3 };
 struct Route {
   void* dst = nullptr;
@@ -76,6 +98,8 @@ struct omchat_ctx {
   float* vw_sumsq = nullptr;
   void *tw_x = nullptr, *tw_x2 = nullptr, *tw_xn = nullptr, *tw_qkv = nullptr, *tw_ao = nullptr, *tw_act = nullptr, *tw_last = nullptr;
   float* tw_logits = nullptr;
+  float* tp_table = nullptr;
+  float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
   float* tw_attn_ws = nullptr;
   size_t tw_attn_ws_bytes = 0;
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr;
@@ -107,14 +131,18 @@ struct omchat_ctx {
   int64_t cache_sb() const { return (int64_t)c.t_kv_heads * c.max_seq * 128; }
   int64_t cache_sh() const { return (int64_t)c.max_seq * 128; }
 
+  omchat_allreduce_fn hook = nullptr;
+  void* hook_user = nullptr;
   int allreduce(void* buf, size_t count, hipStream_t s) {
     if (tp_size == 1) return 0;
+    if (hook) return hook(hook_user, buf, count, dt, s);
     ncclResult_t r = ncclAllReduce(buf, buf, count, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, ncclSum, comm, s);
     if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
     return 0;
   }
   int allreduce_f32(float* buf, size_t count, hipStream_t s) {
     if (tp_size == 1) return 0;
+    if (hook) return hook(hook_user, buf, count, OMCHAT_F32, s);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, s);
     if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
     return 0;
@@ -253,6 +281,8 @@ int build(omchat_ctx* ctx) {
     TRY(ctx->alloc((void**)&ctx->tw_logits, (size_t)c.max_batch * c.t_vocab * 4));
     ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
     TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
+    TRY(ctx->alloc((void**)&ctx->tw_part, (size_t)DEC_KS_MAX * c.max_batch * H * 4));
+    TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
     TRY(ctx->alloc((void**)&ctx->d_pos, (size_t)c.max_batch * 4));
     TRY(ctx->alloc((void**)&ctx->d_len, (size_t)c.max_batch * 4));
     TRY(ctx->alloc((void**)&ctx->d_idx, (size_t)c.max_batch * 4));
@@ -520,7 +550,7 @@ extern "C" int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b
   OM_CHECK(ids && S_out && b > 0 && T > 0 && n_tok >= 0, "bad argument");
   // pass 1: lengths (omchat_arch.py:115-164); a row without sentinels still consumes one tile slot (:122-129)
   std::vector<int> len(b);
-  int cur = 0, S = 0;
+  int cur = 0, S = 0, total_img = 0;
   for (int i = 0; i < b; ++i) {
     int n = 0, n_img = 0;
     for (int t = 0; t < T; ++t) {
@@ -528,11 +558,13 @@ extern "C" int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b
       if (ids[(size_t)i * T + t] == -200) { n += n_tok; ++n_img; } else ++n;
     }
     cur += n_img == 0 ? 1 : n_img;
+    total_img += n_img;
     if (max_length > 0 && n > max_length) n = max_length;
     len[i] = n;
     S = std::max(S, n);
   }
-  OM_CHECK(cur <= n_tiles_avail || n_tok == 0, "more <image> sentinels than image tiles (reference: IndexError on image_features)");
+  // text-only call (no tiles, no sentinels) = plain embed_tokens lookup (the reference short-circuits before the splice, :59-70)
+  OM_CHECK(cur <= n_tiles_avail || n_tok == 0 || (n_tiles_avail == 0 && total_img == 0), "more <image> sentinels than image tiles (reference: IndexError on image_features)");
   *S_out = S;
   if (lengths) for (int i = 0; i < b; ++i) lengths[i] = len[i];
   if (!src_index) return 0;
@@ -576,6 +608,25 @@ static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logit
     TRY(launch_gemv(ctx->dt, g, s));
   }
   return 0;
+}
+
+// greedy argmax over (rank-local) logits; under tensor parallelism the (max, index) pairs are exchanged
+static int greedy_pick(omchat_ctx* ctx, const float* lg, int b, int32_t* next_tokens, hipStream_t s) {
+  const omchat_config& c = ctx->c;
+  TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, s));
+  if (ctx->tp_size > 1) {
+    const size_t n = (size_t)ctx->tp_size * b * 2;
+    OM_HIP(hipMemsetAsync(ctx->tp_table, 0, n * 4, s));
+    hipLaunchKernelGGL(tp_argmax_scatter_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, lg, c.t_vocab, next_tokens, b, ctx->tp_rank, c.t_vocab, ctx->tp_table);
+    TRY(ctx->allreduce_f32(ctx->tp_table, n, s));
+    hipLaunchKernelGGL(tp_argmax_pick_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->tp_table, b, ctx->tp_size, next_tokens);
+  }
+  return 0;
+}
+
+extern "C" int omchat_greedy(omchat_ctx* ctx, const float* logits, int b, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && logits && next_tokens && b >= 1 && b <= ctx->c.max_batch, "bad argument");
+  return greedy_pick(ctx, logits, b, next_tokens, (hipStream_t)stream);
 }
 
 extern "C" int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream) {
@@ -673,16 +724,26 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     for (int r0 = 0; r0 < b; r0 += 16) {
       const int R = std::min(16, b - r0);
       GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
-                 resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0};
+                 resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
       TRY(launch_gemv(ctx->dt, g, s));
     }
     return 0;
   };
+  // split-K over workgroups: fp32 slices [ks][b][H], summed by the fused residual + RMSNorm kernel
+  auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks) -> int {
+    OM_CHECK(b <= 16, "split-K decode path handles b <= 16");
+    GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 1, ks};
+    return launch_gemv(ctx->dt, g, s);
+  };
+  const bool fused = ctx->tp_size == 1 && b <= 16;
+  const int ks_o = std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));      // ~2 workgroups per CU
+  const int ks_d = std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 2 * cdiv(512, cdiv(H, 16)))));
+  if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
-    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
+    if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
     TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE));
     RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
     TRY(launch_rope_kv(ctx->dt, r, s));
@@ -694,18 +755,25 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     a.batch = b; a.q_heads = c.t_heads; a.kv_heads = c.t_kv_heads; a.L = Lmax; a.kv_len = ctx->d_len; a.scale = 0.08838834764831845f;
     a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
     TRY(launch_attn_decode(ctx->dt, a, s));
-    if (ctx->tp_size == 1) {
+    if (fused) {
+      TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o));
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
+    } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
     } else {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, y, H, H, nullptr, lead ? x : nullptr, lead ? EPI_RESID : EPI_NONE));
       TRY(ctx->allreduce(y, (size_t)b * H, s));
       std::swap(x, y);
     }
-    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
+    if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
     ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU));
     ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    if (ctx->tp_size == 1) {
+    if (fused) {
+      TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d));
+      const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s));
+    } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
     } else {
       TRY(gemv(ctx->tw_act, It, L.wd, It, y, H, H, nullptr, lead ? x : nullptr, lead ? EPI_RESID : EPI_NONE));
@@ -713,13 +781,19 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
       std::swap(x, y);
     }
   }
-  TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
+  if (!fused)   TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
   float* lg = logits ? logits : ctx->tw_logits;
   TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s));
-  if (next_tokens) TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, s));
+  if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
   for (int i = 0; i < b; ++i) ctx->h_len[i] += 1;
+  return 0;
+}
+
+extern "C" int omchat_set_allreduce_hook(omchat_ctx* ctx, omchat_allreduce_fn fn, void* user) {
+  OM_CHECK(ctx, "null ctx");
+  ctx->hook = fn; ctx->hook_user = user;
   return 0;
 }
 

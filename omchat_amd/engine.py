@@ -195,5 +195,5 @@ class Engine:
     def argmax(self, logits):
         torch = _torch()
         out = torch.empty(logits.shape[0], dtype=torch.int32, device=self.device)
-        check(self.lib.omchat_op_argmax(ptr(logits), logits.shape[0], logits.shape[1], ptr(out), cur_stream()))
+        check(self.lib.omchat_greedy(self.h, ptr(logits), logits.shape[0], ptr(out), cur_stream()))
         return out

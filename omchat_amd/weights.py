@@ -64,7 +64,7 @@ def prepare_state_dict(sd, cfg, vision=True, text=True):
             continue
         out[k] = v
     pk = TOWER + "embeddings.position_embedding"
-    if pk in out:
+    if pk in out and len(out[pk].shape) >= 2 and int(np.prod(out[pk].shape[:-1])) > 1:
         g_dst = cfg.vision["image_size"] // cfg.vision["patch_size"]
         n = int(np.prod(out[pk].shape[:-1])) - 1
         g_src = int(round(n ** 0.5))

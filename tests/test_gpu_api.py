@@ -1,0 +1,119 @@
+"""GPU: the reference-shaped Python API (load_pretrained_model -> model.generate(input_ids, images=...), the HF facade,
+prepare_inputs_labels_for_multimodal's 6-tuple) on synthetic checkpoints in both key layouts, checked with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from gpu_util import rel, sync, TOL_DEEP
+from omchat_amd import synth
+from omchat_amd.config import tiny
+from omchat_amd.model import load_pretrained_model, save_synthetic_checkpoint, OmChatForConditionalGeneration, KVHandle
+import oracle
+
+T32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+I = -200
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory, gpu_lib):
+    cfg = tiny()
+    root = tmp_path_factory.mktemp("ckpt")
+    return cfg, save_synthetic_checkpoint(str(root / "native"), cfg, 9, "native"), save_synthetic_checkpoint(str(root / "hf"), cfg, 9, "hf")
+
+
+def _oracle_generate(cfg, ids, px, n):
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 9).items()}
+    return oracle.greedy_generate(ids, px, sd, cfg.vision, cfg.text, n)
+
+
+def test_load_pretrained_model_and_generate(ckpt):
+    cfg, native, _ = ckpt
+    tokenizer, model, image_processor, context_len = load_pretrained_model(native, "native", max_seq=256, max_tiles=2)
+    assert context_len == 2048 and image_processor.crop_size["height"] == 448
+    assert model.config.image_grid_pinpoints == cfg.image_grid_pinpoints            # single_inference.py:46
+    assert model.get_vision_tower().is_loaded and model.get_vision_tower().num_patches == 16
+    model.generation_config.pad_token_id = tokenizer.pad_token_id                   # single_inference.py:50
+    px = T32(synth.pixels(2, 56, 5))
+    ids = torch.tensor([[3, I, 17, 18, I, 19, 20, 21]])
+
+    class Streamer:
+        def __init__(self): self.got, self.ended = [], False
+        def put(self, x): self.got.append(x)
+        def end(self): self.ended = True
+    st = Streamer()
+    out = model.generate(ids, images=px.half().cuda(), do_sample=False, temperature=0, max_new_tokens=8, streamer=st, use_cache=True,
+                         eos_token_id=151645)
+    assert out.shape == (1, ids.shape[1] + 8) and torch.equal(out[:, :ids.shape[1]], ids)
+    assert st.ended and len(st.got) == 9 and torch.equal(st.got[0], ids)
+    ref, margins = _oracle_generate(cfg, ids, px, 8)
+    for i, (a, b, m) in enumerate(zip(out[0, ids.shape[1]:].tolist(), ref, margins)):
+        if m < 0.02:
+            break                                    # a near-tie in the fp32 oracle: later tokens may legitimately diverge
+        assert a == b, (i, a, b, m)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, images=px.cuda(), do_sample=True)
+
+
+def test_generate_stops_on_eos_and_keeps_it(ckpt):
+    cfg, native, _ = ckpt
+    _, model, _, _ = load_pretrained_model(native, "native", max_seq=256, max_tiles=2)
+    px = T32(synth.pixels(1, 56, 6)).half().cuda()
+    ids = torch.tensor([[5, I, 7]])
+    free = model.generate(ids, images=px, max_new_tokens=6)
+    eos = int(free[0, ids.shape[1] + 2])                     # declare the 3rd generated token to be EOS
+    out = model.generate(ids, images=px, max_new_tokens=6, eos_token_id=eos)
+    first = free[0, ids.shape[1]:].tolist().index(eos)
+    assert out.shape[1] == ids.shape[1] + first + 1 and int(out[0, -1]) == eos      # EOS kept (README.md:77)
+
+
+def test_forward_protocol_prefill_then_decode(ckpt):
+    """step 0: full ids + images; step >= 1: last token + cache, images re-passed and ignored (omchat_qwen2.py:92-111)"""
+    cfg, native, _ = ckpt
+    _, model, _, _ = load_pretrained_model(native, "native", max_seq=256, max_tiles=2)
+    px = T32(synth.pixels(2, 56, 5))
+    ids = torch.tensor([[3, I, 17, I, 19]])
+    mask = torch.ones_like(ids)
+    r = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, px.half().cuda())
+    assert r[0] is None and r[1] is None and r[3] is None and r[5] is None
+    assert r[4].shape == (1, 3 + 2 * 16, 256) and r[2].dtype == mask.dtype and int(r[2].sum()) == 35
+    out = model(input_ids=ids, attention_mask=mask, images=px.half().cuda(), use_cache=True)
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 9).items()}
+    ref_logits, cache, _ = oracle.prefill(ids, px, sd, cfg.vision, cfg.text)
+    sync()
+    assert out.logits.shape == (1, 1, 320)
+    assert rel(out.logits[0, 0], ref_logits[0, -1]) < TOL_DEEP["f16"]
+    past = out.past_key_values
+    assert isinstance(past, KVHandle) and past.get_seq_length() == 35 and past[-1][-1].shape[-2] == 35      # omchat_arch.py:63 probe
+    tok = int(torch.argmax(out.logits[0, 0]))
+    inp = model.prepare_inputs_for_generation(torch.cat([ids, torch.tensor([[tok]])], 1), past_key_values=past, attention_mask=mask,
+                                              images=px.half().cuda(), use_cache=True)
+    assert inp["input_ids"].shape == (1, 1)
+    out2 = model(**inp)
+    ref2 = oracle.decode_step(torch.tensor([[tok]]), sd, cfg.text, cache)
+    sync()
+    assert rel(out2.logits[0, 0], ref2[0, 0]) < TOL_DEEP["f16"]
+    assert past.get_seq_length() == 36
+
+
+def test_hf_facade_same_tokens_as_native(ckpt):
+    cfg, native, hf = ckpt
+    _, m_native, _, _ = load_pretrained_model(native, "native", max_seq=256, max_tiles=2)
+    m_hf = OmChatForConditionalGeneration.from_pretrained(hf, trust_remote_code=True, torch_dtype=torch.float16, max_seq=256, max_tiles=2).cuda()
+    assert m_hf.vision_tower.select_layer == -1 and m_hf.multi_modal_projector is not None and m_hf.language_model is not None
+    px = T32(synth.pixels(1, 56, 8)).half().cuda()
+    inputs = {"input_ids": torch.tensor([[9, I, 4, 2]]), "images": px}
+    a = m_hf.generate(**inputs, max_new_tokens=6, do_sample=False, eos_token_id=None, pad_token_id=0)
+    b = m_native.generate(inputs["input_ids"], images=px, max_new_tokens=6)
+    assert torch.equal(a, b)
+
+
+def test_text_only_and_bf16(ckpt):
+    cfg, native, _ = ckpt
+    _, model, _, _ = load_pretrained_model(native, "native", max_seq=128, max_tiles=1, torch_dtype=torch.bfloat16)
+    ids = torch.tensor([[3, 4, 5, 6, 7]])
+    out = model(input_ids=ids)
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 9).items()}
+    ref, _, _ = oracle.prefill(ids, None, sd, cfg.vision, cfg.text)
+    sync()
+    assert rel(out.logits[0, 0], ref[0, -1]) < TOL_DEEP["bf16"]

@@ -1,0 +1,111 @@
+"""GPU (one device): the C++ tensor-parallel dataflow end to end.  Two rank contexts (tp_size = 2) live on the same GPU,
+run in two threads, and their all-reduces are served by the test through omchat_set_allreduce_hook (sum of both
+ranks' buffers).  Outputs must equal the tp_size = 1 engine / the oracle.  RCCL itself is exercised by bench.py --gpus N."""
+import ctypes as C
+import threading
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from gpu_util import rel, sync, TOL_DEEP
+from omchat_amd import synth, _lib
+from omchat_amd.config import tiny
+from omchat_amd.engine import Engine
+import oracle
+
+T32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+TDT = {_lib.F16: torch.float16, _lib.BF16: torch.bfloat16, _lib.F32: torch.float32}
+
+
+class Group:
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.calls = 0
+
+    def hook_for(self, rank):
+        def hook(user, buf, count, dtype, stream):
+            torch.cuda.synchronize()
+            self.slots[rank] = buf
+            self.barrier.wait()
+            if rank == 0:
+                tdt = TDT[dtype]
+                nbytes = count * torch.empty(0, dtype=tdt).element_size()
+                parts = []
+                for b in self.slots:
+                    t = torch.empty(count, dtype=tdt, device="cuda")
+                    assert self.hip.hipMemcpy(t.data_ptr(), b, nbytes, 3) == 0
+                    parts.append(t.float())
+                s = sum(parts).to(tdt)
+                for b in self.slots:
+                    assert self.hip.hipMemcpy(b, s.data_ptr(), nbytes, 3) == 0
+                torch.cuda.synchronize()
+                self.calls += 1
+            self.barrier.wait()
+            return 0
+        return _lib.ALLREDUCE_FN(hook)
+
+
+def _run_ranks(fn, n):
+    out, err = [None] * n, [None] * n
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:          # noqa
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("q,kv,hv", [(4, 2, 3), (7, 1, 2)])
+def test_tp2_on_one_gpu_equals_tp1(gpu_lib, dt, q, kv, hv):
+    cfg = tiny(q_heads=q, kv_heads=kv, heads_v=hv)
+    sd = synth.state_dict(cfg, 13)
+    grp = Group(2)
+    engines, hooks = [], []
+    for r in range(2):
+        e = Engine(cfg, dtype=dt, max_seq=128, max_batch=1, max_tiles=2, tp_rank=r, tp_size=2, comm=C.c_void_p(1))
+        h = grp.hook_for(r)
+        _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+        e.load_state_dict(sd)
+        engines.append(e); hooks.append(h)
+    px = T32(synth.pixels(2, 56, 1))
+    ids = torch.tensor([[3, -200, 17, -200, 19, 20]])
+
+    def run(r):
+        e = engines[r]
+        feats = e.encode_images(px)
+        embeds, lengths, _ = e.splice(ids, None, feats)
+        logits, _ = e.prefill(embeds, lengths)
+        nxt, lg = e.decode_step(torch.tensor([5]), want_logits=True)
+        torch.cuda.synchronize()
+        return feats.float().cpu(), logits.float().cpu(), lg.float().cpu(), int(nxt[0])
+
+    res = _run_ranks(run, 2)
+    assert grp.calls > 0
+    assert torch.equal(res[0][0], res[1][0])                      # both ranks hold identical activations after the all-reduce
+    sdt = {k: T32(v) for k, v in sd.items()}
+    ref_feats = oracle.encode_images(px, sdt, cfg.vision)
+    assert rel(res[0][0], ref_feats) < TOL_DEEP[dt]
+    ref_logits, cache, _ = oracle.prefill(ids, px, sdt, cfg.vision, cfg.text)
+    V = cfg.text["vocab_size"]
+    full = torch.cat([res[0][1], res[1][1]], dim=-1)              # vocab-parallel lm_head: rank r holds rows [r*V/2, (r+1)*V/2)
+    assert full.shape[-1] == V
+    assert rel(full[0], ref_logits[0, -1]) < TOL_DEEP[dt]
+    ref_step = oracle.decode_step(torch.tensor([[5]]), sdt, cfg.text, cache)
+    assert rel(torch.cat([res[0][2], res[1][2]], dim=-1)[0], ref_step[0, 0]) < TOL_DEEP[dt]
+    assert res[0][3] == res[1][3]                                 # vocab-parallel greedy: (max, argmax) pairs exchanged
+    full_step = torch.cat([res[0][2], res[1][2]], dim=-1)[0]
+    assert res[0][3] == int(torch.argmax(full_step))
+    for e in engines:
+        e.close()

@@ -1,0 +1,210 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/omchat_hip.h declares; host-side logic
+(splice plan, prompt layout, key mapping, config parsing, error paths) against golden vectors."""
+import ctypes as C
+import json
+import os
+import re
+import types
+import numpy as np
+import pytest
+import torch
+from conftest import golden, ROOT
+from omchat_amd import _lib, synth
+from omchat_amd.config import tiny, omchat13b
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "omchat_hip.h")).read()
+    declared = set(re.findall(r"\b(omchat_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"omchat_ctx", "omchat_config"}
+    l = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(l, n)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert b"gfx950" in _lib.lib().omchat_version()
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from omchat_amd.engine import Engine
+    with pytest.raises(_lib.OmchatError):
+        Engine(tiny())
+    c = _lib.OmchatConfig(); c.dtype = _lib.BF16; c.v_hidden = 256
+    h = C.c_void_p()
+    rc = _lib.lib().omchat_ctx_create(C.byref(c), 0, 1, None, C.byref(h))
+    assert rc != 0 and b"no HIP device" in _lib.lib().omchat_last_error()
+
+
+def _plan(ids, mask, ntok, ntiles, side, maxlen):
+    lib = _lib.lib()
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    b, T = ids.shape
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    S = C.c_int(0)
+    lens = np.zeros(b, np.int32)
+    pm = None if m is None else m.ctypes.data_as(C.c_void_p)
+    _lib.check(lib.omchat_splice_plan(ids.ctypes.data_as(C.c_void_p), pm, b, T, ntok, ntiles, side, maxlen, None, lens.ctypes.data_as(C.c_void_p), C.byref(S)))
+    idx = np.zeros((b, S.value), np.int32)
+    _lib.check(lib.omchat_splice_plan(ids.ctypes.data_as(C.c_void_p), pm, b, T, ntok, ntiles, side, maxlen, idx.ctypes.data_as(C.c_void_p),
+                                      lens.ctypes.data_as(C.c_void_p), C.byref(S)))
+    return idx, lens
+
+
+@pytest.mark.parametrize("name", ["1x3", "2_uneven_right", "2_uneven_left", "noimage_row", "truncate"])
+def test_splice_plan_reproduces_reference_embeds(name):
+    """the integer plan + a numpy gather must give the reference's inputs_embeds bit for bit (omchat_arch.py:103-209)"""
+    g = golden("splice_" + name)
+    cfg = tiny()
+    emb = synth.uniform("model.embed_tokens.weight", (cfg.text["vocab_size"], cfg.text["hidden_size"]), int(g["seed"]))
+    feats = g["feats"].reshape(-1, g["feats"].shape[-1])
+    mask = g["mask"] if bool(g["has_mask"]) else None
+    idx, lens = _plan(g["ids"], mask, g["feats"].shape[1], g["feats"].shape[0], 1 if str(g["side"]) == "left" else 0, int(g["maxlen"]))
+    out = np.zeros(idx.shape + (emb.shape[1],), np.float32)
+    for i in range(idx.shape[0]):
+        for s in range(idx.shape[1]):
+            k = int(idx[i, s])
+            if k == _lib.PAD_ROW:
+                continue
+            out[i, s] = emb[k] if k >= 0 else feats[-1 - k]
+    assert np.array_equal(out, g["embeds"])
+    if mask is not None:
+        assert np.array_equal((idx != _lib.PAD_ROW).astype(np.int64), g["mask_out"])
+    assert [int(x) for x in lens] == [int((idx[i] != _lib.PAD_ROW).sum()) for i in range(idx.shape[0])]
+
+
+def test_splice_plan_errors_and_edges():
+    with pytest.raises(ValueError):                         # more sentinels than tiles
+        _plan([[1, -200, -200]], None, 4, 1, 0, -1)
+    idx, lens = _plan([[7, 8, 9]], None, 4, 0, 0, -1)       # text only, zero tiles available
+    assert idx.tolist() == [[7, 8, 9]] and lens.tolist() == [3]
+    idx, lens = _plan([[1, -200, 2]], [[1, 1, 0]], 2, 1, 0, -1)   # padded token dropped before splicing (:115)
+    assert idx.tolist() == [[1, -1, -2]]
+    idx, lens = _plan([[-200]], None, 0, 1, 0, -1)          # zero-length features (ragged)
+    assert idx.shape == (1, 0) and lens.tolist() == [0]
+
+
+def test_decode_short_circuit_mask_matches_golden():
+    """omchat_arch.py:61-70 through the mirror class, with a stub engine (pure torch integer logic)"""
+    from omchat_amd.model.omchat_qwen2 import OmChatMetaForCausalLM
+    g = golden("splice_decode_shortcircuit")
+    m = OmChatMetaForCausalLM()
+    m.vision_tower = object()
+    probe = types.SimpleNamespace(shape=(2, 1, int(g["past_len"]), 4))
+    past = ((probe, probe),)
+    r = m.prepare_inputs_labels_for_multimodal(torch.zeros(2, 1, dtype=torch.long), None, torch.from_numpy(g["mask_in"]), past, None,
+                                               torch.zeros(1, 3, 56, 56))
+    assert r[4] is None and r[0] is not None
+    assert np.array_equal(r[2].numpy(), g["mask_out"]) and np.array_equal(r[1].numpy(), g["position_ids"])
+
+
+class _Tok:
+    bos_token_id = None
+    pad_token_id = 0
+    def __call__(self, s):
+        return types.SimpleNamespace(input_ids=[1000 + ord(ch) for ch in s])
+    def encode(self, s):
+        return [1000 + ord(ch) for ch in s]
+
+
+def test_make_context_layout():
+    """ChatML layout with hard-coded specials 151644/151645 (make_context.py:79-80) and one -200 per tile"""
+    from omchat_amd.make_context import make_context
+    raw, ids = make_context(_Tok(), "<image>\npatch:<image>\nhi", None, "sys")
+    e = _Tok().encode
+    expect = [151644] + e("system") + e("\n") + e("sys") + [151645] + e("\n") + [151644] + e("user") + e("\n") + \
+        [-200] + e("\npatch:") + [-200] + e("\nhi") + [151645] + e("\n") + [151644] + e("assistant") + e("\n")
+    assert ids == expect
+    assert raw == "<|im_start|>system\nsys<|im_end|>\n<|im_start|>user\n<image>\npatch:<image>\nhi<|im_end|>\n<|im_start|>assistant\n"
+    raw2, ids2 = make_context(_Tok(), "q2", [("q1", "a1")], "sys")
+    assert ids2[:len(e("system")) + 1] == [151644] + e("system") and ids2.count(151644) == 5
+    with pytest.raises(NotImplementedError):
+        make_context(_Tok(), "x", chat_format="bogus")
+
+
+def test_anyres_tile_counts():
+    from omchat_amd.mm_utils import anyres_tile_count
+    pin = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
+    assert [anyres_tile_count(s, pin) for s in [(448, 448), (570, 380), (1000, 667), (1344, 448)]] == [3, 3, 10, 4]
+
+
+def test_anyres_tiles_for_reference_sample_image():
+    """tile count/order/shape for a 570x380 picture (the size of the reference's images/extreme_ironing.jpg)"""
+    from PIL import Image
+    from omchat_amd.mm_utils import process_anyres_image
+    from omchat_amd.model.vision_tower import InternVITVisionTower
+    tw = InternVITVisionTower("internvit-6b-448px", types.SimpleNamespace(mm_vision_select_layer=-1))
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 255, (380, 570, 3), dtype=np.uint8))
+    pin = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
+    tiles, best = process_anyres_image(img, tw.image_processor, pin, True, return_best_res=True)
+    assert best == (896, 448) and len(tiles) == 3 and all(t.shape == (3, 448, 448) for t in tiles)
+
+
+def test_key_layout_roundtrip():
+    from omchat_amd.weights import to_hf_key, to_native_key, prepare_state_dict
+    cfg = tiny()
+    keys = [k for k, *_ in synth.tensor_specs(cfg)]
+    hf = [to_hf_key(k) for k in keys]
+    assert all(k.startswith(("vision_tower.", "multi_modal_projector.linear_", "language_model.")) for k in hf)
+    assert [to_native_key(k) for k in hf] == keys
+    sd = {to_hf_key(k): np.zeros(1) for k in keys}
+    sd["language_model.model.layers.0.self_attn.rotary_emb.inv_freq"] = np.zeros(1)
+    out = prepare_state_dict(sd, cfg)
+    assert sorted(out) == sorted(keys)
+    assert sorted(prepare_state_dict(sd, cfg, vision=False)) == sorted(k for k in keys if not k.startswith("model.vision_tower") and "mm_projector" not in k)
+
+
+def test_pos_embed_resize_matches_reference_golden():
+    """host-side pos-embed resize (folded constant, N9) == InternVisionEmbeddings._get_pos_embed via the golden embeddings"""
+    from omchat_amd.weights import resize_pos_embed
+    import oracle
+    from oracle.pipeline import _sub, TOWER_PFX
+    g = golden("vit_embed_resize")
+    cfg = tiny(image_size=112)
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict(cfg, int(g["seed"]), synth.TOWER).items()}
+    w = _sub(sd, TOWER_PFX)
+    pos = resize_pos_embed(w["embeddings.position_embedding"], 8, 4)
+    w2 = dict(w); w2["embeddings.position_embedding"] = pos
+    emb = oracle.vit_embeddings(torch.from_numpy(g["pixels"]), w2, 14, 56)       # grid already 4x4: identity resize inside
+    assert float((emb - torch.from_numpy(g["emb"])).abs().max()) < 1e-5
+
+
+def test_checkpoint_config_parsing(tmp_path):
+    from omchat_amd.model.builder import save_synthetic_checkpoint, config_from_json, iter_safetensors
+    cfg = tiny()
+    for layout in ("native", "hf"):
+        d = save_synthetic_checkpoint(str(tmp_path / layout), cfg, 0, layout, with_tokenizer=False)
+        c2 = config_from_json(d)
+        assert c2.text == cfg.text and c2.vision["hidden_size"] == 256 and c2.image_grid_pinpoints == cfg.image_grid_pinpoints
+        keys = [k for k, _ in iter_safetensors(d)]
+        assert len(keys) == len(synth.tensor_specs(cfg))
+        assert all(k.startswith(("vision_tower", "multi_modal", "language_model")) for k in keys) == (layout == "hf")
+
+
+def test_projector_and_tower_builders_raise_like_reference():
+    from omchat_amd.model import build_vision_projector, build_vision_tower
+    with pytest.raises(ValueError):
+        build_vision_projector(types.SimpleNamespace(mm_projector_type="nope"))
+    with pytest.raises(ValueError):
+        build_vision_tower(types.SimpleNamespace(mm_vision_tower="clip-vit", mm_vision_select_layer=-1))
+    tw = build_vision_tower(types.SimpleNamespace(mm_vision_tower="InternViT-6B-448px", mm_vision_select_layer=-2), delay_load=True)
+    assert tw.select_layer == -2 and tw.select_feature == "patch" and not tw.is_loaded
+    with pytest.raises(RuntimeError):
+        tw.forward(torch.zeros(1, 3, 448, 448))           # no engine attached -> loud failure, never a CPU fallback
+    assert build_vision_projector(types.SimpleNamespace(mm_projector_type="identity")).forward(3) == 3
+
+
+def test_local_dims_for_omchat13b():
+    from omchat_amd import tp
+    c = omchat13b()
+    assert tp.local_dims(c, 0, 8) == dict(v_heads=4, v_mlp=1600, t_heads=4, t_kv_heads=1, t_mlp=2368, t_vocab=19008)
+    heads = sorted(h for r in range(8) for h in tp.vit_head_map(c, r, 8) if h >= 0)
+    assert heads == list(range(25))
+    qs = sorted(q for r in range(8) for q in tp.decoder_head_map(c, r, 8)[0] if q >= 0)
+    assert qs == list(range(28))
+    for r in range(8):
+        q, kv = tp.decoder_head_map(c, r, 8)
+        assert all(x < 0 or x // 7 == kv[0] for x in q)          # a rank's q heads all belong to its kv head
+    with pytest.raises(ValueError):
+        tp.local_dims(c, 0, 3)

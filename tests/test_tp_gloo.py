@@ -1,0 +1,121 @@
+"""CPU, world_size 2 over gloo: the tensor-parallel sharding plan (omchat_amd/tp.py) executed with the same dataflow as
+the C++ loops (model.hip: rank 0 carries bias + residual, one all-reduce per sub-block, joint q/k-norm sum of squares
+all-reduced with the divisor kept at the full channel count) must reproduce the unsharded oracle."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from omchat_amd import synth, tp
+from omchat_amd.config import tiny
+import oracle
+from oracle.pipeline import _sub, TOWER_PFX
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _vit_layer_tp(x, sd_full, cfg, rank, size):
+    P = synth.TOWER + "encoder.layers.0."
+    w = {k[len(P):]: T(tp.shard_tensor(k, v, cfg, rank, size)) for k, v in sd_full.items() if k.startswith(P)}
+    C = cfg.vision["hidden_size"]
+    hl = tp.local_dims(cfg, rank, size)["v_heads"]
+    B, N, _ = x.shape
+    xn = oracle.rms_norm(x, w["norm1.weight"])
+    qkv = F.linear(xn, w["attn.qkv.weight"]).reshape(B, N, 3, hl * 128)
+    q, k, v = qkv.unbind(2)
+    ss = torch.stack([q.pow(2).sum(-1), k.pow(2).sum(-1)], -1)
+    dist.all_reduce(ss)                                              # launch_vit_qk_sumsq + allreduce_f32
+    q = w["attn.q_norm.weight"] * (q * torch.rsqrt(ss[..., 0:1] / C + 1e-6))
+    k = w["attn.k_norm.weight"] * (k * torch.rsqrt(ss[..., 1:2] / C + 1e-6))
+    q = q.view(B, N, hl, 128).transpose(1, 2); k = k.view(B, N, hl, 128).transpose(1, 2); v = v.reshape(B, N, hl, 128).transpose(1, 2)
+    a = ((q * 128 ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+    a = a.transpose(1, 2).reshape(B, N, hl * 128)
+    y = F.linear(a, w["attn.proj.weight"], w["attn.proj.bias"] if rank == 0 else None) * w["ls1"]
+    if rank == 0:
+        y = y + x
+    dist.all_reduce(y)
+    x = y
+    xn = oracle.rms_norm(x, w["norm2.weight"])
+    h = F.gelu(F.linear(xn, w["mlp.fc1.weight"], w["mlp.fc1.bias"]))
+    y = F.linear(h, w["mlp.fc2.weight"], w["mlp.fc2.bias"] if rank == 0 else None) * w["ls2"]
+    if rank == 0:
+        y = y + x
+    dist.all_reduce(y)
+    return y
+
+
+def _dec_layer_tp(x, sd_full, cfg, rank, size):
+    P = "model.layers.0."
+    w = {k: T(tp.shard_tensor(k, v, cfg, rank, size)) for k, v in sd_full.items() if k.startswith(P)}
+    d = tp.local_dims(cfg, rank, size)
+    local = dict(cfg.text); local["num_attention_heads"] = d["t_heads"]; local["num_key_value_heads"] = d["t_kv_heads"]
+    b, S, _ = x.shape
+    cos, sin = oracle.rope_cos_sin(torch.arange(S)[None], 128, cfg.text["rope_theta"], torch.float32)
+    xn = oracle.rms_norm(x, w[P + "input_layernorm.weight"])
+    y = oracle.qwen2_attention(xn, w, P, local, cos, sin, None, 0)   # o_proj has no bias: partial sums
+    if rank == 0:
+        y = y + x
+    dist.all_reduce(y)
+    x = y
+    xn = oracle.rms_norm(x, w[P + "post_attention_layernorm.weight"])
+    y = oracle.qwen2_mlp(xn, w, P)
+    if rank == 0:
+        y = y + x
+    dist.all_reduce(y)
+    # vocab-parallel lm_head: all-gather of the local logit slices
+    lm = T(tp.shard_tensor("lm_head.weight", sd_full["lm_head.weight"], cfg, rank, size))
+    part = F.linear(y, lm)
+    parts = [torch.empty_like(part) for _ in range(size)]
+    dist.all_gather(parts, part)
+    return y, torch.cat(parts, -1)
+
+
+def _worker(rank, size, port, case, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    torch.manual_seed(0)
+    try:
+        if case == "vit":
+            cfg = tiny(heads_v=3, layers_v=1)                       # 3 heads over 2 ranks: [0,1] and [2,pad]
+            sd = synth.state_dict(cfg, 3, synth.TOWER)
+            x = torch.randn(2, 17, 384)
+            out = _vit_layer_tp(x, sd, cfg, rank, size)
+            ref = oracle.vit_layer(x, _sub({k: T(v) for k, v in sd.items()}, TOWER_PFX), 0, 3)
+            err = float((out - ref).norm() / ref.norm())
+        else:
+            qh, kvh = (4, 2) if case == "dec_split" else (7, 1)     # kv heads split / kv head replicated with 4+3(+pad) q heads
+            cfg = tiny(q_heads=qh, kv_heads=kvh, layers_t=1)
+            sd = {k: v for k, v in synth.state_dict(cfg, 4).items() if k.startswith(("model.layers.0.", "lm_head"))}
+            x = torch.randn(1, 9, 256)
+            out, logits = _dec_layer_tp(x, sd, cfg, rank, size)
+            sdt = {k: T(v) for k, v in sd.items()}
+            cos, sin = oracle.rope_cos_sin(torch.arange(9)[None], 128, 1e6, torch.float32)
+            ref = oracle.qwen2_layer(x, sdt, 0, cfg.text, cos, sin, None)
+            err = max(float((out - ref).norm() / ref.norm()), float((logits - F.linear(ref, sdt["lm_head.weight"])).norm() / logits.norm()))
+        q.put((rank, err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["vit", "dec_split", "dec_replicated_kv"])
+def test_tp2_equals_unsharded(case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err < 1e-5, (case, rank, err)
