@@ -75,7 +75,12 @@ extern "C" int omchat_op_rope_kv(int dtype, void* qkv, int b, int Sq, int Hq, in
 }
 
 extern "C" int omchat_op_argmax(const float* logits, int b, int V, int32_t* out, void* stream) {
-  return launch_argmax(logits, V, b, V, out, S(stream));
+  void* scratch = nullptr;
+  OM_HIP(hipMalloc(&scratch, argmax_scratch_bytes(b)));
+  int rc = launch_argmax(logits, V, b, V, out, scratch, S(stream));
+  hipStreamSynchronize(S(stream));
+  hipFree(scratch);
+  return rc;
 }
 
 extern "C" int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, void* stream) {

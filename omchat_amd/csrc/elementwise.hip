@@ -438,17 +438,13 @@ int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int6
   return 0;
 }
 
-int launch_argmax(const float* logits, int ld, int b, int V, int* out, hipStream_t s) {
+size_t argmax_scratch_bytes(int b) { return (size_t)b * ARG_CHUNKS * 8; }
+
+int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scratch, hipStream_t s) {
   if (b == 0) return 0;
-  static float* pv = nullptr;
-  static int* pi = nullptr;
-  static int cap = 0;
-  if (b > cap) {            // tiny scratch for the slice winners, grown on demand outside any capture
-    if (pv) { hipFree(pv); hipFree(pi); }
-    cap = b > 64 ? b : 64;
-    OM_HIP(hipMalloc(&pv, (size_t)cap * ARG_CHUNKS * 4));
-    OM_HIP(hipMalloc(&pi, (size_t)cap * ARG_CHUNKS * 4));
-  }
+  OM_CHECK(scratch, "argmax scratch missing");
+  float* pv = (float*)scratch;
+  int* pi = (int*)((char*)scratch + (size_t)b * ARG_CHUNKS * 4);
   hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARG_CHUNKS, b), dim3(256), 0, s, logits, ld, V, pv, pi);
   hipLaunchKernelGGL(argmax_stage2_kernel, dim3(b), dim3(64), 0, s, pv, pi, out);
   OM_LAUNCH_CHECK();

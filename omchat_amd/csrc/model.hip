@@ -99,6 +99,7 @@ struct omchat_ctx {
   void *tw_x = nullptr, *tw_x2 = nullptr, *tw_xn = nullptr, *tw_qkv = nullptr, *tw_ao = nullptr, *tw_act = nullptr, *tw_last = nullptr;
   float* tw_logits = nullptr;
   float* tp_table = nullptr;
+  void* arg_scratch = nullptr;
   float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
   float* tw_attn_ws = nullptr;
   size_t tw_attn_ws_bytes = 0;
@@ -282,6 +283,7 @@ int build(omchat_ctx* ctx) {
     ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
     TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
     TRY(ctx->alloc((void**)&ctx->tw_part, (size_t)DEC_KS_MAX * c.max_batch * H * 4));
+    TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
     TRY(ctx->alloc((void**)&ctx->d_pos, (size_t)c.max_batch * 4));
     TRY(ctx->alloc((void**)&ctx->d_len, (size_t)c.max_batch * 4));
@@ -613,7 +615,7 @@ static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logit
 // greedy argmax over (rank-local) logits; under tensor parallelism the (max, index) pairs are exchanged
 static int greedy_pick(omchat_ctx* ctx, const float* lg, int b, int32_t* next_tokens, hipStream_t s) {
   const omchat_config& c = ctx->c;
-  TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, s));
+  TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, ctx->arg_scratch, s));
   if (ctx->tp_size > 1) {
     const size_t n = (size_t)ctx->tp_size * b * 2;
     OM_HIP(hipMemsetAsync(ctx->tp_table, 0, n * 4, s));
@@ -732,7 +734,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   // split-K over workgroups: fp32 slices [ks][b][H], summed by the fused residual + RMSNorm kernel
   auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks) -> int {
     OM_CHECK(b <= 16, "split-K decode path handles b <= 16");
-    GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 1, ks};
+    GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
     return launch_gemv(ctx->dt, g, s);
   };
   const bool fused = ctx->tp_size == 1 && b <= 16;
