@@ -739,7 +739,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   };
   const bool fused = ctx->tp_size == 1 && b <= 16;
   const int ks_o = std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));      // ~2 workgroups per CU
-  const int ks_d = std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 2 * cdiv(512, cdiv(H, 16)))));
+  const int ks_d = std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
   if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];

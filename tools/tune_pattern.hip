@@ -1,0 +1,84 @@
+// Access-pattern microbench (not product): does the MFMA-fragment-shaped weight read (16 rows x 64 B per wave
+// instruction) cost bandwidth against whole-row 1-KiB reads?  Same work split as the decode GEMV.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (a) fragment-shaped: block = 8 waves x 32 rows (2 tiles), wave w takes 64-wide K chunks w, w+8, ...
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(512) void frag_kernel(const unsigned short* W, int N, int K, unsigned* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * 32;
+  const unsigned short* r0 = W + (size_t)(n0 + fr) * K + fg * 8;
+  const unsigned short* r1 = W + (size_t)(n0 + 16 + fr) * K + fg * 8;
+  u32x4 acc = {0, 0, 0, 0};
+  const int nchunk = K / 64;
+  for (int c0 = wave; c0 + (UNROLL - 1) * 8 < nchunk; c0 += 8 * UNROLL) {
+    u32x4 v[UNROLL][4];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int k = (c0 + u * 8) * 64;
+      if (NT) {
+        v[u][0] = __builtin_nontemporal_load((const u32x4*)(r0 + k)); v[u][1] = __builtin_nontemporal_load((const u32x4*)(r0 + k + 32));
+        v[u][2] = __builtin_nontemporal_load((const u32x4*)(r1 + k)); v[u][3] = __builtin_nontemporal_load((const u32x4*)(r1 + k + 32));
+      } else {
+        v[u][0] = *(const u32x4*)(r0 + k); v[u][1] = *(const u32x4*)(r0 + k + 32);
+        v[u][2] = *(const u32x4*)(r1 + k); v[u][3] = *(const u32x4*)(r1 + k + 32);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = 1;
+}
+
+// (b) whole rows: wave = R rows at a time, lanes read consecutive 16-B chunks (1 KiB per instruction), full K per wave
+template <int R, int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void rows_kernel(const unsigned short* W, int N, int K, unsigned* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * WAVES + wave) * R;
+  if (row0 >= N) return;
+  u32x4 acc = {0, 0, 0, 0};
+  const int nchunk = K / 512;      // full 1-KiB pieces; tail ignored (K = 3584 = 7 * 512)
+  for (int c = 0; c < nchunk; ++c) {
+    u32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned short* p = W + (size_t)(row0 + r) * K + c * 512 + lane * 8;
+      v[r] = NT ? __builtin_nontemporal_load((const u32x4*)p) : *(const u32x4*)p;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc ^= v[r];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = 1;
+}
+
+int main() {
+  const int N = 37888, K = 3584, iters = 40;
+  const double bytes = (double)N * K * 2;
+  std::vector<void*> W(6);
+  for (auto& w : W) { hipMalloc(&w, (size_t)bytes); hipMemset(w, 0x3c, (size_t)bytes); }
+  unsigned* out; hipMalloc(&out, 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto time = [&](const char* name, auto launch) {
+    for (int i = 0; i < 3; ++i) launch(W[i % W.size()]);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch(W[i % W.size()]);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %7.1f us  %5.2f TB/s\n", name, ms * 1e3 / iters, bytes / (ms * 1e3 / iters) / 1e6);
+  };
+#define L(KERN, GRID, BLK) [&](void* w) { hipLaunchKernelGGL(KERN, dim3(GRID), dim3(BLK), 0, 0, (const unsigned short*)w, N, K, out); }
+  time("frag 16x64B unroll4 nt", L((frag_kernel<4, true>), N / 32, 512));
+  time("frag 16x64B unroll4 plain", L((frag_kernel<4, false>), N / 32, 512));
+  time("frag 16x64B unroll2 plain", L((frag_kernel<2, false>), N / 32, 512));
+  time("rows R=4 waves=4 plain", L((rows_kernel<4, 4, false>), N / 16, 256));
+  time("rows R=4 waves=4 nt", L((rows_kernel<4, 4, true>), N / 16, 256));
+  time("rows R=8 waves=4 plain", L((rows_kernel<8, 4, false>), N / 32, 256));
+  time("rows R=8 waves=8 plain", L((rows_kernel<8, 8, false>), N / 64, 512));
+  time("rows R=2 waves=8 plain", L((rows_kernel<2, 8, false>), N / 16, 512));
+  time("rows R=4 waves=8 plain", L((rows_kernel<4, 8, false>), N / 32, 512));
+  time("rows R=16 waves=4 plain", L((rows_kernel<16, 4, false>), N / 64, 256));
+  return 0;
+}
