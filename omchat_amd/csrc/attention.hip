@@ -164,43 +164,52 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
         for (int qt = 0; qt < NQ; ++qt) s[qt][kt] = mfma16(kf, qf[qt][ds], s[qt][kt]);
       }
 
-    // ---- mask + online softmax (per lane = per query column)
+    // ---- mask + online softmax (per lane = per query column).  exp2((s - m) * c) = exp2(s * c - m * c).
     const int key0 = t * KV_TILE + 4 * fg;
+    // masking is needed only on the last kv tile (ragged tail) and on tiles that reach the causal diagonal of this block
+    bool need_mask = (t + 1) * KV_TILE > kv_len;
+    if constexpr (!DECODE) need_mask = need_mask || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1);
     frag_t pf[NQ][2];
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) {
-      int lim = kv_len;                                   // keys < lim are visible
-      if constexpr (!DECODE) {
-        if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
-      }
-      float mx = NEG_BIG;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kj = key0 + kt * 16 + r;
-          float v = s[qt][kt][r];
-          v = kj < lim ? v : NEG_BIG;
-          s[qt][kt][r] = v;
-          mx = fmaxf(mx, v);
+      if (need_mask) {
+        int lim = kv_len;                                   // keys < lim are visible
+        if constexpr (!DECODE) {
+          if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
         }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qt][kt][r] = key0 + kt * 16 + r < lim ? s[qt][kt][r] : NEG_BIG;
+      }
+      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
+#pragma unroll
+      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[qt][kt][0], s[qt][kt][1]), fmaxf(s[qt][kt][2], s[qt][kt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f((m_run[qt] - m_new) * p.c);
-      m_run[qt] = m_new;
+      // rescale only when some query of the wave really raised its max (exact: alpha == 1 otherwise)
+      if (__any(mx > m_run[qt])) {
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.c);
+        m_run[qt] = m_new;
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int dn = 0; dn < 8; ++dn) o[qt][dn] *= alpha;
+      }
+      const float mc = m_run[qt] * p.c;
       float psum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int ks = 0; ks < 2; ++ks) {
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        f32x8 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = rnd<T>(exp2f((s[qt][kt][r] - m_new) * p.c));
-          psum += pv;
-          pf[qt][kt >> 1][(kt & 1) * 4 + r] = (T)pv;
+        for (int j = 0; j < 8; ++j) {
+          e[j] = __builtin_amdgcn_exp2f(fmaf(s[qt][2 * ks + (j >> 2)][j & 3], p.c, -mc));
+          psum += e[j];
         }
-      l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-      for (int dn = 0; dn < 8; ++dn) o[qt][dn] *= alpha;
+        pf[qt][ks] = __builtin_convertvector(e, frag_t);     // packed f32 -> 16-bit converts
+      }
+      l_run[qt] += psum;
     }
 
     // ---- O^T += V^T P^T

@@ -20,6 +20,24 @@ struct GemmP {
   int lda, ldw, ldc, ldr, M, N, K;
 };
 
+// Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
+// ids b and b+8 share an L2; give each XCD a contiguous range of logical ids.  (2) inside that range walk the tile grid in
+// groups of GROUP_M row tiles x all column tiles, row fastest: the 32 workgroups an XCD runs at once then form a 4 x 8
+// block that shares 4 A row-panels and 8 W column-panels per K-step (12 panel slices instead of up to 33).
+constexpr int GROUP_M = 4;
+__device__ __forceinline__ void tile_coords(int M, int N, int BM, int BN, int& m0, int& n0) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int per_group = GROUP_M * tiles_n;
+  const int g = wgid / per_group, in_g = wgid % per_group;
+  const int rows_here = tiles_m - g * GROUP_M < GROUP_M ? tiles_m - g * GROUP_M : GROUP_M;
+  m0 = (g * GROUP_M + in_g % rows_here) * BM;
+  n0 = (in_g / rows_here) * BN;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -29,8 +47,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MR = WTM / 16, NR = WTN / 16;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_ROUNDS = BM * 8 / NT, B_ROUNDS = BN * 8 / NT;
-  static_assert(A_ROUNDS * NT == BM * 8 && B_ROUNDS * NT == BN * 8, "tile/threads mismatch");
+  constexpr int A_ROUNDS = (BM * 8 + NT - 1) / NT, B_ROUNDS = (BN * 8 + NT - 1) / NT;
+  // a last partial round is taken by whole waves only (wave-uniform predicate: BM*8 and BN*8 are multiples of 64)
+  static_assert((BM * 8) % 64 == 0 && (BN * 8) % 64 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile geometry");
   typedef typename V8<T>::type frag_t;
   extern __shared__ __attribute__((aligned(256))) char smem[];
 
@@ -39,13 +58,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- tile id: bijective XCD remap (blocks b and b+8 share an XCD), M fastest inside an XCD's chunk
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = (wgid % tiles_m) * BM, n0 = (wgid / tiles_m) * BN;
+  int m0, n0;
+  tile_coords(p.M, p.N, BM, BN, m0, n0);
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
@@ -72,10 +86,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * 64), (lptr_t)(base + (i * NT + wave * 64) * 16), 16, 0, 0);
+      if ((i + 1) * NT <= BM * 8 || i * NT + wave * 64 < BM * 8)
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + kt * 64), (lptr_t)(base + (i * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * 64), (lptr_t)(base + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
+      if ((i + 1) * NT <= BN * 8 || i * NT + wave * 64 < BN * 8)
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + kt * 64), (lptr_t)(base + A_BYTES + (i * NT + wave * 64) * 16), 16, 0, 0);
   };
 
   // ---- fragment read offsets (bytes inside a stage)
@@ -167,6 +183,221 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Shared epilogue: acc[i][j][r] = C[row0 + i*16 + r][col0 + j*16] for the lane (row0/col0 include the lane offsets)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int MR, int NR, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int row0, int col0, int ncol_base, int fr) {
+  const T* __restrict__ bias = (const T*)p.bias;
+  T* C = (T*)p.C;
+  if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+    for (int j = 0; j < NR; j += 2) {
+      const int colg = col0 + j * 16;
+      if (colg + 16 < p.N) {
+        const int oc = ((ncol_base + j * 16) >> 1) + fr;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + i * 16 + r;
+            if (row < p.M) {
+              const float g = rnd<T>(acc[i][j][r]), u = rnd<T>(acc[i][j + 1][r]);
+              C[(size_t)row * p.ldc + oc] = fromf<T>(rnd<T>(silu(g)) * u);
+            }
+          }
+      }
+    }
+  } else {
+    const T* __restrict__ ls = (const T*)p.ls;
+    const T* R = (const T*)p.resid;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int col = col0 + j * 16;
+      if (col < p.N) {
+        const float bv = bias ? tof(bias[col]) : 0.f;
+        float lsv = 1.f;
+        if constexpr (EPI == EPI_LS_RESID) lsv = tof(ls[col]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + i * 16 + r;
+            if (row < p.M) {
+              float v = rnd<T>(acc[i][j][r] + bv);
+              if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
+              if constexpr (EPI == EPI_LS_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + rnd<T>(v * lsv);
+              if constexpr (EPI == EPI_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + v;
+              C[(size_t)row * p.ldc + col] = fromf<T>(v);
+            }
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2 M x 4 N), 4 phases per K-tile, the two wave groups (wm = 0 / 1) staggered by one
+// barrier so that on every SIMD one wave is in its MFMA segment while its partner reads LDS / issues LDS-DMA
+// (cdna_hip_programming.md §5 "The 256^2 8-phase template", T3/T4/T5; MI355X_MICROARCH "Two waves per SIMD").
+//
+// LDS = 2 stage buffers x 4 slots x 16 KiB.  A slot is what ONE phase consumes across all waves:
+//   A_mh: tile rows wm*128 + mh*64 + [0,64) for wm = 0,1   (slot row = wm*64 + r)
+//   B_nh: tile cols wn*64 + nh*32 + [0,32) for wn = 0..3    (slot row = wn*32 + c)
+// Phase p of K-tile t (buffer t&1) computes accumulator quadrant (mh, nh) x K = 64 (16 MFMA):
+//   p1 (0,0) reads A_0 + B_0     p2 (0,1) reads B_1     p3 (1,1) reads A_1     p4 (1,0) re-uses the B_0 registers
+// so slots die early (A_0, B_0 after p1, B_1 after p2, A_1 after p3) and are refilled in place with the data of one or
+// two K-tiles ahead while the rest of the buffer is still being consumed: every slot is issued >= 5 phases before its
+// first read (4 half-tiles = 8 LDS-DMA per wave in flight).
+// Per phase and wave:  LOAD: ds_reads, 2 x global_load_lds, s_waitcnt vmcnt(8), s_waitcnt lgkmcnt(0) (reads retired
+// BEFORE the barrier: WAR safety for the staggered partner)  ->  s_barrier  ->  COMPUTE: 16 MFMA  ->  s_barrier.
+// Group 1 runs one barrier behind group 0.  Hazard bookkeeping (phase numbers global, P = 4t + p; group 0 executes
+// LOAD(P) before barrier 2P-1, group 1 before barrier 2P): a slot last read in LOAD(X) is retired for both groups at
+// barrier 2X; a refill issued in LOAD(Y) starts after barrier 2Y-2, so Y >= X+1 is safe (the schedule keeps Y >= X+2);
+// data issued in LOAD(Y) by every wave has landed for everyone after barrier 2(Y+4) (vmcnt(8) at the end of LOAD(Y+4)),
+// so it may be read from LOAD(Y+5) on.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
+  constexpr int SLOT = 128 * 128;                 // 128 rows x 128 B
+  constexpr int STAGE = 4 * SLOT;                 // A_0, A_1, B_0, B_1
+  typedef typename V8<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int m0, n0;
+  tile_coords(p.M, p.N, 256, 256, m0, n0);
+
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+
+  // staging sources: slot piece lin = i*512 + tid -> slot row rho = lin >> 3, physical chunk pc = lin & 7
+  const T* a_src[2][2];     // [mh][round]
+  const T* b_src[2][2];     // [nh][round]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lin = i * 512 + tid, rho = lin >> 3, pc = lin & 7;
+    const int c = pc ^ ((rho >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int gr = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63); gr = gr < p.M ? gr : p.M - 1;
+      a_src[h][i] = A + (size_t)gr * p.lda + c * 8;
+      int gc = n0 + (rho >> 5) * 64 + h * 32 + (rho & 31); gc = gc < p.N ? gc : p.N - 1;
+      b_src[h][i] = W + (size_t)gc * p.ldw + c * 8;
+    }
+  }
+  // slot order inside a stage: 0 = A_0, 1 = A_1, 2 = B_0, 3 = B_1
+  auto issue = [&](int buf, int slot, const T* const (&src)[2], int kt) {
+    char* base = smem + buf * STAGE + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * 64), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  int a_off[2], b_off[2];            // per k-step, inside a slot
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int pc = ((s * 4 + fg) ^ swz) * 16;
+    a_off[s] = (wm * 64 + fr) * 128 + pc;
+    b_off[s] = (wn * 32 + fr) * 128 + pc;
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / 64;
+  // prologue: K-tile 0 completely, plus A_0 / B_0 of K-tile 1 (steady state issues them in p3 / p4 of tile t-1)
+  issue(0, 0, a_src[0], 0); issue(0, 2, b_src[0], 0); issue(0, 3, b_src[1], 0); issue(0, 1, a_src[1], 0);
+  if (nk > 1) {
+    issue(1, 0, a_src[0], 1); issue(1, 2, b_src[0], 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();      // stagger: group 1 runs one barrier behind
+
+  // Issue schedule (slot X of tile u goes to buffer u&1; its previous content died >= 2 phases earlier because the
+  // B_0 fragments are kept in registers from p1 to p4):
+  //   p1(t): B_1(t+1)   p2(t): A_1(t+1)   p3(t): A_0(t+2)   p4(t): B_0(t+2)
+  // First reads: p1 A_0,B_0   p2 B_1   p3 A_1   -> every slot is issued >= 5 phases before its first read, and
+  // s_waitcnt vmcnt(8) at the end of a LOAD segment (4 half-tiles may stay in flight) retires what the NEXT phase reads.
+  frag_t af[4][2], bf0[2][2], bf1[2][2];
+  for (int t = 0; t < nk; ++t) {
+    const char* st = smem + (t & 1) * STAGE;
+    const int nb = (t + 1) & 1;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+
+#define OM_LOAD_A(MH)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s)                      \
+      af[i][s] = *reinterpret_cast<const frag_t*>(st + (MH) * SLOT + a_off[s] + i * 16 * 128);
+#define OM_LOAD_B(BF, NH)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)                      \
+      BF[j][s] = *reinterpret_cast<const frag_t*>(st + (2 + (NH)) * SLOT + b_off[s] + j * 16 * 128);
+#define OM_SYNC_COMPUTE(MH, NH, BF)                                                                                \
+  if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  __builtin_amdgcn_s_barrier();                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  __builtin_amdgcn_s_setprio(1);                                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+          acc[(MH) * 4 + i][(NH) * 2 + j] = mfma16(af[i][s], BF[j][s], acc[(MH) * 4 + i][(NH) * 2 + j]);           \
+  __builtin_amdgcn_s_setprio(0);                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  __builtin_amdgcn_s_barrier();                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+
+    // phase 1: quadrant (0,0)
+    OM_LOAD_B(bf0, 0) OM_LOAD_A(0)
+    if (more1) issue(nb, 3, b_src[1], t + 1);
+    OM_SYNC_COMPUTE(0, 0, bf0)
+    // phase 2: quadrant (0,1)
+    OM_LOAD_B(bf1, 1)
+    if (more1) issue(nb, 1, a_src[1], t + 1);
+    OM_SYNC_COMPUTE(0, 1, bf1)
+    // phase 3: quadrant (1,1)
+    OM_LOAD_A(1)
+    if (more2) issue(t & 1, 0, a_src[0], t + 2);
+    OM_SYNC_COMPUTE(1, 1, bf1)
+    // phase 4: quadrant (1,0), B_0 fragments still in registers
+    if (more2) issue(t & 1, 2, b_src[0], t + 2);
+    OM_SYNC_COMPUTE(1, 0, bf0)
+#undef OM_LOAD_A
+#undef OM_LOAD_B
+#undef OM_SYNC_COMPUTE
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 matches group 1's extra barrier
+
+  gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128 + fg * 4, n0 + wn * 64 + fr, n0 + wn * 64, fr);
+}
+
+template <typename T, int EPI>
+int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
+  constexpr int LDS = 2 * 4 * 128 * 128;
+  auto kern = gemm8_kernel<T, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K};
+  const int grid = cdiv(a.M, 256) * cdiv(a.N, 256);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -183,15 +414,40 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   return 0;
 }
 
+// Tile menu.  256 CUs take one 8-wave workgroup each (two for the 128^2 tile), so the cost of a launch is
+// rounds(tiles / slots) x per-tile time; the shape that fills the last round best wins (M = 3075 x N = 3200 is
+// 169 tiles of 256^2 = 66 % of one round, but 221 tiles of 256x192 = 86 %).  `eff` = measured MFMA efficiency of the
+// shape relative to 256^2 (smaller tiles re-read more LDS per MFMA).
+struct TileCfg { int id, bm, bn, slots; float eff; };
+// Measured (r01): 224/192-row tiles lose (power-limited chip: idle CUs give their budget to the busy ones), so the
+// automatic menu is 256^2, 256x192 (N = 3200 shapes: -13 % time) and 128^2 for tiny problems.
+static const TileCfg kTiles[] = {{2, 256, 256, 256, 1.00f}, {3, 256, 192, 256, 0.90f}, {1, 128, 128, 512, 0.60f}};
+
+static int pick_tile(int M, int N, int epi) {
+  if ((long)cdiv(M, 256) * cdiv(N, 256) >= 3 * 256) return 2;     // many rounds: the tail round is amortised
+  int best = 2;
+  float best_cost = 1e30f;
+  for (const TileCfg& t : kTiles) {
+    if (epi == EPI_SWIGLU && (t.bn / 4) % 32 != 0) continue;      // gate|up pairs must not straddle a wave's columns
+    const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
+    const long rounds = (tiles + t.slots - 1) / t.slots;
+    const float cost = (float)rounds * (float)(t.bm * t.bn) / t.eff * (t.slots == 512 ? 2.0f : 1.0f) + 0.02f * 65536.f * (float)rounds;
+    if (cost < best_cost) { best_cost = cost; best = t.id; }
+  }
+  return best;
+}
+
 template <typename T, int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-  int tile = a.force_tile;
-  if (tile == 0) {
-    const long big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-    tile = (big >= 128) ? 2 : 1;      // measured (r01): the 256^2 kernel at half-filled CUs still beats the 128^2 one
+  const int tile = a.force_tile ? a.force_tile : pick_tile(a.M, a.N, EPI);
+  switch (tile) {
+    case 1: return launch_cfg<T, 128, 128, 2, 2, EPI>(a, stream);
+    case 3: return launch_cfg<T, 256, 192, 2, 4, EPI>(a, stream);
+    case 4: return launch_cfg<T, 224, 256, 2, 4, EPI>(a, stream);
+    case 5: return launch_cfg<T, 192, 256, 2, 4, EPI>(a, stream);
+    case 6: return launch_cfg<T, 256, 256, 2, 4, EPI>(a, stream);     // one-barrier-per-K-step structure (kept for A/B)
+    default: return launch_cfg8<T, EPI>(a, stream);
   }
-  if (tile == 2) return launch_cfg<T, 256, 256, 2, 4, EPI>(a, stream);
-  return launch_cfg<T, 128, 128, 2, 2, EPI>(a, stream);
 }
 
 template <typename T>

@@ -23,7 +23,7 @@ struct GemmArgs {
   const void* resid;  // [M, ldr] (EPI_LS_RESID / EPI_RESID); may alias C
   int ldr;
   int epi;
-  int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256
+  int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256, 3 = 256x192, 4 = 224x256, 5 = 192x256
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 

@@ -46,13 +46,13 @@ def _gemm_ref(A, W, bias, ls, resid, epi, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(300, 224, 128), (1025, 416, 320), (64, 3200, 640), (515, 512, 1024)])
 def test_gemm_epilogues(gpu_lib, dt, tile, M, N, K):
     A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2, 0.05), dt)
     bias = rnd(randn((N,), 3, 0.1), dt); ls = rnd(randn((N,), 4, 0.1) + 0.1, dt); resid = rnd(randn((M, N), 5), dt)
     for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_LS_RESID, _lib.EPI_RESID, _lib.EPI_SWIGLU):
-        if epi == _lib.EPI_SWIGLU and N % 32:
+        if epi == _lib.EPI_SWIGLU and (N % 32 or tile == 3):
             continue
         No = N // 2 if epi == _lib.EPI_SWIGLU else N
         use_bias = epi != _lib.EPI_SWIGLU and epi != _lib.EPI_RESID
@@ -64,6 +64,31 @@ def test_gemm_epilogues(gpu_lib, dt, tile, M, N, K):
         ref = _gemm_ref(A, W, bias if use_bias else None, ls, resid, epi, dt)
         assert torch.isfinite(out.float()).all(), (epi, "non-finite / unwritten outputs")
         assert rel(out, ref) < TOL[dt], (epi, tile, rel(out, ref))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(3584, 1024, 3584), (3075, 768, 12800), (512, 512, 64), (700, 900, 128)])
+def test_gemm_staggered_kernel_race_screen(gpu_lib, dt, M, N, K):
+    """the 4-phase staggered 256^2 kernel: production-size K loops, repeated launches must be bit-identical and correct"""
+    A = rnd(randn((M, K), 11, 0.5), dt); W = rnd(randn((N, K), 12, 0.05), dt)
+    dA, dW = dev(A, dt), dev(W, dt)
+    ref = A @ W.t()
+    outs = []
+    for it in range(4):
+        out = torch.full((M, N), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), N, M, N, K, None, None, None, 0, _lib.EPI_NONE, 2, None))
+        sync()
+        outs.append(out)
+    assert rel(outs[0], ref) < TOL[dt], rel(outs[0], ref)
+    # element-wise: no wrong tile may hide inside a small Frobenius error
+    err = (outs[0].float().cpu() - ref).abs()
+    assert float(err.max()) < (0.25 if dt == "bf16" else 0.05) * float(ref.abs().max())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    old = torch.empty_like(outs[0])
+    _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(old), N, M, N, K, None, None, None, 0, _lib.EPI_NONE, 6, None))
+    sync()
+    assert torch.equal(old, outs[0])          # same fp32 accumulation order per element as the one-barrier kernel
 
 
 @pytest.mark.parametrize("dt", DTS)
