@@ -109,3 +109,15 @@ def test_tp2_on_one_gpu_equals_tp1(gpu_lib, dt, q, kv, hv):
     assert res[0][3] == int(torch.argmax(full_step))
     for e in engines:
         e.close()
+
+
+def test_rccl_bootstrap_single_rank(gpu_lib):
+    """omchat_comm_unique_id / omchat_comm_init / omchat_comm_destroy through the ctypes binding (world of 1: the multi-GPU
+    RCCL data path itself is exercised by `bench.py --gpus N` under torchrun)"""
+    buf = C.create_string_buffer(128)
+    _lib.check(gpu_lib.omchat_comm_unique_id(buf))
+    assert any(b != 0 for b in buf.raw)
+    comm = C.c_void_p()
+    _lib.check(gpu_lib.omchat_comm_init(bytes(buf.raw), 0, 1, C.byref(comm)))
+    assert comm.value
+    gpu_lib.omchat_comm_destroy(comm)
