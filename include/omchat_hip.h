@@ -125,6 +125,11 @@ int omchat_mha_fwd(const void* qkv, int B, int S, int H, float softmax_scale, in
 /* ---- op-level entry points (unit parity tests, benches) --------------------------------------------------------- */
 int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                    const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream);
+/* same with the stream-K tail enabled: ws from omchat_op_gemm_sk_ws() bytes of device memory; stream_k 0 = auto, 1 = required */
+size_t omchat_op_gemm_sk_ws(void);
+int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                      const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* ws,
+                      size_t ws_bytes, int stream_k, void* stream);
 int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
                    const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream);
 int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream);

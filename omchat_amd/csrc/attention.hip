@@ -29,7 +29,27 @@ struct AttnP {
   int q_heads, kv_heads, Sq, Skv, causal, q_pos0, nsplit;
   float c;      // scale * log2(e)
   float* ws;
+  // decode with fused RoPE + KV append (one new token per sequence): raw q/k/v of the new token live in the qkv buffer
+  const float* rope;      // [max_pos][64][2] or null
+  const int* pos;         // [batch] position of the new token (= kv_len - 1)
+  const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v rows, batch stride (elements); head stride 128
+  void* k_cache_w; void* v_cache_w;                          // writable views of K / V (same strides as K / V)
+  int rope_max;
 };
+
+// RoPE of one 8-element chunk (rotate-half, modeling_qwen2.py:105-135) with the reference's rounding (N11):
+// x = own chunk, o = partner chunk 64 elements away, first half gets -partner*sin, second half +partner*sin
+template <typename T>
+__device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type x, typename V8<T>::type o, const float* cs, bool second_half) {
+  typename V8<T>::type r;
+  const float sgn = second_half ? 1.f : -1.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
+    r[j] = fromf<T>(rnd<T>(tof(x[j]) * co) + rnd<T>(sgn * tof(o[j]) * si));
+  }
+  return r;
+}
 
 constexpr int KV_TILE = 64;
 constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
@@ -94,6 +114,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     }
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = ld8<T>(qp + ds * 32 + fg * 8);
+    if constexpr (DECODE) {
+      if (p.rope) {     // lane holds d = 32*ds + 8*fg + j: the rotate-half partner (d +- 64) is fragment ds +- 2 of the same lane
+        int pp = p.pos[b]; pp = pp < p.rope_max ? pp : p.rope_max - 1;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          const float* cs = p.rope + ((size_t)pp * 64 + ds * 32 + fg * 8) * 2;
+          const frag_t lo = qf[qt][ds], hi = qf[qt][ds + 2];
+          qf[qt][ds] = rope_chunk<T>(lo, hi, cs, false);
+          qf[qt][ds + 2] = rope_chunk<T>(hi, lo, cs, true);
+        }
+      }
+    }
   }
 
   f32x4 o[NQ][8];
@@ -113,8 +145,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     for (int i = 0; i < PF; ++i) {
       const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
       int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;     // clamp: masked keys must still be finite
-      kreg[i] = ld8<T>(Kg + kr * p.k_sr + ch * 8);
-      vreg[i] = ld8<T>(Vg + kr * p.v_sr + ch * 8);
+      bool fresh = false;
+      if constexpr (DECODE) fresh = p.rope && kr >= kv_len - 1;            // the token being appended: not in the cache yet
+      if (fresh) {
+        const int pp = kv_len - 1, pt = pp < p.rope_max ? pp : p.rope_max - 1;
+        const T* kn = (const T*)p.k_new + b * p.new_sb + kvh * 128;
+        const T* vn = (const T*)p.v_new + b * p.new_sb + kvh * 128;
+        const float* cs = p.rope + ((size_t)pt * 64 + (ch & 7) * 8) * 2;
+        kreg[i] = rope_chunk<T>(ld8<T>(kn + ch * 8), ld8<T>(kn + ((ch + 8) & 15) * 8), cs, ch >= 8);
+        vreg[i] = ld8<T>(vn + ch * 8);
+        if (t * KV_TILE + row == pp) {        // the one staging thread per chunk that owns the real row appends it (N14)
+          st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ch * 8, kreg[i]);
+          st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + ch * 8, vreg[i]);
+        }
+      } else {
+        kreg[i] = ld8<T>(Kg + kr * p.k_sr + ch * 8);
+        vreg[i] = ld8<T>(Vg + kr * p.v_sr + ch * 8);
+      }
     }
   };
   auto write_part = [&](int i0) {
@@ -317,7 +364,8 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.Sq > 0 && a.Skv > 0 && a.batch > 0, "empty attention");
   OM_CHECK(a.q_sr % 8 == 0 && a.k_sr % 8 == 0 && a.v_sr % 8 == 0 && a.o_sr % 4 == 0, "row strides must keep 16-B alignment");
   AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
-          a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr};
+          a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
+          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, false>), grid, dim3(256), 0, s, p);
   else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, false>), grid, dim3(256), 0, s, p);
@@ -336,7 +384,9 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   const int nsplit = cdiv(a.L, KV_TILE);
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
-          a.kv_len, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws};
+          a.kv_len, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
+          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max};
+  OM_CHECK(!a.rope || (a.pos && a.k_new && a.v_new && a.kv_len), "fused RoPE decode needs pos, k_new, v_new and kv_len");
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {

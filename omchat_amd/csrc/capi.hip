@@ -8,7 +8,16 @@
 
 extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                               const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream) {
-  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, force_tile};
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, force_tile, nullptr, 0, -1};
+  return launch_gemm(dtype, g, S(stream));
+}
+
+extern "C" size_t omchat_op_gemm_sk_ws(void) { return gemm_sk_ws_bytes(); }
+
+extern "C" int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                 const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* ws,
+                                 size_t ws_bytes, int stream_k, void* stream) {
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, force_tile, ws, ws_bytes, stream_k};
   return launch_gemm(dtype, g, S(stream));
 }
 

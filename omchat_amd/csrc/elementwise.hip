@@ -59,8 +59,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
 
 // decode tail of o_proj / down_proj: add the split-K fp32 slices (fixed order), round like the reference
 // (T(linear) then T(residual + .), modeling_qwen2.py:283-296), then the NEXT RMSNorm of the same row, in one pass.
-template <typename T>
-__global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int ldx, const float* part, int ks, int rows, const T* w, T* xn,
+template <typename T, int KS>
+__global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int ldx, const float* part, int rows, const T* w, T* xn,
                                                                      int ldn, int H, float eps) {
   typedef typename V8<T>::type v8;
   __shared__ float red[NORM_THREADS / 64];
@@ -77,12 +77,16 @@ __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int l
       float a[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = 0.f;
-      for (int s = 0; s < ks; ++s) {
-        const float* pp = part + ((size_t)s * rows + row) * H + c * 8;
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+      f32x4 p0[KS], p1[KS];            // all slices in flight at once (KS is a compile-time constant)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] += p0[j]; a[4 + j] += p1[j]; }
+      for (int s = 0; s < KS; ++s) {
+        const float* pp = part + ((size_t)s * rows + row) * H + c * 8;
+        p0[s] = *reinterpret_cast<const f32x4*>(pp); p1[s] = *reinterpret_cast<const f32x4*>(pp + 4);
       }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)       // fixed summation order: deterministic
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += p0[s][j]; a[4 + j] += p1[s][j]; }
       v8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -455,7 +459,10 @@ int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks,
                          hipStream_t s) {
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldn % 8 == 0 && ks >= 1, "H % 8, H <= 16384, ld % 8");
   if (rows == 0) return 0;
-  DISPATCH(dtype, hipLaunchKernelGGL(resid_rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, part, ks, rows, (const T*)w, (T*)xn, ldn, H, eps));
+  OM_CHECK(ks <= 8, "at most 8 K slices");
+#define RR(KS_) case KS_: DISPATCH(dtype, hipLaunchKernelGGL((resid_rmsnorm_kernel<T, KS_>), dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, part, rows, (const T*)w, (T*)xn, ldn, H, eps)); break;
+  switch (ks) { RR(1) RR(2) RR(3) RR(4) RR(5) RR(6) RR(7) RR(8) }
+#undef RR
   OM_LAUNCH_CHECK();
   return 0;
 }

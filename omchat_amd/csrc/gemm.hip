@@ -25,17 +25,20 @@ struct GemmP {
 // groups of GROUP_M row tiles x all column tiles, row fastest: the 32 workgroups an XCD runs at once then form a 4 x 8
 // block that shares 4 A row-panels and 8 W column-panels per K-step (12 panel slices instead of up to 33).
 constexpr int GROUP_M = 4;
-__device__ __forceinline__ void tile_coords(int M, int N, int BM, int BN, int& m0, int& n0) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+__device__ __forceinline__ void tile_coords_id(int wgid, int M, int N, int BM, int BN, int& m0, int& n0) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int per_group = GROUP_M * tiles_n;
   const int g = wgid / per_group, in_g = wgid % per_group;
   const int rows_here = tiles_m - g * GROUP_M < GROUP_M ? tiles_m - g * GROUP_M : GROUP_M;
   m0 = (g * GROUP_M + in_g % rows_here) * BM;
   n0 = (in_g / rows_here) * BN;
+}
+__device__ __forceinline__ void tile_coords(int M, int N, int BM, int BN, int& m0, int& n0) {
+  tile_coords_id(xcd_remap(blockIdx.x, gridDim.x), M, N, BM, BN, m0, n0);
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -258,19 +261,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
 // data issued in LOAD(Y) by every wave has landed for everyone after barrier 2(Y+4) (vmcnt(8) at the end of LOAD(Y+4)),
 // so it may be read from LOAD(Y+5) on.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
+// K-tiles [kt0, kt1) of the 256x256 tile at (m0, n0), accumulated into acc (zeroed here).  All 512 threads call it
+// together; on return every wave has passed the same number of barriers and no LDS read is outstanding.
+template <typename T>
+__device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, int kt0, int kt1, char* smem, f32x4 (&acc)[8][4]) {
   constexpr int SLOT = 128 * 128;                 // 128 rows x 128 B
   constexpr int STAGE = 4 * SLOT;                 // A_0, A_1, B_0, B_1
   typedef typename V8<T>::type frag_t;
-  extern __shared__ __attribute__((aligned(256))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-
-  int m0, n0;
-  tile_coords(p.M, p.N, 256, 256, m0, n0);
 
   const T* __restrict__ A = (const T*)p.A;
   const T* __restrict__ W = (const T*)p.W;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
     char* base = smem + buf * STAGE + slot * SLOT;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * 64), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (kt0 + kt) * 64), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16, 0, 0);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -308,13 +309,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
     b_off[s] = (wn * 32 + fr) * 128 + pc;
   }
 
-  f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / 64;
+  const int nk = kt1 - kt0;
   // prologue: K-tile 0 completely, plus A_0 / B_0 of K-tile 1 (steady state issues them in p3 / p4 of tile t-1)
   issue(0, 0, a_src[0], 0); issue(0, 2, b_src[0], 0); issue(0, 3, b_src[1], 0); issue(0, 1, a_src[1], 0);
   if (nk > 1) {
@@ -379,21 +379,149 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 matches group 1's extra barrier
 
+}
+
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  int m0, n0;
+  tile_coords(p.M, p.N, 256, 256, m0, n0);          // data-parallel: workgroup = one whole tile (logical ids [0, gridDim))
+  f32x4 acc[8][4];
+  gemm8_segment<T>(p, m0, n0, 0, p.K / 64, smem, acc);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
   gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128 + fg * 4, n0 + wn * 64 + fr, n0 + wn * 64, fr);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Stream-K tail: the tiles of the last, partially filled round (logical ids [tile_first, tile_first + R)) are cut
+// into R * KT K-tile iterations and dealt to the G resident workgroups in contiguous, equal ranges, so every CU gets
+// the same number of MFMA iterations whatever R is.  A range may START inside a tile: that workgroup stores the fp32
+// accumulators of this first segment (one 256 KiB slab per workgroup, lane-linear) and raises its flag at once; the
+// workgroup that began the tile (k = 0, necessarily its LAST segment) adds the slabs of the following workgroups in
+// ascending order (deterministic) and runs the epilogue -- producers publish early, owners wait late: no chains.  Hand-off = cdna_hip_programming.md Guideline 16: every storing wave drains vmcnt, workgroup barrier, one lane
+// agent-scope release + drain + relaxed agent flag store; consumer: one lane polls relaxed (bounded), one agent-scope
+// acquire + drain, workgroup barrier, plain loads.  G <= #CUs with one workgroup per CU (128 KiB LDS), so every awaited
+// producer is resident and producers never wait: no deadlock; flags are zeroed by a memset
+// node before every launch.
+// ---------------------------------------------------------------------------------------------------------
+struct SkP { int tile_first, R; float* slabs; unsigned* flags; unsigned* err; };
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm8_sk_kernel(GemmP p, SkP sk) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int KT = p.K / 64;
+  const int total = sk.R * KT;                      // <= 256 tiles x K/64: fits int with room for the * G below
+  const int G = gridDim.x, w = blockIdx.x;
+  auto begin_of = [&](int g) { return (int)((long)g * total / G); };
+  int it = begin_of(w);
+  const int it_end = begin_of(w + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[8][4];
+  while (it < it_end) {
+    const int tl = it / KT;
+    const int k0 = it - tl * KT;
+    const int k1 = KT - k0 < it_end - it ? KT : k0 + (it_end - it);
+    int m0, n0;
+    tile_coords_id(sk.tile_first + tl, p.M, p.N, 256, 256, m0, n0);
+    gemm8_segment<T>(p, m0, n0, k0, k1, smem, acc);
+    if (k0 > 0) {
+      // contributor: this range starts inside a tile that a LOWER workgroup began; publish the slab right away (it is
+      // the first thing this workgroup computes, so the owner never waits on a chain)
+      // buffer stores: one descriptor (SGPRs) + one per-lane offset; the per-slot offset is a scalar, so no address VGPRs
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sk.slabs + (size_t)w * 65536, 0, 65536 * 4, 0x00020000);
+      const int voff = (wave * 2048 + lane) * 16;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, voff, (i * 4 + j) * 1024, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(sk.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (k1 < KT) {
+        // owner of a tile it cannot finish (its range ends inside the tile, so this is its LAST segment): add the slabs of
+        // the following workgroups, in ascending order, until the tile's K range is covered
+        const int tile_end = (tl + 1) * KT;
+        int covered = tl * KT + k1;
+        for (int c = w + 1; covered < tile_end && c < G; ++c) {
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(sk.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > (1u << 24)) { atomicExch(sk.err, 1u); break; }      // bounded: never hang the device
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sk.slabs + (size_t)c * 65536, 0, 65536 * 4, 0x00020000);
+          const int voff = (wave * 2048 + lane) * 16;
+          // 4 loads in flight at a time: hoisting all 32 would spill the accumulators
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (i * 4 + j) * 1024, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += __builtin_bit_cast(f32x4, v[j]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int e = begin_of(c + 1);
+          covered = e < tile_end ? e : tile_end;
+        }
+      }
+      gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128 + fg * 4, n0 + wn * 64 + fr, n0 + wn * 64, fr);
+    }
+    it += k1 - k0;
+  }
+}
+
+constexpr size_t SK_SLAB_BYTES = 65536 * 4;
+constexpr int SK_MAX_WG = 256;
 
 template <typename T, int EPI>
 int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * 4 * 128 * 128;
   auto kern = gemm8_kernel<T, EPI>;
+  auto kern_sk = gemm8_sk_kernel<T, EPI>;
   static bool attr_set = false;
+  static int n_cu = 0;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    int dev = 0;
+    OM_HIP(hipGetDevice(&dev));
+    OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
   GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K};
-  const int grid = cdiv(a.M, 256) * cdiv(a.N, 256);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+  const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  const int KT = a.K / 64;
+  const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
+  int R = tiles % G;
+  const bool have_ws = a.sk_ws && a.sk_ws_bytes >= (size_t)G * SK_SLAB_BYTES + 4096;
+  // stream-K only pays when the last round is visibly under-filled and every workgroup still gets a few K-tiles
+  // measured on MI355X (r01, tools/bench_gemm.py t20 vs t2): the under-filled GEMMs of this model are operand-fetch bound,
+  // not balance bound, and the slab exchange costs more than the idle CUs: stream-K only runs when explicitly requested
+  const bool use_sk = a.stream_k > 0 && have_ws && R > 0 && R * 10 < G * 9 && (long)R * KT >= 4L * G && KT >= 8;
+  if (a.stream_k > 0 && !use_sk && !have_ws) { omchat_set_error("launch_gemm: stream-K requested without workspace"); return 1; }
+  if (!use_sk) R = 0;
+  const int n_dp = tiles - R;
+  if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p);
+  if (R > 0) {
+    unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
+    OM_HIP(hipMemsetAsync(flags, 0, 4096, stream));
+    SkP sk{n_dp, R, (float*)a.sk_ws, flags, flags + 1000};
+    hipLaunchKernelGGL(kern_sk, dim3(G), dim3(512), LDS, stream, p, sk);
+  }
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -464,6 +592,8 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+size_t gemm_sk_ws_bytes() { return (size_t)SK_MAX_WG * SK_SLAB_BYTES + 4096; }
 
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "empty problem");

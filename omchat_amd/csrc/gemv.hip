@@ -18,6 +18,48 @@ struct GemvP {
   int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
 };
 
+template <typename T, int NTILE, int N, int WAVES, bool NTL>
+__device__ __forceinline__ void gemv_group(f32x4 (&acc)[NTILE], const T* const (&wrow)[NTILE], const T* xrow, int k0, bool xvalid) {
+  typedef typename V8<T>::type frag_t;
+  frag_t wf[N][NTILE][2], xf[N][2];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int k = k0 + u * WAVES * 64;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      if constexpr (NTL) {
+        wf[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k));
+        wf[u][t][1] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k + 32));
+      } else {
+        wf[u][t][0] = ld8<T>(wrow[t] + k);
+        wf[u][t][1] = ld8<T>(wrow[t] + k + 32);
+      }
+    }
+    xf[u][0] = ld8<T>(xrow + k);
+    xf[u][1] = ld8<T>(xrow + k + 32);
+  }
+  frag_t zero;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    if (!xvalid) { xf[u][0] = zero; xf[u][1] = zero; }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      acc[t] = mfma16(wf[u][t][0], xf[u][0], acc[t]);
+      acc[t] = mfma16(wf[u][t][1], xf[u][1], acc[t]);
+    }
+  }
+}
+
+template <typename T, int NTILE, int N, int WAVES, bool NTL>
+__device__ __forceinline__ void gemv_tail(int rem, f32x4 (&acc)[NTILE], const T* const (&wrow)[NTILE], const T* xrow, int k0, bool xvalid) {
+  if constexpr (N > 0) {
+    if (rem == N) gemv_group<T, NTILE, N, WAVES, NTL>(acc, wrow, xrow, k0, xvalid);
+    else gemv_tail<T, NTILE, N - 1, WAVES, NTL>(rem, acc, wrow, xrow, k0, xvalid);
+  }
+}
+
 template <typename T, int NTILE, int EPI, int GV_WAVES = 8, int GV_UNROLL = 4, bool NTL = false>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   typedef typename V8<T>::type frag_t;
@@ -47,50 +89,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   const int nchunk_all = p.K / 64;
   const int c_lo = (int)(((long)nchunk_all * blockIdx.y) / p.ksplit);
   const int nchunk = (int)(((long)nchunk_all * (blockIdx.y + 1)) / p.ksplit);
-  frag_t zero;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
-
-  int c0 = c_lo + wave;
-  // full groups: no per-load predicate (a runtime select around each load would serialise them)
-  for (; c0 + (GV_UNROLL - 1) * GV_WAVES < nchunk; c0 += GV_WAVES * GV_UNROLL) {
-    frag_t wf[GV_UNROLL][NTILE][2], xf[GV_UNROLL][2];
-#pragma unroll
-    for (int u = 0; u < GV_UNROLL; ++u) {
-      const int k = (c0 + u * GV_WAVES) * 64;
-#pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        if constexpr (NTL) {
-          wf[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k));
-          wf[u][t][1] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(wrow[t] + k + 32));
-        } else {
-          wf[u][t][0] = ld8<T>(wrow[t] + k);
-          wf[u][t][1] = ld8<T>(wrow[t] + k + 32);
-        }
-      }
-      xf[u][0] = ld8<T>(xrow + k);
-      xf[u][1] = ld8<T>(xrow + k + 32);
-    }
-#pragma unroll
-    for (int u = 0; u < GV_UNROLL; ++u) {
-      if (!xvalid) { xf[u][0] = zero; xf[u][1] = zero; }
-#pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        acc[t] = mfma16(wf[u][t][0], xf[u][0], acc[t]);
-        acc[t] = mfma16(wf[u][t][1], xf[u][1], acc[t]);
-      }
-    }
-  }
-  for (; c0 < nchunk; c0 += GV_WAVES) {
-    const int k = c0 * 64;
-    frag_t x0 = ld8<T>(xrow + k), x1 = ld8<T>(xrow + k + 32);
-    if (!xvalid) { x0 = zero; x1 = zero; }
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      acc[t] = mfma16(ld8<T>(wrow[t] + k), x0, acc[t]);
-      acc[t] = mfma16(ld8<T>(wrow[t] + k + 32), x1, acc[t]);
-    }
-  }
+  // Wave w owns chunks c_lo + w, c_lo + w + WAVES, ...: full groups of GV_UNROLL chunks in flight, then ONE group of
+  // exactly the remaining count (compile-time unrolled per count, so the tail is as deep as the body).
+  const int first = c_lo + wave;
+  const int n_w = first < nchunk ? (nchunk - first + GV_WAVES - 1) / GV_WAVES : 0;
+  int g = 0;
+  for (; g + GV_UNROLL <= n_w; g += GV_UNROLL)
+    gemv_group<T, NTILE, GV_UNROLL, GV_WAVES, NTL>(acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
+  gemv_tail<T, NTILE, GV_UNROLL - 1, GV_WAVES, NTL>(n_w - g, acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
 
   // acc[t][r] = Y^T[n = n0 + t*16 + 4*fg + r][batch = fr]
 #pragma unroll

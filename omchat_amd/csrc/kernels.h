@@ -23,9 +23,12 @@ struct GemmArgs {
   const void* resid;  // [M, ldr] (EPI_LS_RESID / EPI_RESID); may alias C
   int ldr;
   int epi;
-  int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256, 3 = 256x192, 4 = 224x256, 5 = 192x256
+  int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256 (staggered 4-phase), 3 = 256x192, 4 = 224x256, 5 = 192x256, 6 = 256x256 (one barrier)
+  void* sk_ws; size_t sk_ws_bytes;   // stream-K workspace (gemm_sk_ws_bytes()), null = data-parallel only
+  int stream_k;       // 0 auto (when a workspace is given), -1 never, 1 required
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
+size_t gemm_sk_ws_bytes();
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM (decode)
 // Y[b,N] = epilogue(X[b,K] @ W[N,K]^T) for b <= 16: weight-streaming, HBM-bound.  K % 64 == 0.
@@ -81,6 +84,11 @@ struct AttnDecodeArgs {
   const int* kv_len;                            // optional device [batch]
   float scale;
   float* ws; size_t ws_bytes;                   // workspace for partials
+  // optional fused RoPE + KV append of the token being decoded (replaces rope_kv for S = 1): q is rotated in registers,
+  // the split that owns position pos[b] rotates k, appends k/v to the cache and uses them from LDS
+  const float* rope; int rope_max;              // cos/sin table [max_pos][64][2] or null (= q, K, V already rotated/appended)
+  const int* pos;                               // device [batch]; kv_len[b] must be pos[b] + 1
+  const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v of the new token: [b][kv_heads*128] views, batch stride
 };
 size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len);
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s);

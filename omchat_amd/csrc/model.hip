@@ -98,6 +98,7 @@ struct omchat_ctx {
   float* vw_sumsq = nullptr;
   void *tw_x = nullptr, *tw_x2 = nullptr, *tw_xn = nullptr, *tw_qkv = nullptr, *tw_ao = nullptr, *tw_act = nullptr, *tw_last = nullptr;
   float* tw_logits = nullptr;
+  void* sk_ws = nullptr; size_t sk_ws_bytes = 0;      // stream-K slabs + flags of the MFMA GEMM
   float* tp_table = nullptr;
   void* arg_scratch = nullptr;
   float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
@@ -420,7 +421,7 @@ extern "C" int omchat_weights_missing(omchat_ctx* ctx) {
 // ---------------------------------------------------------------------------------------------------------
 static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias,
                 const void* ls, const void* resid, int ldr, int epi, hipStream_t s) {
-  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, 0};
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, 0, nullptr, 0, -1};
   return launch_gemm(ctx->dt, g, s);
 }
 
@@ -747,8 +748,8 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
     TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE));
-    RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
-    TRY(launch_rope_kv(ctx->dt, r, s));
+    // RoPE + KV append are fused into the attention kernel (q rotated in registers, the split that owns the new
+    // position rotates k and appends k / v)
     AttnDecodeArgs a{};
     a.Q = ctx->tw_qkv; a.q_sb = qkvd; a.q_sh = 128;
     a.K = kc; a.k_sb = ctx->cache_sb(); a.k_sh = ctx->cache_sh(); a.k_sr = 128;
@@ -756,6 +757,8 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     a.O = ctx->tw_ao; a.o_sb = qd; a.o_sh = 128;
     a.batch = b; a.q_heads = c.t_heads; a.kv_heads = c.t_kv_heads; a.L = Lmax; a.kv_len = ctx->d_len; a.scale = 0.08838834764831845f;
     a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
+    a.rope = ctx->rope; a.rope_max = c.max_seq; a.pos = ctx->d_pos;
+    a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o));
@@ -768,9 +771,12 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
       std::swap(x, y);
     }
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
-    ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
+    // HIP-event bracket on ONE layer per token only: each event record costs ~1-2 us of launch-stream time, and 56 of them
+    // per token would themselves slow the measured decode by a few per cent
+    const bool mark = i == c.t_layers / 2;
+    if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU));
-    ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
+    if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (fused) {
       TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm

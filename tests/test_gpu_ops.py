@@ -92,6 +92,34 @@ def test_gemm_staggered_kernel_race_screen(gpu_lib, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K,epi", [(3075, 3200, 3200, _lib.EPI_LS_RESID), (3584, 3584, 3584, _lib.EPI_RESID), (3075, 12800, 3200, _lib.EPI_GELU),
+                                       (1025, 3200, 12800, _lib.EPI_NONE), (3584, 6400, 1024, _lib.EPI_SWIGLU), (700, 3000, 2048, _lib.EPI_NONE)])
+def test_gemm_stream_k_tail(gpu_lib, dt, M, N, K, epi):
+    """stream-K tail (partial slabs + flags between workgroups) == data-parallel result, bit for bit, on repeated launches"""
+    A = rnd(randn((M, K), 21, 0.5), dt); W = rnd(randn((N, K), 22, 0.05), dt)
+    bias = rnd(randn((N,), 23, 0.1), dt); ls = rnd(randn((N,), 24, 0.1) + 0.1, dt); resid = rnd(randn((M, N), 25), dt)
+    dA, dW, db, dl, dr = dev(A, dt), dev(W, dt), dev(bias, dt), dev(ls, dt), dev(resid, dt)
+    No = N // 2 if epi == _lib.EPI_SWIGLU else N
+    use_bias = epi in (_lib.EPI_GELU, _lib.EPI_LS_RESID)
+    wsb = gpu_lib.omchat_op_gemm_sk_ws()
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    base = torch.full((M, No), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(base), No, M, N, K, ptr(db) if use_bias else None, ptr(dl), ptr(dr), N, epi, 2, None))
+    sync()
+    ref = _gemm_ref(A, W, bias if use_bias else None, ls, resid, epi, dt)
+    assert rel(base, ref) < TOL[dt]
+    for it in range(5):
+        out = torch.full((M, No), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemm_sk(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), No, M, N, K, ptr(db) if use_bias else None, ptr(dl), ptr(dr), N,
+                                             epi, 2, ptr(ws), wsb, 1, None))
+        sync()
+        assert torch.isfinite(out.float()).all()
+        assert rel(out, ref) < TOL[dt], (it, rel(out, ref))
+        # the split accumulation adds slabs in a different association than one long K loop: equal up to fp32 rounding
+        assert rel(out, base) < 2e-3
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_gemm_identity_asymmetric(gpu_lib, dt):
     """A = I against an asymmetric W catches a transposed C write (cdna_hip_programming.md §3)."""
     K = 256

@@ -8,6 +8,8 @@ shapes = [("vit_qkv", 3075, 9600, 3200, 0), ("vit_proj", 3075, 3200, 3200, 2), (
           ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0)]
 tiles = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 6, 3, 1]
 p = lambda t: C.c_void_p(t.data_ptr())
+wsb = lib.omchat_op_gemm_sk_ws()
+ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 for name, M, N, K, epi in shapes:
     A = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); W = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
     bias = torch.zeros(N, device="cuda", dtype=torch.bfloat16); ls = torch.ones(N, device="cuda", dtype=torch.bfloat16)
@@ -18,7 +20,10 @@ for name, M, N, K, epi in shapes:
         if epi == 4 and tile == 3:
             continue
         def run():
-            _lib.check(lib.omchat_op_gemm(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, tile, None))
+            if tile == 20:      # 256^2 staggered kernel + stream-K tail
+                _lib.check(lib.omchat_op_gemm_sk(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, 2, p(ws), wsb, 0, None))
+            else:
+                _lib.check(lib.omchat_op_gemm(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, tile, None))
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
