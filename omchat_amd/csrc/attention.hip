@@ -61,14 +61,33 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
 }
 
+// lane ^ 32 / lane ^ 16 reductions on the VALU (v_permlane32_swap / v_permlane16_swap): swapping a value with itself gives
+// {own, partner}; no LDS round trip (ds_bpermute) on the softmax critical path
+__device__ __forceinline__ float max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <typename T, int NW, int NQ, bool DECODE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   constexpr int NT = NW * 64;
   constexpr int CH = 1024 / NT;            // 16-B chunks per thread per tile (K and V each)
-  __shared__ __attribute__((aligned(256))) char smem[2 * KV_TILE * 256];
-  char* const Ks = smem;
-  char* const Vs = smem + KV_TILE * 256;
+  constexpr int NBUF = DECODE ? 1 : 2;     // prefill double-buffers the K/V tiles: one barrier per tile
+  constexpr int BUF = 2 * KV_TILE * 256;
+  __shared__ __attribute__((aligned(256))) char smem[NBUF * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,21 +183,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
       }
     }
   };
-  auto write_part = [&](int i0) {
+  auto write_part = [&](int i0, int buf) {
+    char* const Kw = smem + buf * BUF;
+    char* const Vw = Kw + KV_TILE * 256;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
-      *reinterpret_cast<frag_t*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
-      *reinterpret_cast<frag_t*>(Vs + row * 256 + ((ch ^ ((row & 7) << 1)) << 4)) = vreg[i];
+      *reinterpret_cast<frag_t*>(Kw + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<frag_t*>(Vw + row * 256 + ((ch ^ ((row & 7) << 1)) << 4)) = vreg[i];
     }
   };
   auto load_tile = [&](int t) { if constexpr (!DECODE) load_part(t, 0); };
-  auto write_tile = [&](int t) {
+  auto write_tile = [&](int t, int buf) {
     if constexpr (DECODE) {
 #pragma unroll
-      for (int i0 = 0; i0 < CH; i0 += PF) { load_part(t, i0); write_part(i0); }
+      for (int i0 = 0; i0 < CH; i0 += PF) { load_part(t, i0); write_part(i0, buf); }
     } else {
-      write_part(0);
+      write_part(0, buf);
     }
   };
 
@@ -189,12 +210,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   const int vrow_lo = 4 * fg + tq;                       // (+32*ks, +16 for the second read)
   const int vswz = ((vrow_lo & 7) << 1);                 // rows +16 / +32 keep (row & 7)
 
-  if (t_begin < t_end) load_tile(t_begin);
+  // tile t lives in buffer (t - t_begin) & 1.  Iteration t: S^T and softmax from buffer cur, then the registers holding tile
+  // t+1 go to the other buffer (last read in iteration t-1, a barrier ago) and the global loads of tile t+2 are issued,
+  // then PV from buffer cur, then ONE barrier.
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    write_tile(t_begin, 0);
+    if (t_begin + 1 < t_end) load_tile(t_begin + 1);
+  }
+  __syncthreads();
   for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();                 // everyone is done reading the previous tile
-    write_tile(t);
-    __syncthreads();
-    if (t + 1 < t_end) load_tile(t + 1);     // in flight during the MFMA work below
+    const int cur = DECODE ? 0 : ((t - t_begin) & 1);
+    const char* const Ks = smem + cur * BUF;
+    const char* const Vs = Ks + KV_TILE * 256;
 
     // ---- S^T = K Q^T
     f32x4 s[NQ][4];
@@ -232,8 +260,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
       float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
 #pragma unroll
       for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[qt][kt][0], s[qt][kt][1]), fmaxf(s[qt][kt][2], s[qt][kt][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_xor32(max_xor16(mx));
       // rescale only when some query of the wave really raised its max (exact: alpha == 1 otherwise)
       if (__any(mx > m_run[qt])) {
         const float m_new = fmaxf(m_run[qt], mx);
@@ -259,6 +286,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
       l_run[qt] += psum;
     }
 
+    if constexpr (!DECODE) {
+      if (t + 1 < t_end) {
+        write_tile(t + 1, cur ^ 1);
+        if (t + 2 < t_end) load_tile(t + 2);
+      }
+    }
+
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -274,14 +308,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int qt = 0; qt < NQ; ++qt) o[qt][dn] = mfma16(vf, pf[qt][ks], o[qt][dn]);
       }
+    __syncthreads();       // tile t fully consumed, tile t+1 fully written
   }
 
   // ---- finalize.  o[qt][dn][r] = O^T[d = 16*dn + 4*fg + r][query fc]
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = sum_xor32(sum_xor16(l_run[qt]));
     if constexpr (DECODE) {
       if (fc < n_rep) {
         float* w = p.ws + ((size_t)(b * p.q_heads + hq0 + fc) * p.nsplit + split) * WS_STRIDE;

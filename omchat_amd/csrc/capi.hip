@@ -12,6 +12,12 @@ extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, 
   return launch_gemm(dtype, g, S(stream));
 }
 
+extern "C" int omchat_op_set_tuning(int key, int value) {
+  if (key == 0) { gemm_set_skew(value); return 0; }
+  omchat_set_error("omchat_op_set_tuning: unknown key");
+  return 1;
+}
+
 extern "C" size_t omchat_op_gemm_sk_ws(void) { return gemm_sk_ws_bytes(); }
 
 extern "C" int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,

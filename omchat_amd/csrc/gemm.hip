@@ -383,10 +383,18 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
 
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm8_kernel(GemmP p) {
+__global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   int m0, n0;
   tile_coords(p.M, p.N, 256, 256, m0, n0);          // data-parallel: workgroup = one whole tile (logical ids [0, gridDim))
+  if (skew > 0) {
+    // Start skew between the workgroups of an XCD that share an operand panel (logical ids walk GROUP_M rows, then the next
+    // column): tiles that begin in lockstep all miss on the same L2 lines at the same moment and every miss goes to the
+    // fabric (TCC_MISS ~ sharers x unique bytes, measured); a delay of a fraction of a K-step lets the followers hit.
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int d = (id & 3) + ((id >> 2) & 3);
+    for (int i = 0; i < d * skew; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   f32x4 acc[8][4];
   gemm8_segment<T>(p, m0, n0, 0, p.K / 64, smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(GemmP p, SkP sk) {
   }
 }
 
+int g_gemm_skew = 0;      // tuning knob (omchat_op_set_tuning), units of s_sleep(16) ~ 1024 cycles
 constexpr size_t SK_SLAB_BYTES = 65536 * 4;
 constexpr int SK_MAX_WG = 256;
 
@@ -515,7 +524,7 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   if (a.stream_k > 0 && !use_sk && !have_ws) { omchat_set_error("launch_gemm: stream-K requested without workspace"); return 1; }
   if (!use_sk) R = 0;
   const int n_dp = tiles - R;
-  if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p);
+  if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
   if (R > 0) {
     unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
     OM_HIP(hipMemsetAsync(flags, 0, 4096, stream));
@@ -593,6 +602,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+void gemm_set_skew(int v) { g_gemm_skew = v; }
 size_t gemm_sk_ws_bytes() { return (size_t)SK_MAX_WG * SK_SLAB_BYTES + 4096; }
 
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {

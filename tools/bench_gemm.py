@@ -19,11 +19,16 @@ for name, M, N, K, epi in shapes:
     for tile in tiles:
         if epi == 4 and tile == 3:
             continue
+        lib.omchat_op_set_tuning(0, 0)
+        if tile >= 100:          # 1xx: 256^2 staggered kernel with start skew xx
+            lib.omchat_op_set_tuning(0, tile - 100); tile_code = 2
+        else:
+            tile_code = tile
         def run():
             if tile == 20:      # 256^2 staggered kernel + stream-K tail
                 _lib.check(lib.omchat_op_gemm_sk(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, 2, p(ws), wsb, 0, None))
             else:
-                _lib.check(lib.omchat_op_gemm(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, tile, None))
+                _lib.check(lib.omchat_op_gemm(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, tile_code, None))
         for _ in range(3): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
