@@ -338,6 +338,159 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode attention, one wave per (64-key split, kv head, sequence).  Same transposed MFMA formulation as the prefill kernel
+// with the n_rep query heads of the kv group as the 16 "queries", but latency-shaped: ALL global loads of the tile (K as
+// MFMA A fragments straight to registers, V for the LDS transpose image, Q, RoPE table row) are issued at once -- one HBM
+// round trip -- then S^T from registers, softmax, V -> LDS, PV through ds_read_b64_tr_b16.  With `rope` set it also
+// rotates q in registers and, in the split that owns the new position, rotates k and appends k / v to the cache
+// (replaces the separate RoPE + KV-append launch for S = 1).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ __attribute__((aligned(256))) char Vs[KV_TILE * 256];
+  const int lane = threadIdx.x, fc = lane & 15, fg = lane >> 4;
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  const int key0 = split * KV_TILE;
+  float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
+  if (key0 >= kv_len) {                       // empty split (uniform): neutral partial
+    if (fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
+    return;
+  }
+  const bool fuse = p.rope != nullptr;
+  const int pp = kv_len - 1;                  // position of the token being appended (fuse)
+  const int pt = pp < p.rope_max ? pp : p.rope_max - 1;
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
+  const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
+
+  // ---- issue every load of the tile
+  frag_t kf[4][4];                            // A operand of S^T: key = key0 + 16*kt + fc, d = 32*ds + 8*fg + j
+  bool kfresh[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = key0 + kt * 16 + fc;
+    kfresh[kt] = fuse && key >= pp;           // not in the cache yet (or clamped onto it)
+    const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
+  }
+  frag_t vreg[16];                            // V^T image source: chunk idx = i*64 + lane -> row = 4*i + fg, ch = fc
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int key = key0 + i * 4 + fg;
+    const bool fresh = fuse && key >= pp;
+    const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+    vreg[i] = ld8<T>(src + fc * 8);
+  }
+  frag_t qf[4];
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
+  }
+  if (fuse) {
+    // rotate-half partner of d = 32*ds + 8*fg + j is fragment ds ^ 2 of the same lane (q and fresh k alike)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
+      const frag_t lo = qf[ds], hi = qf[ds + 2];
+      qf[ds] = rope_chunk<T>(lo, hi, cs, false);
+      qf[ds + 2] = rope_chunk<T>(hi, lo, cs, true);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kfresh[kt]) {
+          const frag_t kl = kf[kt][ds], kh = kf[kt][ds + 2];
+          kf[kt][ds] = rope_chunk<T>(kl, kh, cs, false);
+          kf[kt][ds + 2] = rope_chunk<T>(kh, kl, cs, true);
+        }
+    }
+    // append (N14): the lanes that hold the real row pp write it (4 lanes x 4 chunks for k, 16 lanes x 1 chunk for v)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (key0 + kt * 16 + fc == pp) {
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+          st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ds * 32 + fg * 8, kf[kt][ds]);
+      }
+  }
+
+  // ---- S^T = K Q^T from registers
+  f32x4 s[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kf[kt][ds], qf[ds], s[kt]);
+  }
+  // ---- softmax over this split (keys >= kv_len masked)
+  float mx = NEG_BIG;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? s[kt][r] : NEG_BIG;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = max_xor32(max_xor16(mx));
+  const float mc = mx * p.c;
+  float psum = 0.f;
+  frag_t pf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
+      psum += e[j];
+    }
+    pf[ks] = __builtin_convertvector(e, frag_t);
+  }
+  const float l = sum_xor32(sum_xor16(psum));
+
+  // ---- V -> LDS transpose image (chunk' = chunk ^ ((row & 7) << 1)), append the fresh v row
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = i * 4 + fg;
+    *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ ((row & 7) << 1)) << 4)) = vreg[i];
+    if (fuse && key0 + row == pp)
+      st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + fc * 8, vreg[i]);
+  }
+  __syncthreads();
+
+  // ---- O^T = V^T P^T
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;
+  const int vswz = ((vrow_lo & 7) << 1);
+  f32x4 o[8];
+#pragma unroll
+  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) {
+      const int ch = (2 * dn + (tp >> 1)) ^ vswz;
+      const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+      const s16x4 lo = tr_read(a0);
+      const s16x4 hi = tr_read(a0 + 16 * 256);
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
+    }
+  if (fc < n_rep) {
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
+    if (fg == 0) { wsb[128] = mx; wsb[129] = l; }
+  }
+}
+
 // merge split-KV partials: one 128-thread block per (sequence, head).  Phase 1: thread s owns split s (max, weight);
 // phase 2: thread d sums its column over the splits with independent (unrolled) loads.
 template <typename T>
@@ -423,10 +576,10 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
-    hipLaunchKernelGGL((attn_kernel<f16, 1, 1, true>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(attn_decode_kernel<f16>, grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh);
   } else if (dtype == OMCHAT_BF16) {
-    hipLaunchKernelGGL((attn_kernel<bf16, 1, 1, true>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(attn_decode_kernel<bf16>, grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
