@@ -155,12 +155,153 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// b = 1: whole-row streaming + packed dot products.  Measured on MI355X (tools/tune_rowdot.hip): 6.5-6.8 TB/s on the
+// gate|up shape against 5.5 TB/s for the MFMA form above, whose 16-row x 64-B fragment reads reach ~6.0 TB/s at best; here
+// every wave instruction reads 1 KiB of ONE row (non-temporal).  x (this workgroup's K slice) sits in registers; a wave
+// takes R rows at a time (all R x NCH loads in flight), v_dot2 per 32 bits, butterfly over the wave, lane 0 applies the
+// epilogue.  Split-K slices are chunk ranges of 512 elements, <= RW_MAXC chunks each.
+// ---------------------------------------------------------------------------------------------------------
+int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
+constexpr int RW_MAXC = 8;
+typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ float rw_dot8(rw_u32x4 w, rw_u32x4 x, float acc);
+template <> __device__ __forceinline__ float rw_dot8<bf16>(rw_u32x4 w, rw_u32x4 x, float acc) {
+  typedef bf16 v2 __attribute__((ext_vector_type(2)));
+  // explicit components: bit_cast of a loop-indexed vector element was observed to read element 0 four times
+  const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w0), __builtin_bit_cast(v2, x0), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w1), __builtin_bit_cast(v2, x1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w2), __builtin_bit_cast(v2, x2), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w3), __builtin_bit_cast(v2, x3), acc, false);
+  return acc;
+}
+template <> __device__ __forceinline__ float rw_dot8<f16>(rw_u32x4 w, rw_u32x4 x, float acc) {
+  typedef f16 v2 __attribute__((ext_vector_type(2)));
+  const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w0), __builtin_bit_cast(v2, x0), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w1), __builtin_bit_cast(v2, x1), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w2), __builtin_bit_cast(v2, x2), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w3), __builtin_bit_cast(v2, x3), acc, false);
+  return acc;
+}
+
+// rows r0 .. r0+R-1 (already mapped to weight-row indices by the caller) over NCH chunks starting at element k0
+template <typename T, int R, int NCH>
+__device__ __forceinline__ void rw_rows(const T* W, int ldw, const int (&rows)[R], int k0, int K, int lane, const rw_u32x4 (&xr)[RW_MAXC],
+                                        float (&acc)[R]) {
+  rw_u32x4 w[R][NCH];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int k = k0 + c * 512 + lane * 8;
+      k = k < K ? k : k0;                       // ragged last chunk: clamp (x is zero there)
+      w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>(W + (size_t)rows[r] * ldw + k));
+    }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a = rw_dot8<T>(w[r][c], xr[c], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    acc[r] = a;
+  }
+}
+
+template <typename T, int R, int N>
+__device__ __forceinline__ void rw_dispatch(int nch, const T* W, int ldw, const int (&rows)[R], int k0, int K, int lane,
+                                            const rw_u32x4 (&xr)[RW_MAXC], float (&acc)[R]) {
+  if constexpr (N > 0) {
+    if (nch == N) rw_rows<T, R, N>(W, ldw, rows, k0, K, lane, xr, acc);
+    else rw_dispatch<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, acc);
+  }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvP p) {
+  constexpr int R = EPI == EPI_SWIGLU ? 8 : 4;            // SwiGLU: 4 (gate, up) row pairs per group
+  constexpr int OUT = EPI == EPI_SWIGLU ? 4 : R;          // outputs per group
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* W = (const T*)p.W;
+  // K slice of this workgroup row (blockIdx.y): chunk range [c_lo, c_hi)
+  const int nch_all = (p.K + 511) / 512;
+  const int c_lo = (int)(((long)nch_all * blockIdx.y) / p.ksplit), c_hi = (int)(((long)nch_all * (blockIdx.y + 1)) / p.ksplit);
+  const int nch = c_hi - c_lo, k0 = c_lo * 512;
+  rw_u32x4 xr[RW_MAXC];
+#pragma unroll
+  for (int c = 0; c < RW_MAXC; ++c) {
+    const int k = k0 + c * 512 + lane * 8;
+    rw_u32x4 z = {0u, 0u, 0u, 0u};
+    xr[c] = (c < nch && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+  }
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  const int ngroups = (n_out + OUT - 1) / OUT;
+  for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+    int rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        int n = g * 4 + (r & 3); n = n < n_out ? n : n_out - 1;
+        rows[r] = 32 * (n >> 4) + (n & 15) + (r >> 2) * 16;       // gate row, then the matching up row
+      } else {
+        const int n = g * R + r;
+        rows[r] = n < p.N ? n : p.N - 1;
+      }
+    }
+    float acc[R];
+    rw_dispatch<T, R, RW_MAXC>(nch, W, p.ldw, rows, k0, p.K, lane, xr, acc);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < OUT; ++r) {
+        const int n = g * OUT + r;
+        if (n >= n_out) continue;
+        if constexpr (EPI == EPI_SWIGLU) {
+          const float gt = rnd<T>(acc[r]), up = rnd<T>(acc[r + 4]);
+          ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
+        } else if constexpr (EPI == EPI_PARTIAL) {
+          ((float*)p.Y)[(size_t)blockIdx.y * p.ldy + n] = acc[r];        // [ksplit][1][ldy]
+        } else {
+          float y = acc[r] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+          if (p.out_f32) ((float*)p.Y)[n] = y;
+          else {
+            y = rnd<T>(y);
+            if constexpr (EPI == EPI_RESID) y = tof(((const T*)p.resid)[n]) + y;
+            ((T*)p.Y)[n] = fromf<T>(y);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int EPI>
+void launch_rows(const GemvP& p, hipStream_t s) {
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  const int ngroups = cdiv(n_out, 4);
+  int grid = cdiv(ngroups, 4);
+  grid = grid > 2048 ? 2048 : grid;
+  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+}
+
 // Launch shapes measured with tools/tune_gemv.hip on MI355X (r01): plain loads beat non-temporal ones for this access
 // shape (gate|up 54.9 -> 49.4 us), split-K slices prefer 4 waves x 8 chunks in flight when a slice is short.
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks};
+  if (a.b == 1 && !a.force_mfma && !g_gemv_force_mfma && cdiv(cdiv(a.K, 512), ks) <= RW_MAXC) {       // whole-row streaming form
+    switch (a.epi) {
+      case EPI_PARTIAL: launch_rows<T, EPI_PARTIAL>(p, s); break;
+      case EPI_SWIGLU: launch_rows<T, EPI_SWIGLU>(p, s); break;
+      case EPI_RESID: launch_rows<T, EPI_RESID>(p, s); break;
+      default: launch_rows<T, EPI_NONE>(p, s); break;
+    }
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.epi == EPI_PARTIAL) {
     if (a.K / 64 / ks <= 32)
       hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_PARTIAL, 4, 8>), dim3(cdiv(a.N, 16), ks), dim3(256), 0, s, p);
@@ -182,6 +323,8 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 16, "batch must be 1..16 per call");

@@ -43,8 +43,10 @@ struct GemvArgs {
   int epi;                  // EPI_NONE | EPI_RESID | EPI_SWIGLU | EPI_PARTIAL
   int out_f32;
   int ksplit;               // K slices across workgroups (EPI_PARTIAL), <= 1 = none
+  int force_mfma;           // 1 = always the MFMA form (tests / A-B); default: b == 1 uses the whole-row streaming form
 };
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
+void gemv_set_force_mfma(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)

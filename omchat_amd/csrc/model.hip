@@ -739,8 +739,11 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     return launch_gemv(ctx->dt, g, s);
   };
   const bool fused = ctx->tp_size == 1 && b <= 16;
-  const int ks_o = std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));      // ~2 workgroups per CU
-  const int ks_d = std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
+  // K slices: batch 1 (whole-row streaming form) wants <= 8 chunks of 512 per slice and >= ~2500 waves in the grid;
+  // the MFMA form (b > 1) wants ~2-3 workgroups per CU
+  auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return std::max(1, std::min(std::min(DEC_KS_MAX, nch), std::max(cdiv(nch, 8), cdiv(2500, cdiv(H, 4))))); };
+  const int ks_o = b == 1 ? ks_rows(qd) : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));
+  const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
   if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];

@@ -142,8 +142,18 @@ def test_gemm_in_place_residual(gpu_lib, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("b,N,K", [(1, 100, 256), (5, 4608, 3584), (16, 320, 512), (1, 3584, 18944), (3, 160, 64)])
-def test_gemv(gpu_lib, dt, b, N, K):
+@pytest.mark.parametrize("form", ["auto", "mfma"])
+@pytest.mark.parametrize("b,N,K", [(1, 100, 256), (5, 4608, 3584), (16, 320, 512), (1, 3584, 18944), (3, 160, 64), (1, 37888, 3584), (1, 96, 2368)])
+def test_gemv(gpu_lib, dt, form, b, N, K):
+    """b == 1 takes the whole-row streaming (v_dot2) form unless the MFMA form is forced; both must agree with the reference"""
+    gpu_lib.omchat_op_set_tuning(1, 1 if form == "mfma" else 0)
+    try:
+        _gemv_case(gpu_lib, dt, b, N, K)
+    finally:
+        gpu_lib.omchat_op_set_tuning(1, 0)
+
+
+def _gemv_case(gpu_lib, dt, b, N, K):
     X = rnd(randn((b, K), 1), dt); W = rnd(randn((N, K), 2, 0.03), dt)
     bias = rnd(randn((N,), 3, 0.1), dt); resid = rnd(randn((b, N), 4), dt)
     dX, dW, db, dr = dev(X, dt), dev(W, dt), dev(bias, dt), dev(resid, dt)
