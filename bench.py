@@ -212,9 +212,9 @@ def main():
     roof = None
     if n:
         avg_s = ms / n / 1e3
-        roof = {"bound": "hbm", "kernel": "gemv_kernel<NTILE=2,EPI_SWIGLU> (decode gate|up)", "achieved": gu_bytes / avg_s / 1e9,
+        roof = {"bound": "hbm", "kernel": "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream)", "achieved": gu_bytes / avg_s / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(["gemv_kernel", "Li2ELi4E"]) if (world == 1 and not a.tiny) else None,
+                "traffic": pmc_traffic(["gemv_rows_kernel", "Li4E"]) if (world == 1 and not a.tiny) else None,
                 "avg_launch_us": avg_s * 1e6, "launches": n, "bytes_per_launch": gu_bytes}
     ms, n = prof[_lib.PROF_PREFILL_GATEUP]
     roof_pre = None

@@ -220,10 +220,10 @@ __device__ __forceinline__ void rw_dispatch(int nch, const T* W, int ldw, const 
   }
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(GemvP p) {
-  constexpr int R = EPI == EPI_SWIGLU ? 8 : 4;            // SwiGLU: 4 (gate, up) row pairs per group
-  constexpr int OUT = EPI == EPI_SWIGLU ? 4 : R;          // outputs per group
+template <typename T, int EPI, int RR = 4, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
+  constexpr int R = EPI == EPI_SWIGLU ? 2 * RR : RR;      // SwiGLU: RR (gate, up) row pairs per group
+  constexpr int OUT = RR;                                 // outputs per group
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* W = (const T*)p.W;
   // K slice of this workgroup row (blockIdx.y): chunk range [c_lo, c_hi)
@@ -239,13 +239,13 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvP p) {
   }
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   const int ngroups = (n_out + OUT - 1) / OUT;
-  for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+  for (int g = blockIdx.x * WAVES + wave; g < ngroups; g += gridDim.x * WAVES) {
     int rows[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if constexpr (EPI == EPI_SWIGLU) {
-        int n = g * 4 + (r & 3); n = n < n_out ? n : n_out - 1;
-        rows[r] = 32 * (n >> 4) + (n & 15) + (r >> 2) * 16;       // gate row, then the matching up row
+        int n = g * RR + (r % RR); n = n < n_out ? n : n_out - 1;
+        rows[r] = 32 * (n >> 4) + (n & 15) + (r / RR) * 16;       // gate rows, then the matching up rows
       } else {
         const int n = g * R + r;
         rows[r] = n < p.N ? n : p.N - 1;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvP p) {
         const int n = g * OUT + r;
         if (n >= n_out) continue;
         if constexpr (EPI == EPI_SWIGLU) {
-          const float gt = rnd<T>(acc[r]), up = rnd<T>(acc[r + 4]);
+          const float gt = rnd<T>(acc[r]), up = rnd<T>(acc[r + RR]);
           ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
         } else if constexpr (EPI == EPI_PARTIAL) {
           ((float*)p.Y)[(size_t)blockIdx.y * p.ldy + n] = acc[r];        // [ksplit][1][ldy]
@@ -277,13 +277,19 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(GemvP p) {
   }
 }
 
+template <typename T, int EPI, int RR>
+void launch_rows_r(const GemvP& p, hipStream_t s) {
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  int grid = cdiv(cdiv(n_out, RR), 4);
+  grid = grid > 2048 ? 2048 : grid;
+  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+}
+// rows per wave-group from tools/tune_rows.hip (MI355X, r01): short outputs (fused qkv) are latency-bound and want the most
+// waves (R = 1: 7.8 vs 8.8 us), everything else is flat in R; 4 waves per workgroup beat 8
 template <typename T, int EPI>
 void launch_rows(const GemvP& p, hipStream_t s) {
-  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
-  const int ngroups = cdiv(n_out, 4);
-  int grid = cdiv(ngroups, 4);
-  grid = grid > 2048 ? 2048 : grid;
-  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+  if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1>(p, s);
+  else launch_rows_r<T, EPI, 4>(p, s);
 }
 
 // Launch shapes measured with tools/tune_gemv.hip on MI355X (r01): plain loads beat non-temporal ones for this access
