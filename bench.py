@@ -255,7 +255,7 @@ def main():
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N = 1 only
         res["cpu_baseline"] = cpu_baseline(cfg, S, a.gen, n_tiles)
     print(json.dumps(res))
 
