@@ -15,7 +15,7 @@
 // V tile LDS image: 256-B rows, 16-B chunk' = chunk ^ ((row & 7) << 1) (conflict-free transposed reads)
 //
 // Prefill: workgroup = 4 waves x 32 queries (2 query tiles per wave share every K/V fragment), KV tile = 64 keys,
-// next tile's global loads are issued before the MFMA work of the current one (register staged).
+// double-buffered in LDS and filled by LDS-DMA one tile ahead.
 // Decode: one wave per (sequence, kv head, 64-key split); the "queries" are the n_rep heads sharing that kv head;
 // partial (m, l, O) go to a workspace and a merge kernel normalises.
 #include "kernels.h"
@@ -54,6 +54,7 @@ __device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type 
 constexpr int KV_TILE = 64;
 constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
 constexpr float NEG_BIG = -1e30f;
+constexpr float RESCALE_LOG2 = 8.f;   // prefill: running-max reference moves only on a > 2^8 overshoot
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -80,71 +81,70 @@ __device__ __forceinline__ float sum_xor16(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <typename T, int NW, int NQ, bool DECODE>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Prefill kernel.  K/V tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write): the LDS
+// destination is lane-linear (wave instruction i of wave w fills rows 4*(NW*i + w) .. +3), so the bank swizzles are
+// applied to the per-lane SOURCE chunk (physical chunk pc of row r holds logical chunk pc ^ f(r)).  Tile t+1 is issued
+// right after the barrier that opens iteration t and is waited for (vmcnt(0)) just before the next barrier.
+// raw v_max3_f32 / v_max_f32: fmaxf() makes the compiler canonicalise every operand it cannot prove quiet (an extra
+// v_max x, x each); the scores are finite by construction
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max_xor32_raw(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor16_raw(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <typename T, int NW, int NQ>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   constexpr int NT = NW * 64;
-  constexpr int CH = 1024 / NT;            // 16-B chunks per thread per tile (K and V each)
-  constexpr int NBUF = DECODE ? 1 : 2;     // prefill double-buffers the K/V tiles: one barrier per tile
+  constexpr int CH = 1024 / NT;            // LDS-DMA instructions per thread per tile (K and V each)
+  constexpr int RPI = NT / 16;             // rows covered by one instruction round of the workgroup
   constexpr int BUF = 2 * KV_TILE * 256;
-  __shared__ __attribute__((aligned(256))) char smem[NBUF * BUF];
+  __shared__ __attribute__((aligned(256))) char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fc = lane & 15, fg = lane >> 4;
 
-  int b, hq0, kvh, n_rep, q0 = 0, t_begin, t_end, split = 0;
-  n_rep = p.q_heads / p.kv_heads;
-  if constexpr (DECODE) {
-    split = blockIdx.x; kvh = blockIdx.y; b = blockIdx.z; hq0 = kvh * n_rep;
-  } else {
-    const int nqb = gridDim.x;
-    const int qb = p.causal ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;     // heaviest causal blocks first
-    hq0 = blockIdx.y; kvh = hq0 / n_rep; b = blockIdx.z;
-    q0 = qb * (NW * NQ * 16);
-  }
+  const int n_rep = p.q_heads / p.kv_heads;
+  const int nqb = gridDim.x;
+  const int qb = p.causal ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;     // heaviest causal blocks first
+  const int hq0 = blockIdx.y, kvh = hq0 / n_rep, b = blockIdx.z;
+  const int q0 = qb * (NW * NQ * 16);
   const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
-  if constexpr (DECODE) {
-    t_begin = split; t_end = split + 1;
-    if (t_begin * KV_TILE >= kv_len) t_end = t_begin;      // empty split: writes l = 0, m = NEG_BIG
-  } else {
-    int kmax = kv_len;
-    if (p.causal) { const int lim = q0 + NW * NQ * 16 + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
-    t_begin = 0; t_end = (kmax + KV_TILE - 1) / KV_TILE;
-  }
+  int kmax = kv_len;
+  if (p.causal) { const int lim = q0 + NW * NQ * 16 + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
+  const int t_end = (kmax + KV_TILE - 1) / KV_TILE;
 
   const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
 
   // ---- Q fragments (B operand of S^T): lane holds Q[query fc][d = 32*ds + 8*fg + j]
   frag_t qf[NQ][4];
-  int qrow[NQ];                 // prefill: global query row of this lane's column; decode: head index in the group
+  int qrow[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    const T* qp;
-    if constexpr (DECODE) {
-      qrow[qt] = fc;
-      const int hh = fc < n_rep ? fc : n_rep - 1;
-      qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
-    } else {
-      qrow[qt] = q0 + (wave * NQ + qt) * 16 + fc;
-      const int rr = qrow[qt] < p.Sq ? qrow[qt] : p.Sq - 1;
-      qp = (const T*)p.Q + b * p.q_sb + hq0 * p.q_sh + rr * p.q_sr;
-    }
+    qrow[qt] = q0 + (wave * NQ + qt) * 16 + fc;
+    const int rr = qrow[qt] < p.Sq ? qrow[qt] : p.Sq - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + hq0 * p.q_sh + rr * p.q_sr;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = ld8<T>(qp + ds * 32 + fg * 8);
-    if constexpr (DECODE) {
-      if (p.rope) {     // lane holds d = 32*ds + 8*fg + j: the rotate-half partner (d +- 64) is fragment ds +- 2 of the same lane
-        int pp = p.pos[b]; pp = pp < p.rope_max ? pp : p.rope_max - 1;
-#pragma unroll
-        for (int ds = 0; ds < 2; ++ds) {
-          const float* cs = p.rope + ((size_t)pp * 64 + ds * 32 + fg * 8) * 2;
-          const frag_t lo = qf[qt][ds], hi = qf[qt][ds + 2];
-          qf[qt][ds] = rope_chunk<T>(lo, hi, cs, false);
-          qf[qt][ds + 2] = rope_chunk<T>(hi, lo, cs, true);
-        }
-      }
-    }
   }
 
   f32x4 o[NQ][8];
@@ -156,50 +156,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     for (int dn = 0; dn < 8; ++dn) o[qt][dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- staging: thread handles chunks idx = i*NT + tid -> row = idx >> 4, ch = idx & 15
-  constexpr int PF = DECODE ? 4 : CH;      // chunks held in registers at a time
-  frag_t kreg[PF], vreg[PF];
-  auto load_part = [&](int t, int i0) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
-      int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;     // clamp: masked keys must still be finite
-      bool fresh = false;
-      if constexpr (DECODE) fresh = p.rope && kr >= kv_len - 1;            // the token being appended: not in the cache yet
-      if (fresh) {
-        const int pp = kv_len - 1, pt = pp < p.rope_max ? pp : p.rope_max - 1;
-        const T* kn = (const T*)p.k_new + b * p.new_sb + kvh * 128;
-        const T* vn = (const T*)p.v_new + b * p.new_sb + kvh * 128;
-        const float* cs = p.rope + ((size_t)pt * 64 + (ch & 7) * 8) * 2;
-        kreg[i] = rope_chunk<T>(ld8<T>(kn + ch * 8), ld8<T>(kn + ((ch + 8) & 15) * 8), cs, ch >= 8);
-        vreg[i] = ld8<T>(vn + ch * 8);
-        if (t * KV_TILE + row == pp) {        // the one staging thread per chunk that owns the real row appends it (N14)
-          st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ch * 8, kreg[i]);
-          st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + ch * 8, vreg[i]);
-        }
-      } else {
-        kreg[i] = ld8<T>(Kg + kr * p.k_sr + ch * 8);
-        vreg[i] = ld8<T>(Vg + kr * p.v_sr + ch * 8);
-      }
-    }
-  };
-  auto write_part = [&](int i0, int buf) {
+  // ---- staging: instruction i of this thread fills LDS (row = i*RPI + tid/16, physical chunk tid%16).  RPI is a multiple
+  // of 16, so the swizzled source chunk is the same for every i: one base pointer per operand + wave-uniform row offsets
+  static_assert(RPI % 16 == 0, "staging rows per round must keep row & 15");
+  const int srow = tid >> 4, spc = tid & 15;
+  const T* const kbase = Kg + (int64_t)srow * p.k_sr + ((spc ^ (srow & 15)) << 3);
+  const T* const vbase = Vg + (int64_t)srow * p.v_sr + ((spc ^ ((srow & 7) << 1)) << 3);
+  auto issue_tile = [&](int t, int buf) {
     char* const Kw = smem + buf * BUF;
     char* const Vw = Kw + KV_TILE * 256;
+    if ((t + 1) * KV_TILE <= kv_len) {                                      // full tile (uniform): scalar row offsets
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int idx = (i0 + i) * NT + tid, row = idx >> 4, ch = idx & 15;
-      *reinterpret_cast<frag_t*>(Kw + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
-      *reinterpret_cast<frag_t*>(Vw + row * 256 + ((ch ^ ((row & 7) << 1)) << 4)) = vreg[i];
-    }
-  };
-  auto load_tile = [&](int t) { if constexpr (!DECODE) load_part(t, 0); };
-  auto write_tile = [&](int t, int buf) {
-    if constexpr (DECODE) {
+      for (int i = 0; i < CH; ++i) {
+        const int64_t r0 = t * KV_TILE + i * RPI;
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + r0 * p.k_sr), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + r0 * p.v_sr), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    } else {                                                                // ragged last tile: clamp the row per lane
 #pragma unroll
-      for (int i0 = 0; i0 < CH; i0 += PF) { load_part(t, i0); write_part(i0, buf); }
-    } else {
-      write_part(0, buf);
+      for (int i = 0; i < CH; ++i) {
+        int kr = t * KV_TILE + i * RPI + srow; kr = (kr < kv_len ? kr : kv_len - 1) - srow;     // masked keys must stay finite
+        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (int64_t)kr * p.k_sr), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (int64_t)kr * p.v_sr), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
     }
   };
 
@@ -210,19 +189,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   const int vrow_lo = 4 * fg + tq;                       // (+32*ks, +16 for the second read)
   const int vswz = ((vrow_lo & 7) << 1);                 // rows +16 / +32 keep (row & 7)
 
-  // tile t lives in buffer (t - t_begin) & 1.  Iteration t: S^T and softmax from buffer cur, then the registers holding tile
-  // t+1 go to the other buffer (last read in iteration t-1, a barrier ago) and the global loads of tile t+2 are issued,
-  // then PV from buffer cur, then ONE barrier.
-  if (t_begin < t_end) {
-    load_tile(t_begin);
-    write_tile(t_begin, 0);
-    if (t_begin + 1 < t_end) load_tile(t_begin + 1);
-  }
-  __syncthreads();
-  for (int t = t_begin; t < t_end; ++t) {
-    const int cur = DECODE ? 0 : ((t - t_begin) & 1);
+  // tile t lives in buffer t & 1.  Iteration t: wait for own DMA of tile t, barrier (tile t visible to everyone, buffer
+  // (t+1)&1 no longer read by anyone), issue tile t+1, then S^T, softmax and PV from buffer t & 1.
+  if (t_end > 0) issue_tile(0, 0);
+  for (int t = 0; t < t_end; ++t) {
+    const int cur = t & 1;
     const char* const Ks = smem + cur * BUF;
     const char* const Vs = Ks + KV_TILE * 256;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);
 
     // ---- S^T = K Q^T
     f32x4 s[NQ][4];
@@ -242,55 +218,62 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     // ---- mask + online softmax (per lane = per query column).  exp2((s - m) * c) = exp2(s * c - m * c).
     const int key0 = t * KV_TILE + 4 * fg;
     // masking is needed only on the last kv tile (ragged tail) and on tiles that reach the causal diagonal of this block
-    bool need_mask = (t + 1) * KV_TILE > kv_len;
-    if constexpr (!DECODE) need_mask = need_mask || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1);
+    const bool need_mask = (t + 1) * KV_TILE > kv_len || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1);
     frag_t pf[NQ][2];
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) {
       if (need_mask) {
         int lim = kv_len;                                   // keys < lim are visible
-        if constexpr (!DECODE) {
-          if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
-        }
+        if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
+        const int rel = lim - key0;                         // register r of key tile kt is key key0 + 16*kt + r
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[qt][kt][r] = key0 + kt * 16 + r < lim ? s[qt][kt][r] : NEG_BIG;
+          for (int r = 0; r < 4; ++r) s[qt][kt][r] = kt * 16 + r < rel ? s[qt][kt][r] : NEG_BIG;
       }
-      float mx = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3]));
-#pragma unroll
-      for (int kt = 1; kt < 4; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[qt][kt][0], s[qt][kt][1]), fmaxf(s[qt][kt][2], s[qt][kt][3])));
-      mx = max_xor32(max_xor16(mx));
-      // rescale only when some query of the wave really raised its max (exact: alpha == 1 otherwise)
-      if (__any(mx > m_run[qt])) {
-        const float m_new = fmaxf(m_run[qt], mx);
+      // VALU is the bound of this kernel (MFMA and VALU issue do not overlap on a SIMD: tools/tune_pipes.hip), so the
+      // softmax is written for instruction count: v_max3 chain, v_pk_fma / v_pk_add on register pairs
+      float mx = max3(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
+      mx = max3(mx, s[qt][0][3], s[qt][1][0]);
+      mx = max3(mx, s[qt][1][1], s[qt][1][2]);
+      mx = max3(mx, s[qt][1][3], s[qt][2][0]);
+      mx = max3(mx, s[qt][2][1], s[qt][2][2]);
+      mx = max3(mx, s[qt][2][3], s[qt][3][0]);
+      mx = max3(mx, s[qt][3][1], s[qt][3][2]);
+      mx = max2(mx, s[qt][3][3]);
+      mx = max_xor32_raw(max_xor16_raw(mx));
+      // lazy rescale: the reference point m_run only has to keep exp2() in range, not to be the exact running max, so it
+      // moves only when some query of the wave exceeds it by more than 2^RESCALE_LOG2 (p <= 2^8: exact in fp32 sums,
+      // same relative rounding in the 16-bit P operand); the final O / l is the same quantity either way
+      if (__any((mx - m_run[qt]) * p.c > RESCALE_LOG2)) {
+        const float m_new = max2(m_run[qt], mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.c);
         m_run[qt] = m_new;
         l_run[qt] *= alpha;
 #pragma unroll
         for (int dn = 0; dn < 8; ++dn) o[qt][dn] *= alpha;
       }
-      const float mc = m_run[qt] * p.c;
-      float psum = 0.f;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float nmc = -m_run[qt] * p.c;
+      const f32x2 c2 = {p.c, p.c}, nmc2 = {nmc, nmc};
+      f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         typedef float f32x8 __attribute__((ext_vector_type(8)));
         f32x8 e;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          e[j] = __builtin_amdgcn_exp2f(fmaf(s[qt][2 * ks + (j >> 2)][j & 3], p.c, -mc));
-          psum += e[j];
+        for (int h = 0; h < 4; ++h) {
+          const f32x4 sv = s[qt][2 * ks + (h >> 1)];
+          const f32x2 x = (h & 1) ? __builtin_shufflevector(sv, sv, 2, 3) : __builtin_shufflevector(sv, sv, 0, 1);
+          const f32x2 y = __builtin_elementwise_fma(x, c2, nmc2);
+          f32x2 ex;
+          ex[0] = __builtin_amdgcn_exp2f(y[0]); ex[1] = __builtin_amdgcn_exp2f(y[1]);
+          psum2 += ex;
+          e[2 * h] = ex[0]; e[2 * h + 1] = ex[1];
         }
         pf[qt][ks] = __builtin_convertvector(e, frag_t);     // packed f32 -> 16-bit converts
       }
-      l_run[qt] += psum;
-    }
-
-    if constexpr (!DECODE) {
-      if (t + 1 < t_end) {
-        write_tile(t + 1, cur ^ 1);
-        if (t + 2 < t_end) load_tile(t + 2);
-      }
+      l_run[qt] += psum2[0] + psum2[1];
     }
 
     // ---- O^T += V^T P^T
@@ -308,35 +291,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int qt = 0; qt < NQ; ++qt) o[qt][dn] = mfma16(vf, pf[qt][ks], o[qt][dn]);
       }
-    __syncthreads();       // tile t fully consumed, tile t+1 fully written
   }
 
   // ---- finalize.  o[qt][dn][r] = O^T[d = 16*dn + 4*fg + r][query fc]
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
     const float l = sum_xor32(sum_xor16(l_run[qt]));
-    if constexpr (DECODE) {
-      if (fc < n_rep) {
-        float* w = p.ws + ((size_t)(b * p.q_heads + hq0 + fc) * p.nsplit + split) * WS_STRIDE;
+    if (qrow[qt] < p.Sq) {
+      const float inv = 1.f / l;
+      T* op = (T*)p.O + b * p.o_sb + hq0 * p.o_sh + qrow[qt] * p.o_sr + fg * 4;
 #pragma unroll
-        for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(w + dn * 16 + fg * 4) = o[qt][dn];
-        if (fg == 0) { w[128] = m_run[qt]; w[129] = l; }
-      }
-    } else {
-      if (qrow[qt] < p.Sq) {
-        const float inv = 1.f / l;
-        T* op = (T*)p.O + b * p.o_sb + hq0 * p.o_sh + qrow[qt] * p.o_sr + fg * 4;
+      for (int dn = 0; dn < 8; ++dn) {
+        typename V8<T>::half_type h4;
 #pragma unroll
-        for (int dn = 0; dn < 8; ++dn) {
-          typename V8<T>::half_type h4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h4[r] = fromf<T>(o[qt][dn][r] * inv);
-          *reinterpret_cast<typename V8<T>::half_type*>(op + dn * 16) = h4;
-        }
+        for (int r = 0; r < 4; ++r) h4[r] = fromf<T>(o[qt][dn][r] * inv);
+        *reinterpret_cast<typename V8<T>::half_type*>(op + dn * 16) = h4;
       }
     }
   }
 }
+
 
 // ---------------------------------------------------------------------------------------------------------
 // Decode attention, one wave per (64-key split, kv head, sequence).  Same transposed MFMA formulation as the prefill kernel
@@ -553,8 +527,8 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
           a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
           nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
-  if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, false>), grid, dim3(256), 0, s, p);
-  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, false>), grid, dim3(256), 0, s, p);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2>), grid, dim3(256), 0, s, p);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2>), grid, dim3(256), 0, s, p);
   else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;
