@@ -16,6 +16,7 @@ HIP events recorded on the launch stream inside the timed region, and a CPU base
 """
 import argparse
 import json
+import numpy as np
 import os
 import sys
 import time
@@ -255,8 +256,30 @@ def main():
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
     }
+    # image front-end (row f-1), outside the timed region: raw RGB bytes on the host -> normalised tiles in HBM
+    pins = [(448, 896), (896, 448), (896, 896), (1344, 448), (448, 1344), (1344, 1344)]
+    rgb = np.random.default_rng(0).integers(0, 256, (380, 570, 3), dtype=np.uint8)       # size of the reference's sample picture -> 3 tiles
+    from omchat_amd.image_processing import HipImageProcessor
+    proc = HipImageProcessor(crop_size=cfg.vision["image_size"])
+    fe = []
+    for _ in range(12):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        proc.process_anyres(rgb, pins, dtype=eng.torch_dtype)
+        torch.cuda.synchronize(); fe.append((time.perf_counter() - t0) * 1e3)
+    res["frontend_ms_p50"] = sorted(fe[2:])[len(fe[2:]) // 2]
     if not a.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N = 1 only
         res["cpu_baseline"] = cpu_baseline(cfg, S, a.gen, n_tiles)
+        from PIL import Image
+        from transformers import CLIPImageProcessor
+        from omchat_amd.mm_utils import process_anyres_image
+        cp = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
+                                image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)
+        img = Image.fromarray(rgb)
+        process_anyres_image(img, cp, pins)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            process_anyres_image(img, cp, pins)
+        res["cpu_baseline"]["frontend_ms"] = (time.perf_counter() - t0) / 3 * 1e3
     print(json.dumps(res))
 
 

@@ -22,7 +22,7 @@ extern "C" {
 
 #define OMCHAT_F16 0
 #define OMCHAT_BF16 1
-#define OMCHAT_F32 2            /* accepted as a SOURCE dtype by omchat_load_tensor only */
+#define OMCHAT_F32 2            /* accepted as a SOURCE dtype by omchat_load_tensor and as an output dtype of omchat_preproc_anyres */
 #define OMCHAT_PAD_ROW INT32_MIN /* splice index: zero row */
 
 typedef struct omchat_ctx omchat_ctx;
@@ -150,6 +150,22 @@ int omchat_op_rope_kv(int dtype, void* qkv, int b, int S, int Hq, int Hkv, int p
                       int cap, void* stream);
 int omchat_op_argmax(const float* logits, int b, int V, int32_t* out, void* stream);
 int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, void* stream);
+
+/* ---- image front-end: process_anyres_image (omchat/mm_utils.py:119-158) + CLIPImageProcessor ---- */
+/* (internVIT_encoder.py:25-29) on the device, bit-identical to the reference's PIL/numpy result.
+ * plan (host only): select_best_resolution (mm_utils.py:12-39) over `pinpoints` [n_pin][2] = (w, h); n_tiles = 1 thumbnail
+ * + the tiles of the best resolution.  anyres: `rgb` uint8 [H][W][3] (host, or device when rgb_on_device) ->
+ * pixels_out device [n_tiles][3][tile][tile] in `dtype` (OMCHAT_F16 / BF16 / F32): tile 0 = Image.resize((tile, tile)),
+ * then the row-major tiles of resize_and_pad_image (mm_utils.py:42-74); every value = (u/255 - mean)/std with
+ * transformers' rounding order.  Blocks until the staging copies are done (the kernels stay ordered on `stream`). */
+int omchat_preproc_plan(int W, int H, const int* pinpoints, int n_pin, int tile, int* best_w, int* best_h, int* n_tiles);
+int omchat_preproc_anyres(int dtype, const void* rgb, int rgb_on_device, int W, int H, int best_w, int best_h, int tile,
+                          const float mean[3], const float std_[3], void* pixels_out, void* stream);
+/* host-only pieces exposed for the CPU parity tests: Pillow's fixed-point resampling taps (Resample.c precompute_coeffs +
+ * normalize_coeffs_8bpc, BICUBIC): bounds [out][2] = (first source index, taps), kk [out][*ksize]; and the 3 x 256
+ * rescale+normalize table */
+int omchat_resample_coeffs(int in_size, int out_size, int* ksize, int* bounds, int* kk, int kk_cap);
+int omchat_normalize_lut(const float mean[3], const float std_[3], float lut[768]);
 
 /* ---- tensor-parallel bootstrap (RCCL over xGMI; one process per GPU) -------------------------------------------- */
 int omchat_comm_unique_id(char id[128]);

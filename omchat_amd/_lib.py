@@ -64,6 +64,10 @@ _SIGS = {
     "omchat_op_rope_kv": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "omchat_op_argmax": (_i, [_vp, _i, _i, _vp, _vp]),
     "omchat_op_fill_uniform": (_i, [_i, _vp, _i64, _u64, _f, _f, _vp]),
+    "omchat_preproc_plan": (_i, [_i, _i, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "omchat_preproc_anyres": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "omchat_resample_coeffs": (_i, [_i, _i, C.POINTER(_i), _vp, _vp, _i]),
+    "omchat_normalize_lut": (_i, [_vp, _vp, _vp]),
     "omchat_comm_unique_id": (_i, [C.c_char_p]),
     "omchat_comm_init": (_i, [C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "omchat_comm_destroy": (None, [_vp]),

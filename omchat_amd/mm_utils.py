@@ -53,6 +53,10 @@ def anyres_tile_count(image_size, grid_pinpoints, tile=448):
 def process_anyres_image(image, processor, grid_pinpoints, return_type_list=False, return_best_res=False):
     """mm_utils.py:119-158: [thumbnail] + tiles of the resized/padded canvas, each through `processor.preprocess`."""
     import torch
+    if hasattr(processor, "process_anyres"):            # device front-end (image_processing.HipImageProcessor): same tiles, on the GPU
+        out, best = processor.process_anyres(image, grid_pinpoints, return_best_res=True)
+        out = list(out) if return_type_list else out
+        return (out, best) if return_best_res else out
     best = select_best_resolution(image.size, grid_pinpoints)
     padded = resize_and_pad_image(image, best)
     edge = processor.crop_size["height"] if hasattr(processor, "crop_size") else processor.size["height"]

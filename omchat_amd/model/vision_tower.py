@@ -18,10 +18,11 @@ class InternVITVisionTower:
             self.load_model()
 
     def load_model(self, is_train=False):
-        from transformers import CLIPImageProcessor
+        from ..image_processing import HipImageProcessor
         crop = 448 if "448" in self.vision_tower_name else 336
-        self.image_processor = CLIPImageProcessor(crop_size=crop, do_center_crop=True, do_normalize=True, do_resize=True,
-                                                  image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=crop)
+        # same parameters as the reference's CLIPImageProcessor (:25-29); the arithmetic runs in csrc/preproc.hip
+        self.image_processor = HipImageProcessor(crop_size=crop, image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225],
+                                                 device=self.engine.device if self.engine is not None else None)
         self.is_loaded = True
 
     def feature_select(self, hidden_state):

@@ -1,0 +1,88 @@
+"""Image front-end on the device (csrc/preproc.hip) against the oracle (itself pinned to Pillow + transformers in
+tests/test_preproc_cpu.py): byte work -> bit-exact, including the dtype cast."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import preproc as opp
+
+pytestmark = pytest.mark.gpu
+PINS = [(448, 896), (896, 448), (896, 896), (1344, 448), (448, 1344), (1344, 1344)]
+
+
+def _proc():
+    from omchat_amd.image_processing import HipImageProcessor
+    return HipImageProcessor(crop_size=448)
+
+
+@pytest.mark.parametrize("w,h", [(570, 380), (333, 999), (448, 448), (61, 97), (3000, 2000), (1344, 1344), (449, 447), (2000, 90)])
+def test_anyres_matches_oracle_bit_exact(w, h):
+    a = np.random.default_rng(w * 5 + h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    proc = _proc()
+    out, best = proc.process_anyres(a, PINS, return_best_res=True)
+    ref = opp.anyres_tiles(a, best)
+    assert out.dtype == torch.float32 and tuple(out.shape) == ref.shape
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_anyres_dtypes_and_device_input():
+    a = np.random.default_rng(11).integers(0, 256, (380, 570, 3), dtype=np.uint8)
+    proc = _proc()
+    f32 = proc.process_anyres(a, PINS)
+    for dt in (torch.float16, torch.bfloat16):
+        got = proc.process_anyres(a, PINS, dtype=dt)
+        assert got.dtype == dt and torch.equal(got, f32.to(dt))               # fused cast == the reference's .half() / .to(bf16)
+    dev = proc.process_anyres(torch.from_numpy(a).cuda(), PINS)
+    assert torch.equal(dev, f32)
+    from PIL import Image
+    assert torch.equal(proc.process_anyres(Image.fromarray(a), PINS), f32)
+
+
+def test_extreme_images():
+    proc = _proc()
+    for a in (np.zeros((100, 300, 3), np.uint8), np.full((700, 200, 3), 255, np.uint8),
+              np.tile(np.array([[0, 255]], np.uint8).repeat(3).reshape(1, 2, 3), (64, 256, 1))):
+        out, best = proc.process_anyres(a, PINS, return_best_res=True)
+        assert np.array_equal(out.cpu().numpy(), opp.anyres_tiles(np.ascontiguousarray(a), best))
+
+
+def test_preprocess_tile_and_errors():
+    proc = _proc()
+    a = np.random.default_rng(5).integers(0, 256, (448, 448, 3), dtype=np.uint8)
+    pv = proc.preprocess(a, return_tensors="pt")["pixel_values"]
+    lut = opp.normalize_lut()
+    ref = np.stack([lut[c][a[:, :, c]] for c in range(3)])
+    assert tuple(pv.shape) == (1, 3, 448, 448) and np.array_equal(pv[0].cpu().numpy(), ref)
+    with pytest.raises(NotImplementedError):
+        proc.preprocess(np.zeros((10, 10, 3), np.uint8))
+    with pytest.raises(ValueError):
+        proc.process_anyres(np.zeros((10, 10), np.uint8), PINS)
+
+
+def test_mm_utils_and_get_context_use_the_device_front_end():
+    """process_anyres_image / get_context call sites (mm_utils.py:119-158, make_context.py:14-43) with the device processor"""
+    from PIL import Image
+    from omchat_amd.mm_utils import process_anyres_image
+    from omchat_amd.make_context import get_context
+    a = np.random.default_rng(2).integers(0, 256, (380, 570, 3), dtype=np.uint8)
+    img = Image.fromarray(a)
+    proc = _proc()
+    tiles, best = process_anyres_image(img, proc, PINS, True, return_best_res=True)
+    ref = opp.anyres_tiles(a, best)
+    assert best == (896, 448) and len(tiles) == 3 and all(t.is_cuda for t in tiles)
+    assert np.array_equal(torch.stack(tiles).cpu().numpy(), ref)
+
+    import types
+
+    class _Tok:
+        bos_token_id = None
+        pad_token_id = 0
+
+        def __call__(self, s):
+            return types.SimpleNamespace(input_ids=[1000 + ord(ch) for ch in s])
+
+        def encode(self, s):
+            return [1000 + ord(ch) for ch in s]
+    _, ids, image_tensor = get_context("hi", _Tok(), image=img, image_processor=proc, image_grid_pinpoints=PINS)
+    assert ids.count(-200) == 3 and image_tensor.dtype == torch.float16 and image_tensor.is_cuda and tuple(image_tensor.shape) == (3, 3, 448, 448)
+    assert torch.equal(image_tensor.cpu(), torch.from_numpy(ref).half())      # make_context.py:25 `.half()`

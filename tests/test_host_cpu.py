@@ -132,12 +132,13 @@ def test_anyres_tiles_for_reference_sample_image():
     """tile count/order/shape for a 570x380 picture (the size of the reference's images/extreme_ironing.jpg)"""
     from PIL import Image
     from omchat_amd.mm_utils import process_anyres_image
-    from omchat_amd.model.vision_tower import InternVITVisionTower
-    tw = InternVITVisionTower("internvit-6b-448px", types.SimpleNamespace(mm_vision_select_layer=-1))
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
+                              image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)      # internVIT_encoder.py:25-29
     rng = np.random.default_rng(0)
     img = Image.fromarray(rng.integers(0, 255, (380, 570, 3), dtype=np.uint8))
     pin = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
-    tiles, best = process_anyres_image(img, tw.image_processor, pin, True, return_best_res=True)
+    tiles, best = process_anyres_image(img, proc, pin, True, return_best_res=True)
     assert best == (896, 448) and len(tiles) == 3 and all(t.shape == (3, 448, 448) for t in tiles)
 
 

@@ -1,0 +1,84 @@
+"""Image front-end, CPU side: the numpy restatement of Pillow's 8-bit BICUBIC resampler is pinned
+against Pillow itself (the reference's dependency; Image.resize is what omchat/mm_utils.py:42-74,144 call), and the
+host pieces of libomchat_hip.so (fixed-point taps, normalisation table, resolution plan) are compared with it.  No GPU."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from oracle import preproc as opp
+from omchat_amd import _lib
+from omchat_amd.mm_utils import select_best_resolution, process_anyres_image
+
+PINS = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
+SIZES = [(300, 500, 448, 448), (1000, 1500, 448, 896), (448, 448, 448, 448), (97, 61, 448, 448), (1344, 700, 231, 448),
+         (500, 300, 600, 301), (448, 900, 448, 448), (2, 3, 5, 7)]
+
+
+@pytest.mark.parametrize("h,w,oh,ow", SIZES)
+def test_oracle_resize_is_pillow(h, w, oh, ow):
+    from PIL import Image
+    a = np.random.default_rng(h * 7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    assert np.array_equal(opp.resize_bicubic(a, ow, oh), np.asarray(Image.fromarray(a).resize((ow, oh))))
+
+
+def test_oracle_resize_extremes_are_pillow():
+    from PIL import Image
+    for a in (np.zeros((40, 30, 3), np.uint8), np.full((40, 30, 3), 255, np.uint8),
+              np.tile(np.array([[0, 255]], np.uint8).repeat(3).reshape(1, 2, 3), (33, 17, 1))):      # overshoot -> clip8
+        assert np.array_equal(opp.resize_bicubic(a, 77, 19), np.asarray(Image.fromarray(a).resize((77, 19))))
+
+
+@pytest.mark.parametrize("n_in,n_out", [(500, 448), (61, 448), (1500, 896), (448, 448), (3000, 448), (7, 3), (3, 7)])
+def test_library_taps_match_oracle(n_in, n_out):
+    lib = _lib.lib()
+    ks, bounds, kk = opp.precompute_coeffs(n_in, n_out)
+    k = C.c_int(0)
+    b = np.zeros((n_out, 2), np.int32)
+    t = np.zeros((n_out, ks), np.int32)
+    _lib.check(lib.omchat_resample_coeffs(n_in, n_out, C.byref(k), b.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), t.size))
+    assert k.value == ks and np.array_equal(b, bounds) and np.array_equal(t, kk)
+    with pytest.raises(ValueError):
+        _lib.check(lib.omchat_resample_coeffs(n_in, n_out, C.byref(k), None, t.ctypes.data_as(C.c_void_p), 1))
+
+
+def test_normalize_table_matches_transformers():
+    from transformers import CLIPImageProcessor
+    lib = _lib.lib()
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    lut = np.zeros((3, 256), np.float32)
+    _lib.check(lib.omchat_normalize_lut((C.c_float * 3)(*mean), (C.c_float * 3)(*std), lut.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(lut, opp.normalize_lut(mean, std))
+    # the reference's processor (internVIT_encoder.py:25-29) on an image holding every byte value in every channel
+    proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True, image_mean=mean, image_std=std, size=448)
+    img = np.zeros((448, 448, 3), np.uint8)
+    img[:256, 0, :] = np.arange(256, dtype=np.uint8)[:, None]
+    from PIL import Image
+    pv = proc.preprocess(Image.fromarray(img), return_tensors="np")["pixel_values"][0]
+    assert np.array_equal(pv[:, :256, 0], lut)
+
+
+def test_plan_matches_select_best_resolution():
+    lib = _lib.lib()
+    pins = np.asarray(PINS, np.int32)
+    rng = np.random.default_rng(3)
+    sizes = [(448, 448), (570, 380), (1000, 667), (1344, 448), (1, 1), (5000, 300), (300, 5000)] + [tuple(int(x) for x in rng.integers(1, 4000, 2)) for _ in range(200)]
+    for w, h in sizes:
+        bw, bh, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(lib.omchat_preproc_plan(w, h, pins.ctypes.data_as(C.c_void_p), len(pins), 448, C.byref(bw), C.byref(bh), C.byref(n)))
+        best = select_best_resolution((w, h), [tuple(p) for p in PINS])
+        assert (bw.value, bh.value) == tuple(best) and n.value == 1 + (best[0] // 448) * (best[1] // 448), (w, h)
+    with pytest.raises(ValueError):
+        _lib.check(lib.omchat_preproc_plan(10, 10, np.asarray([[100, 100]], np.int32).ctypes.data_as(C.c_void_p), 1, 448, C.byref(bw), C.byref(bh), C.byref(n)))
+
+
+@pytest.mark.parametrize("w,h", [(570, 380), (333, 999), (448, 448)])
+def test_oracle_anyres_is_the_reference_pipeline(w, h):
+    """oracle.anyres_tiles == process_anyres_image with the reference's CLIPImageProcessor (PIL resize / paste / crop + transformers)"""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
+                              image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)
+    a = np.random.default_rng(w + h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    tiles, best = process_anyres_image(Image.fromarray(a), proc, [tuple(p) for p in PINS], return_best_res=True)
+    got = opp.anyres_tiles(a, best)
+    assert got.shape == tuple(tiles.shape) and np.array_equal(got, tiles.numpy())
