@@ -31,6 +31,7 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-fp8", action="store_true", help="skip the (untimed) weight-only fp8 decode measurement")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gen", type=int, default=256, help="greedy decode tokens per step")
@@ -256,6 +257,27 @@ def main():
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
     }
+    # weight-only fp8 decode (row f-2 / configs[4]), outside the timed region: same prompt, 64 greedy tokens on the e4m3 replica
+    if world == 1 and not a.no_fp8:
+        eng.enable_fp8_decode(True)
+        n8 = min(64, a.gen)
+        t8 = []
+        for _ in range(2):
+            feats = eng.encode_images(px)
+            embeds, lengths, _ = eng.splice(ids, None, feats)
+            logits, _ = eng.prefill(embeds, lengths)
+            tok = eng.argmax(logits)
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(n8):
+                tok, _ = eng.decode_step(tok)
+            e1.record(); torch.cuda.synchronize()
+            t8.append(e0.elapsed_time(e1) / n8)
+        eng.enable_fp8_decode(False)
+        res["fp8_decode"] = {"decode_ms_per_token": min(t8), "decode_tokens_per_sec": 1e3 / min(t8),
+                             "hbm_frac": ((14.14e9 / 2 + 57344.0 * S) / (min(t8) / 1e3) / 1e9 / HBM_PEAK_GBS) if not a.tiny else None,
+                             "note": "decoder GEMV weights as OCP e4m3 + per-row fp32 scale (7.07 GB/step instead of 14.14); "
+                                     "prefill, KV cache and activations stay 16-bit; NOT part of `value`"}
     # image front-end (row f-1), outside the timed region: raw RGB bytes on the host -> normalised tiles in HBM
     pins = [(448, 896), (896, 448), (896, 896), (1344, 448), (448, 1344), (1344, 1344)]
     rgb = np.random.default_rng(0).integers(0, 256, (380, 570, 3), dtype=np.uint8)       # size of the reference's sample picture -> 3 tiles

@@ -109,6 +109,14 @@ int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, vo
 int omchat_greedy(omchat_ctx* ctx, const float* logits, int b, int32_t* next_tokens, void* stream);
 int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
 
+/* ---- weight-only fp8 for decode (BASELINE configs[4]) -------------------------------------------- */
+/* Builds (once) an OCP e4m3 replica of the decoder weights that a decode step streams (fused qkv, o, gate|up, down,
+ * lm_head): per output row scale = absmax / 448, W8 = e4m3_rne(W / scale).  With on != 0, batch-1 decode steps on a
+ * TP = 1 context read these bytes (half the HBM traffic of the 16-bit weights) and apply the scale after the fp32
+ * row reduction; prefill and b > 1 steps keep the 16-bit weights.  Not part of the reference (it has no quantised
+ * path): parity is against the oracle run on the de-quantised weights. */
+int omchat_enable_fp8_decode(omchat_ctx* ctx, int on);
+
 /* ---- measurement: HIP-event timing of the dominant kernel classes, recorded on the launch stream ------------------ */
 #define OMCHAT_PROF_DECODE_GATEUP 0   /* decode gate|up weight-streaming GEMV (+SwiGLU), one launch per layer per token */
 #define OMCHAT_PROF_PREFILL_GATEUP 1  /* decoder prefill gate|up MFMA GEMM (+SwiGLU), one launch per layer */
@@ -135,6 +143,11 @@ int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw,
                       size_t ws_bytes, int stream_k, void* stream);
 int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
                    const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream);
+/* fp8 pieces: W [N][K] (dtype) -> W8 [N][K] e4m3 bytes + scale [N]; y[N] = (W8 . x) * scale (+ epilogue), batch 1;
+ * epi EPI_PARTIAL writes fp32 slices [ksplit][N] */
+int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float* scale, void* stream);
+int omchat_op_gemv_fp8(int dtype, const void* X, const void* W8, const float* scale, void* Y, int N, int K, const void* bias,
+                       const void* resid, int epi, int out_f32, int ksplit, void* stream);
 int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream);
 int omchat_op_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total,
                          float eps, float q_scale, void* stream);

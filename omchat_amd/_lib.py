@@ -56,6 +56,9 @@ _SIGS = {
     "omchat_op_gemm_sk_ws": (_sz, []),
     "omchat_op_gemm_sk": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
     "omchat_op_gemv": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "omchat_enable_fp8_decode": (_i, [_vp, _i]),
+    "omchat_op_quant_fp8": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
+    "omchat_op_gemv_fp8": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_rmsnorm": (_i, [_i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "omchat_op_vit_qknorm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "omchat_op_attn_prefill": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp]),

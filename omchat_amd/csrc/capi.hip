@@ -116,3 +116,14 @@ extern "C" int omchat_mha_fwd(const void* qkv, int B, int Sq, int H, float softm
   a.scale = softmax_scale > 0.f ? softmax_scale : 0.08838834764831845f;
   return launch_attn_prefill(dtype, a, S(stream));
 }
+
+extern "C" int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float* scale, void* stream) {
+  return launch_quant_fp8_rows(dtype, W, K, N, K, W8, K, scale, S(stream));
+}
+
+extern "C" int omchat_op_gemv_fp8(int dtype, const void* X, const void* W8, const float* scale, void* Y, int N, int K, const void* bias,
+                                  const void* resid, int epi, int out_f32, int ksplit, void* stream) {
+  OM_CHECK(scale, "scale missing");
+  GemvArgs g{X, K, W8, K, Y, N, 1, N, K, bias, resid, N, epi, out_f32, ksplit, 0, scale};
+  return launch_gemv(dtype, g, S(stream));
+}

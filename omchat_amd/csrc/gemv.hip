@@ -16,6 +16,7 @@ namespace {
 struct GemvP {
   const void* X; const void* W; void* Y; const void* bias; const void* resid;
   int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
+  const float* w_scale;
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL>
@@ -187,6 +188,62 @@ template <> __device__ __forceinline__ float rw_dot8<f16>(rw_u32x4 w, rw_u32x4 x
   return acc;
 }
 
+// weight-only fp8 (OCP e4m3): 8 weights of a lane = 8 bytes.  gfx950's v_cvt_scalef32_pk_{bf16,f16}_fp8 widens two e4m3
+// values to a packed 16-bit pair in one instruction (exact: 3 mantissa bits), which then feeds the same v_dot2 as the
+// 16-bit kernel with x still packed in registers: 4 converts + 4 dot2 per 8 weights.
+typedef unsigned int rw_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ float rw_dot8_fp8(rw_u32x2 w, rw_u32x4 x, float acc);
+template <> __device__ __forceinline__ float rw_dot8_fp8<bf16>(rw_u32x2 w, rw_u32x4 x, float acc) {
+  typedef bf16 v2 __attribute__((ext_vector_type(2)));
+  const unsigned w0 = w.x, w1 = w.y, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false), __builtin_bit_cast(v2, x0), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, true), __builtin_bit_cast(v2, x1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, false), __builtin_bit_cast(v2, x2), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, true), __builtin_bit_cast(v2, x3), acc, false);
+  return acc;
+}
+template <> __device__ __forceinline__ float rw_dot8_fp8<f16>(rw_u32x2 w, rw_u32x4 x, float acc) {
+  typedef f16 v2 __attribute__((ext_vector_type(2)));
+  const unsigned w0 = w.x, w1 = w.y, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
+  acc = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false), __builtin_bit_cast(v2, x0), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true), __builtin_bit_cast(v2, x1), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false), __builtin_bit_cast(v2, x2), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true), __builtin_bit_cast(v2, x3), acc, false);
+  return acc;
+}
+
+template <typename T, int R, int NCH>
+__device__ __forceinline__ void rw_rows_fp8(const unsigned char* W, int ldw, const int (&rows)[R], int k0, int K, int lane, const rw_u32x4 (&xr)[RW_MAXC],
+                                            const float* scale, float (&acc)[R]) {
+  rw_u32x2 w[R][NCH];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int k = k0 + c * 512 + lane * 8;
+      k = k < K ? k : k0;
+      w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>(W + (size_t)rows[r] * ldw + k));
+    }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a = rw_dot8_fp8<T>(w[r][c], xr[c], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    acc[r] = a * scale[rows[r]];
+  }
+}
+
+template <typename T, int R, int N>
+__device__ __forceinline__ void rw_dispatch_fp8(int nch, const unsigned char* W, int ldw, const int (&rows)[R], int k0, int K, int lane,
+                                                const rw_u32x4 (&xr)[RW_MAXC], const float* scale, float (&acc)[R]) {
+  if constexpr (N > 0) {
+    if (nch == N) rw_rows_fp8<T, R, N>(W, ldw, rows, k0, K, lane, xr, scale, acc);
+    else rw_dispatch_fp8<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, scale, acc);
+  }
+}
+
 // rows r0 .. r0+R-1 (already mapped to weight-row indices by the caller) over NCH chunks starting at element k0
 template <typename T, int R, int NCH>
 __device__ __forceinline__ void rw_rows(const T* W, int ldw, const int (&rows)[R], int k0, int K, int lane, const rw_u32x4 (&xr)[RW_MAXC],
@@ -220,7 +277,7 @@ __device__ __forceinline__ void rw_dispatch(int nch, const T* W, int ldw, const 
   }
 }
 
-template <typename T, int EPI, int RR = 4, int WAVES = 4>
+template <typename T, int EPI, int RR = 4, int WAVES = 4, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   constexpr int R = EPI == EPI_SWIGLU ? 2 * RR : RR;      // SwiGLU: RR (gate, up) row pairs per group
   constexpr int OUT = RR;                                 // outputs per group
@@ -252,7 +309,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
       }
     }
     float acc[R];
-    rw_dispatch<T, R, RW_MAXC>(nch, W, p.ldw, rows, k0, p.K, lane, xr, acc);
+    if constexpr (F8) rw_dispatch_fp8<T, R, RW_MAXC>(nch, (const unsigned char*)p.W, p.ldw, rows, k0, p.K, lane, xr, p.w_scale, acc);
+    else rw_dispatch<T, R, RW_MAXC>(nch, W, p.ldw, rows, k0, p.K, lane, xr, acc);
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < OUT; ++r) {
@@ -277,19 +335,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   }
 }
 
-template <typename T, int EPI, int RR>
+template <typename T, int EPI, int RR, bool F8>
 void launch_rows_r(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   int grid = cdiv(cdiv(n_out, RR), 4);
   grid = grid > 2048 ? 2048 : grid;
-  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
 }
 // rows per wave-group from tools/tune_rows.hip (MI355X, r01): short outputs (fused qkv) are latency-bound and want the most
-// waves (R = 1: 7.8 vs 8.8 us), everything else is flat in R; 4 waves per workgroup beat 8
+// waves (R = 1: 7.8 vs 8.8 us), everything else is flat in R; 4 waves per workgroup beat 8.  fp8 rows are half as many
+// bytes: the wide lm_head takes 8 rows per group, the split-K shapes measured flat (o_proj slightly worse) and keep 4.
 template <typename T, int EPI>
 void launch_rows(const GemvP& p, hipStream_t s) {
-  if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1>(p, s);
-  else launch_rows_r<T, EPI, 4>(p, s);
+  if (p.w_scale) {
+    if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1, true>(p, s);
+    else if (EPI == EPI_NONE) launch_rows_r<T, EPI, 8, true>(p, s);      // lm_head: 80.7 vs 82.3 us
+    else launch_rows_r<T, EPI, 4, true>(p, s);
+    return;
+  }
+  if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1, false>(p, s);
+  else launch_rows_r<T, EPI, 4, false>(p, s);
 }
 
 // Launch shapes measured with tools/tune_gemv.hip on MI355X (r01): plain loads beat non-temporal ones for this access
@@ -297,8 +362,10 @@ void launch_rows(const GemvP& p, hipStream_t s) {
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks};
-  if (a.b == 1 && !a.force_mfma && !g_gemv_force_mfma && cdiv(cdiv(a.K, 512), ks) <= RW_MAXC) {       // whole-row streaming form
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale};
+  const bool rows_ok = a.b == 1 && cdiv(cdiv(a.K, 512), ks) <= RW_MAXC;
+  if (a.w_scale && !rows_ok) { omchat_set_error("launch_gemv: fp8 weights need b == 1 and <= 8 chunks of 512 per K slice"); return 1; }
+  if (rows_ok && (a.w_scale || (!a.force_mfma && !g_gemv_force_mfma))) {       // whole-row streaming form
     switch (a.epi) {
       case EPI_PARTIAL: launch_rows<T, EPI_PARTIAL>(p, s); break;
       case EPI_SWIGLU: launch_rows<T, EPI_SWIGLU>(p, s); break;
@@ -332,9 +399,53 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 
+namespace {
+// one wave per row: absmax, then e4m3 (round to nearest even) of w / scale, 8 weights per lane per step
+template <typename T>
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const T* __restrict__ W, int ldw, int N, int K, unsigned char* __restrict__ W8, int ldq,
+                                                             float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const T* w = W + (size_t)n * ldw;
+  float m = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const typename V8<T>::type v = ld8<T>(w + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(tof(v[j])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float sc = m > 0.f ? m / 448.0f : 1.0f;
+  if (lane == 0) scale[n] = sc;
+  for (int k = lane * 8; k < K; k += 512) {
+    const typename V8<T>::type v = ld8<T>(w + k);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = tof(v[j]) / sc;
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    rw_u32x2 o2 = {(unsigned)lo, (unsigned)hi};
+    *reinterpret_cast<rw_u32x2*>(W8 + (size_t)n * ldq + k) = o2;
+  }
+}
+}  // namespace
+
+int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t s) {
+  OM_CHECK(K % 8 == 0 && ldw % 8 == 0 && ld8 % 8 == 0, "K, ldw, ld8 must be multiples of 8");
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(quant_fp8_rows_kernel<f16>, dim3(cdiv(N, 4)), dim3(256), 0, s, (const f16*)W, ldw, N, K, (unsigned char*)W8, ld8, scale);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(quant_fp8_rows_kernel<bf16>, dim3(cdiv(N, 4)), dim3(256), 0, s, (const bf16*)W, ldw, N, K, (unsigned char*)W8, ld8, scale);
+  else { omchat_set_error("launch_quant_fp8_rows: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 16, "batch must be 1..16 per call");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
+  OM_CHECK(!a.w_scale || a.b == 1, "fp8 weights: batch 1 only");
   OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU || a.epi == EPI_PARTIAL, "bad epilogue");
   OM_CHECK(a.ksplit <= 1 || a.epi == EPI_PARTIAL, "ksplit > 1 only with EPI_PARTIAL (fp32 slices)");
   OM_CHECK(a.ksplit <= a.K / 64, "ksplit exceeds the number of 64-wide K chunks");

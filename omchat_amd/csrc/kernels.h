@@ -44,8 +44,12 @@ struct GemvArgs {
   int out_f32;
   int ksplit;               // K slices across workgroups (EPI_PARTIAL), <= 1 = none
   int force_mfma;           // 1 = always the MFMA form (tests / A-B); default: b == 1 uses the whole-row streaming form
+  const float* w_scale;     // non-null: W is OCP e4m3 bytes [N][ldw] with one fp32 scale per row (weight-only fp8, b == 1 only)
 };
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
+// per-row (output channel) symmetric quantisation of W [N][ldw] (T) to OCP e4m3: scale[n] = absmax_n / 448 (1 if the row is 0),
+// W8[n][k] = e4m3_rne(W[n][k] / scale[n])
+int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t stream);
 void gemv_set_force_mfma(int v);
 
 // ------------------------------------------------------------------------------------------------ norms

@@ -85,6 +85,12 @@ struct omchat_ctx {
   // weights (device, compute dtype)
   struct VitLayer { void *ls1, *ls2, *n1, *n2, *wqkv, *qn, *kn, *wproj, *bproj, *w1, *b1, *w2, *b2; };
   struct DecLayer { void *ln1, *ln2, *wqkv, *bqkv, *wo, *wgu, *wd; };
+  // weight-only fp8 replica of the decode-streamed decoder weights (omchat_enable_fp8_decode): OCP e4m3 bytes + one fp32
+  // scale per output row; batch-1 decode steps stream these instead of the 16-bit weights, prefill keeps the 16-bit ones
+  struct DecLayer8 { void *wqkv, *wo, *wgu, *wd; float *sqkv, *so, *sgu, *sd; };
+  std::vector<DecLayer8> dl8;
+  void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
+  bool fp8_decode = false;
   void *v_cls = nullptr, *v_pos = nullptr, *v_wpatch = nullptr, *v_bpatch = nullptr;
   std::vector<VitLayer> vl;
   void *p_w0 = nullptr, *p_b0 = nullptr, *p_w2 = nullptr, *p_b2 = nullptr;
@@ -603,13 +609,42 @@ extern "C" int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, c
 // ---------------------------------------------------------------------------------------------------------
 // decoder
 // ---------------------------------------------------------------------------------------------------------
-static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s) {
+static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s, bool fp8 = false) {
   const int H = ctx->c.t_hidden, V = ctx->c.t_vocab;
   for (int r0 = 0; r0 < n; r0 += 16) {
     const int R = std::min(16, n - r0);
     GemvArgs g{(const char*)hidden + (size_t)r0 * H * 2, H, ctx->t_lm, H, logits + (size_t)r0 * V, V, R, V, H, nullptr, nullptr, 0, EPI_NONE, 1};
+    if (fp8 && n == 1) { g.W = ctx->t_lm8; g.w_scale = ctx->t_lm8_s; }
     TRY(launch_gemv(ctx->dt, g, s));
   }
+  return 0;
+}
+
+extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null context");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  if (!on) { ctx->fp8_decode = false; return 0; }
+  if (ctx->dl8.empty()) {
+    OM_CHECK(omchat_weights_missing(ctx) == 0, "load the weights before quantising them");
+    const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
+    ctx->dl8.resize(c.t_layers);
+    auto quant = [&](const void* W, int N, int K, void** w8, float** sc) -> int {
+      TRY(ctx->alloc(w8, (size_t)N * K));
+      TRY(ctx->alloc((void**)sc, (size_t)N * 4));
+      return launch_quant_fp8_rows(ctx->dt, W, K, N, K, *w8, K, *sc, nullptr);
+    };
+    for (int i = 0; i < c.t_layers; ++i) {
+      auto& L = ctx->dl[i]; auto& Q = ctx->dl8[i];
+      TRY(quant(L.wqkv, qkvd, H, &Q.wqkv, &Q.sqkv));
+      TRY(quant(L.wo, H, qd, &Q.wo, &Q.so));
+      TRY(quant(L.wgu, 2 * It, H, &Q.wgu, &Q.sgu));
+      TRY(quant(L.wd, H, It, &Q.wd, &Q.sd));
+    }
+    TRY(quant(ctx->t_lm, c.t_vocab, H, &ctx->t_lm8, &ctx->t_lm8_s));
+    OM_HIP(hipDeviceSynchronize());
+  }
+  ctx->fp8_decode = true;
   return 0;
 }
 
@@ -723,19 +758,24 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   void* x = ctx->tw_x;
   void* y = ctx->tw_x2;
   TRY(launch_gather_rows(ctx->dt, tokens, ctx->t_embed, nullptr, x, b, H, s));      // embed_tokens
-  auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi) -> int {
+  // weight-only fp8 replica (omchat_enable_fp8_decode): batch-1 steps stream e4m3 bytes + per-row scales
+  const bool f8 = ctx->fp8_decode && b == 1 && ctx->tp_size == 1;
+  auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi,
+                  const void* W8 = nullptr, const float* sc = nullptr) -> int {
     for (int r0 = 0; r0 < b; r0 += 16) {
       const int R = std::min(16, b - r0);
       GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
                  resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
+      if (f8 && W8) { g.W = W8; g.w_scale = sc; }
       TRY(launch_gemv(ctx->dt, g, s));
     }
     return 0;
   };
   // split-K over workgroups: fp32 slices [ks][b][H], summed by the fused residual + RMSNorm kernel
-  auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks) -> int {
+  auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks, const void* W8 = nullptr, const float* sc = nullptr) -> int {
     OM_CHECK(b <= 16, "split-K decode path handles b <= 16");
     GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
+    if (f8 && W8) { g.W = W8; g.w_scale = sc; }
     return launch_gemv(ctx->dt, g, s);
   };
   const bool fused = ctx->tp_size == 1 && b <= 16;
@@ -748,10 +788,12 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
+    static const omchat_ctx::DecLayer8 none8{};
+    const omchat_ctx::DecLayer8& Q = f8 ? ctx->dl8[i] : none8;
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
-    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE));
+    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv));
     // RoPE + KV append are fused into the attention kernel (q rotated in registers, the split that owns the new
     // position rotates k and appends k / v)
     AttnDecodeArgs a{};
@@ -765,7 +807,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
-      TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o));
+      TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so));
       TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
@@ -779,10 +821,10 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     // per token would themselves slow the measured decode by a few per cent
     const bool mark = i == c.t_layers / 2;
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU));
+    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu));
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (fused) {
-      TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d));
+      TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
       TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s));
     } else if (ctx->tp_size == 1) {
@@ -795,7 +837,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   }
   if (!fused)   TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
   float* lg = logits ? logits : ctx->tw_logits;
-  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s));
+  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8));
   if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();

@@ -87,6 +87,10 @@ class Engine:
     def fill_synthetic(self, seed=0):
         check(self.lib.omchat_fill_synthetic(self.h, seed))
 
+    def enable_fp8_decode(self, on=True):
+        """Weight-only OCP e4m3 replica of the decode-streamed decoder weights (quantised on first call); batch-1 decode only."""
+        check(self.lib.omchat_enable_fp8_decode(self.h, int(on)))
+
     def prof_enable(self, on=True):
         check(self.lib.omchat_prof_enable(self.h, int(on)))
 

@@ -91,3 +91,34 @@ def get_model_name_from_path(model_path):
     """mm_utils.py:233-239."""
     parts = model_path.strip("/").split("/")
     return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]
+
+
+class KeywordsStoppingCriteria:
+    """mm_utils.py:242-274: stop when the tail of the generated ids equals a keyword's ids, or a keyword appears in the decoded
+    tail.  Callable as HF StoppingCriteria: criteria(output_ids [b, T], scores) -> bool (all sequences hit)."""
+
+    def __init__(self, keywords, tokenizer, input_ids):
+        import torch
+        self.keywords = keywords
+        self.keyword_ids = []
+        self.max_keyword_len = 0
+        for keyword in keywords:
+            ids = tokenizer(keyword).input_ids
+            if len(ids) > 1 and ids[0] == tokenizer.bos_token_id:
+                ids = ids[1:]
+            self.max_keyword_len = max(self.max_keyword_len, len(ids))
+            self.keyword_ids.append(torch.tensor(ids))
+        self.tokenizer = tokenizer
+        self.start_len = input_ids.shape[1]
+
+    def call_for_batch(self, output_ids, scores, **kwargs):
+        import torch
+        offset = min(output_ids.shape[1] - self.start_len, self.max_keyword_len)
+        for kid in self.keyword_ids:
+            if torch.equal(output_ids[0, -kid.shape[0]:].cpu(), kid):
+                return True
+        outputs = self.tokenizer.batch_decode(output_ids[:, -offset:], skip_special_tokens=True)[0]
+        return any(k in outputs for k in self.keywords)
+
+    def __call__(self, output_ids, scores=None, **kwargs):
+        return all(self.call_for_batch(output_ids[i].unsqueeze(0), scores) for i in range(output_ids.shape[0]))

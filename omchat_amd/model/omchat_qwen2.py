@@ -164,7 +164,7 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
 
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, do_sample=False, temperature=0, max_new_tokens=None, streamer=None, use_cache=True,
-                 eos_token_id=None, pad_token_id=None, attention_mask=None, **kwargs):
+                 eos_token_id=None, pad_token_id=None, attention_mask=None, stopping_criteria=None, **kwargs):
         """Greedy loop as HF GenerationMixin drives it for single_inference.py:53-62: argmax of the last position (first
         index wins), stop on EOS (kept in the output) or max_new_tokens; returns prompt + new ids [b, T + new]."""
         if do_sample:
@@ -191,6 +191,10 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             done = done | torch.tensor([int(x) in eos for x in t_cpu])
             if bool(done.all()) or step == max_new_tokens - 1:
                 break
+            if stopping_criteria:                                     # HF StoppingCriteriaList semantics: any criterion stops the batch
+                so_far = torch.cat([input_ids.cpu(), torch.stack(new, dim=1)], dim=1)
+                if any(bool(c(so_far, None)) for c in stopping_criteria):
+                    break
             tok, _ = self.engine.decode_step(tok)
         if streamer is not None:
             streamer.end()

@@ -67,6 +67,30 @@ def test_generate_stops_on_eos_and_keeps_it(ckpt):
     assert out.shape[1] == ids.shape[1] + first + 1 and int(out[0, -1]) == eos      # EOS kept (README.md:77)
 
 
+def test_generate_with_keywords_stopping_criteria(ckpt):
+    """KeywordsStoppingCriteria (mm_utils.py:242-274) through generate(stopping_criteria=[...]): stops right after the keyword ids"""
+    import types
+    from omchat_amd.mm_utils import KeywordsStoppingCriteria
+    cfg, native, _ = ckpt
+    _, model, _, _ = load_pretrained_model(native, "native", max_seq=256, max_tiles=2)
+    px = T32(synth.pixels(1, 56, 6)).half().cuda()
+    ids = torch.tensor([[5, I, 7]])
+    free = model.generate(ids, images=px, max_new_tokens=8)
+    new = free[0, ids.shape[1]:].tolist()
+    kw = new[2:4]                                            # the 3rd+4th generated tokens spell the "keyword"
+
+    class _Tok:
+        bos_token_id = None
+        def __call__(self, s):
+            return types.SimpleNamespace(input_ids=kw)
+        def batch_decode(self, x, skip_special_tokens=True):
+            return [""]
+    crit = KeywordsStoppingCriteria(["STOP"], _Tok(), ids)
+    out = model.generate(ids, images=px, max_new_tokens=8, stopping_criteria=[crit])
+    first = next(i for i in range(1, len(new)) if new[i - 1:i + 1] == kw)
+    assert out[0].tolist() == free[0, :ids.shape[1] + first + 1].tolist()
+
+
 def test_forward_protocol_prefill_then_decode(ckpt):
     """step 0: full ids + images; step >= 1: last token + cache, images re-passed and ignored (omchat_qwen2.py:92-111)"""
     cfg, native, _ = ckpt

@@ -209,3 +209,24 @@ def test_local_dims_for_omchat13b():
         assert all(x < 0 or x // 7 == kv[0] for x in q)          # a rank's q heads all belong to its kv head
     with pytest.raises(ValueError):
         tp.local_dims(c, 0, 3)
+
+
+def test_keywords_stopping_criteria_semantics():
+    """mm_utils.py:242-274: id-suffix match, decoded-tail substring match, bos stripping, all() over the batch"""
+    import torch
+    from omchat_amd.mm_utils import KeywordsStoppingCriteria
+
+    class T:
+        bos_token_id = 1
+        def __call__(self, s):
+            return types.SimpleNamespace(input_ids=[1] + [ord(c) for c in s])
+        def batch_decode(self, x, skip_special_tokens=True):
+            return ["".join(chr(int(v)) for v in row if 32 <= int(v) < 127) for row in x]
+    prompt = torch.tensor([[9, 9, 9]])
+    c = KeywordsStoppingCriteria(["###", "ab"], T(), prompt)
+    assert c.max_keyword_len == 3 and [k.tolist() for k in c.keyword_ids] == [[35, 35, 35], [97, 98]]
+    assert not c(torch.tensor([[9, 9, 9, 35, 35]]), None)
+    assert c(torch.tensor([[9, 9, 9, 35, 35, 35]]), None)                       # id suffix
+    assert c(torch.tensor([[9, 9, 9, 97, 98, 50]]), None)                       # substring of the decoded tail
+    assert not c(torch.tensor([[9, 9, 9, 97, 50, 98]]), None)
+    assert not c(torch.tensor([[9, 9, 9, 35, 35, 35], [9, 9, 9, 1, 2, 3]]), None)   # every row must hit
