@@ -55,6 +55,11 @@ typedef struct {
   int max_tiles;       /* ViT tiles per launch batch */
   int max_prefill_rows;/* b * S rows of one prefill call */
   int dtype;           /* OMCHAT_F16 | OMCHAT_BF16 */
+  /* tower variant (0 = the InternViT-6B defaults, so older callers that zero the tail are unchanged):
+   * InternViT-300M (intern_vit_300m/configuration_intern_vit.py:60-80) = head_dim 64, LayerNorm, no q/k norm */
+  int v_head_dim;      /* 0 or 128 | 64 */
+  int v_norm_type;     /* 0 = InternRMSNorm, 1 = nn.LayerNorm (weight + bias) */
+  int v_no_qk_norm;    /* 0 = joint-head q/k RMSNorm (qk_normalization=True), 1 = none */
 } omchat_config;
 
 const char* omchat_last_error(void);
@@ -154,6 +159,11 @@ int omchat_op_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const voi
 /* q [b,Sq,Hq,128], k/v [b,Hkv,Skv,128] (cache layout), out [b,Sq,Hq,128]; kv_len device int32 [b] or NULL */
 int omchat_op_attn_prefill(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Sq, int Skv,
                            int Hq, int Hkv, const int32_t* kv_len, int causal, int q_pos0, float scale, void* stream);
+/* same with head dim D = 128 or 64 (InternViT-300M attention, intern_vit_300m/modeling_intern_vit.py:138-155) */
+int omchat_op_attn_prefill_d(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Sq, int Skv,
+                             int Hq, int Hkv, int D, const int32_t* kv_len, int causal, int q_pos0, float scale, void* stream);
+/* nn.LayerNorm over the last dim (weight + bias), fp32 statistics, one rounding */
+int omchat_op_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, float eps, void* stream);
 /* q [b,Hq,128], k/v [b,Hkv,cap,128]; kv_len device int32 [b] or NULL (-> L); ws from omchat_op_attn_decode_ws */
 size_t omchat_op_attn_decode_ws(int b, int Hq, int L);
 int omchat_op_attn_decode(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Hq, int Hkv,
@@ -174,6 +184,12 @@ int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float 
 int omchat_preproc_plan(int W, int H, const int* pinpoints, int n_pin, int tile, int* best_w, int* best_h, int* n_tiles);
 int omchat_preproc_anyres(int dtype, const void* rgb, int rgb_on_device, int W, int H, int best_w, int best_h, int tile,
                           const float mean[3], const float std_[3], void* pixels_out, void* stream);
+/* dynamic_preprocess + process_dynamic_image (mm_utils.py:276-323, the OmChat-2.1 / InternViT-300M tiling): plain resize to
+ * (grid_w*tile, grid_h*tile) -- aspect not preserved --, row-major tiles, thumbnail FIRST when `thumbnail` (the reference
+ * adds it when the grid has more than one block); pixels_out [thumbnail + grid_w*grid_h][3][tile][tile].  The grid choice
+ * (find_closest_aspect_ratio, :326-339) is host integer/float logic in omchat_amd/mm_utils.py. */
+int omchat_preproc_dynamic(int dtype, const void* rgb, int rgb_on_device, int W, int H, int grid_w, int grid_h, int tile, int thumbnail,
+                           const float mean[3], const float std_[3], void* pixels_out, void* stream);
 /* host-only pieces exposed for the CPU parity tests: Pillow's fixed-point resampling taps (Resample.c precompute_coeffs +
  * normalize_coeffs_8bpc, BICUBIC): bounds [out][2] = (first source index, taps), kk [out][*ksize]; and the 3 x 256
  * rescale+normalize table */

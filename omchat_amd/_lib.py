@@ -20,6 +20,7 @@ class OmchatConfig(C.Structure):
         ("t_hidden", C.c_int), ("t_layers", C.c_int), ("t_heads", C.c_int), ("t_kv_heads", C.c_int), ("t_mlp", C.c_int),
         ("t_vocab", C.c_int), ("t_vocab_total", C.c_int), ("t_eps", C.c_float), ("rope_theta", C.c_float),
         ("max_seq", C.c_int), ("max_batch", C.c_int), ("max_tiles", C.c_int), ("max_prefill_rows", C.c_int), ("dtype", C.c_int),
+        ("v_head_dim", C.c_int), ("v_norm_type", C.c_int), ("v_no_qk_norm", C.c_int),
     ]
 
 
@@ -62,6 +63,8 @@ _SIGS = {
     "omchat_op_rmsnorm": (_i, [_i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "omchat_op_vit_qknorm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "omchat_op_attn_prefill": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp]),
+    "omchat_op_attn_prefill_d": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp]),
+    "omchat_op_layernorm": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "omchat_op_attn_decode_ws": (_sz, [_i, _i, _i]),
     "omchat_op_attn_decode": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _sz, _vp]),
     "omchat_op_rope_kv": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
@@ -69,6 +72,7 @@ _SIGS = {
     "omchat_op_fill_uniform": (_i, [_i, _vp, _i64, _u64, _f, _f, _vp]),
     "omchat_preproc_plan": (_i, [_i, _i, _vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "omchat_preproc_anyres": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "omchat_preproc_dynamic": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "omchat_resample_coeffs": (_i, [_i, _i, C.POINTER(_i), _vp, _vp, _i]),
     "omchat_normalize_lut": (_i, [_vp, _vp, _vp]),
     "omchat_comm_unique_id": (_i, [C.c_char_p]),

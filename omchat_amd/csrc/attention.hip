@@ -109,13 +109,23 @@ __device__ __forceinline__ float max_xor16_raw(float v) {
   return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int NW, int NQ>
+// Head dim D = 128 (InternViT-6B, Qwen2) or 64 (InternViT-300M): tile rows are 2*D bytes = CPR 16-B chunks, and the two
+// swizzles become  K: chunk ^ (D == 128 ? row & 15 : (row >> 1) & 7)   V: chunk ^ (D == 128 ? (row & 7) << 1 : ((row >> 1) & 3) << 1)
+// (a 128-B row spans 32 banks, so two consecutive rows already differ and the XOR acts on row >> 1).
+template <int D> __device__ __forceinline__ int swz_k(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int D> __device__ __forceinline__ int swz_v(int row) { return D == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1); }
+
+template <typename T, int NW, int NQ, int D>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   constexpr int NT = NW * 64;
-  constexpr int CH = 1024 / NT;            // LDS-DMA instructions per thread per tile (K and V each)
-  constexpr int RPI = NT / 16;             // rows covered by one instruction round of the workgroup
-  constexpr int BUF = 2 * KV_TILE * 256;
+  constexpr int RB = D * 2;                // bytes per K / V tile row
+  constexpr int CPR = RB / 16;             // 16-B chunks per row
+  constexpr int RPI = NT / CPR;            // rows covered by one instruction round of the workgroup
+  constexpr int CH = KV_TILE / RPI;        // LDS-DMA instructions per thread per tile (K and V each)
+  constexpr int DS = D / 32;               // 32-wide d steps of S^T = K Q^T
+  constexpr int DN = D / 16;               // 16-row tiles of O^T
+  constexpr int BUF = 2 * KV_TILE * RB;
   __shared__ __attribute__((aligned(256))) char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
 
   // ---- Q fragments (B operand of S^T): lane holds Q[query fc][d = 32*ds + 8*fg + j]
-  frag_t qf[NQ][4];
+  frag_t qf[NQ][DS];
   int qrow[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
@@ -144,27 +154,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     const int rr = qrow[qt] < p.Sq ? qrow[qt] : p.Sq - 1;
     const T* qp = (const T*)p.Q + b * p.q_sb + hq0 * p.q_sh + rr * p.q_sr;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = ld8<T>(qp + ds * 32 + fg * 8);
+    for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld8<T>(qp + ds * 32 + fg * 8);
   }
 
-  f32x4 o[NQ][8];
+  f32x4 o[NQ][DN];
   float m_run[NQ], l_run[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
     m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
 #pragma unroll
-    for (int dn = 0; dn < 8; ++dn) o[qt][dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dn = 0; dn < DN; ++dn) o[qt][dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
   // ---- staging: instruction i of this thread fills LDS (row = i*RPI + tid/16, physical chunk tid%16).  RPI is a multiple
   // of 16, so the swizzled source chunk is the same for every i: one base pointer per operand + wave-uniform row offsets
-  static_assert(RPI % 16 == 0, "staging rows per round must keep row & 15");
-  const int srow = tid >> 4, spc = tid & 15;
-  const T* const kbase = Kg + (int64_t)srow * p.k_sr + ((spc ^ (srow & 15)) << 3);
-  const T* const vbase = Vg + (int64_t)srow * p.v_sr + ((spc ^ ((srow & 7) << 1)) << 3);
+  static_assert(RPI % 16 == 0 && KV_TILE % RPI == 0, "staging rows per round must keep the swizzle bits of the row");
+  const int srow = tid / CPR, spc = tid % CPR;
+  const T* const kbase = Kg + (int64_t)srow * p.k_sr + ((spc ^ swz_k<D>(srow)) << 3);
+  const T* const vbase = Vg + (int64_t)srow * p.v_sr + ((spc ^ swz_v<D>(srow)) << 3);
   auto issue_tile = [&](int t, int buf) {
     char* const Kw = smem + buf * BUF;
-    char* const Vw = Kw + KV_TILE * 256;
+    char* const Vw = Kw + KV_TILE * RB;
     if ((t + 1) * KV_TILE <= kv_len) {                                      // full tile (uniform): scalar row offsets
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   // V^T operand (transposed read): lane fc = 4*tq + tp supplies row 32*ks + 4*fg + tq (+16), chunk 2*dn + (tp>>1), +8*(tp&1)
   const int tq = fc >> 2, tp = fc & 3;
   const int vrow_lo = 4 * fg + tq;                       // (+32*ks, +16 for the second read)
-  const int vswz = ((vrow_lo & 7) << 1);                 // rows +16 / +32 keep (row & 7)
+  const int vswz = swz_v<D>(vrow_lo);                    // rows +16 / +32 keep the swizzle
 
   // tile t lives in buffer t & 1.  Iteration t: wait for own DMA of tile t, barrier (tile t visible to everyone, buffer
   // (t+1)&1 no longer read by anyone), issue tile t+1, then S^T, softmax and PV from buffer t & 1.
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   for (int t = 0; t < t_end; ++t) {
     const int cur = t & 1;
     const char* const Ks = smem + cur * BUF;
-    const char* const Vs = Ks + KV_TILE * 256;
+    const char* const Vs = Ks + KV_TILE * RB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);
@@ -209,8 +219,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + (kt * 16 + fc) * 256 + (((ds * 4 + fg) ^ fc) << 4));
+      for (int ds = 0; ds < DS; ++ds) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + (kt * 16 + fc) * RB + (((ds * 4 + fg) ^ swz_k<D>(fc)) << 4));
 #pragma unroll
         for (int qt = 0; qt < NQ; ++qt) s[qt][kt] = mfma16(kf, qf[qt][ds], s[qt][kt]);
       }
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
         m_run[qt] = m_new;
         l_run[qt] *= alpha;
 #pragma unroll
-        for (int dn = 0; dn < 8; ++dn) o[qt][dn] *= alpha;
+        for (int dn = 0; dn < DN; ++dn) o[qt][dn] *= alpha;
       }
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       const float nmc = -m_run[qt] * p.c;
@@ -280,11 +290,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int dn = 0; dn < 8; ++dn) {
+      for (int dn = 0; dn < DN; ++dn) {
         const int ch = (2 * dn + (tp >> 1)) ^ vswz;
-        const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+        const char* a0 = Vs + (ks * 32 + vrow_lo) * RB + (ch << 4) + 8 * (tp & 1);
         const s16x4 lo = tr_read(a0);
-        const s16x4 hi = tr_read(a0 + 16 * 256);
+        const s16x4 hi = tr_read(a0 + 16 * RB);
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         const frag_t vf = __builtin_bit_cast(frag_t, cat);
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
       const float inv = 1.f / l;
       T* op = (T*)p.O + b * p.o_sb + hq0 * p.o_sh + qrow[qt] * p.o_sr + fg * 4;
 #pragma unroll
-      for (int dn = 0; dn < 8; ++dn) {
+      for (int dn = 0; dn < DN; ++dn) {
         typename V8<T>::half_type h4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h4[r] = fromf<T>(o[qt][dn][r] * inv);
@@ -527,8 +537,17 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
           a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
           nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
-  if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2>), grid, dim3(256), 0, s, p);
-  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2>), grid, dim3(256), 0, s, p);
+  const int hd = a.head_dim ? a.head_dim : 128;
+  OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
+  if (hd == 64) {
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, 64>), grid, dim3(256), 0, s, p);
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, 64>), grid, dim3(256), 0, s, p);
+    else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, 128>), grid, dim3(256), 0, s, p);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, 128>), grid, dim3(256), 0, s, p);
   else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

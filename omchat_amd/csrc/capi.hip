@@ -127,3 +127,19 @@ extern "C" int omchat_op_gemv_fp8(int dtype, const void* X, const void* W8, cons
   GemvArgs g{X, K, W8, K, Y, N, 1, N, K, bias, resid, N, epi, out_f32, ksplit, 0, scale};
   return launch_gemv(dtype, g, S(stream));
 }
+
+extern "C" int omchat_op_attn_prefill_d(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Sq, int Skv, int Hq,
+                                        int Hkv, int D, const int32_t* kv_len, int causal, int q_pos0, float scale, void* stream) {
+  AttnArgs a{};
+  a.Q = q; a.q_sb = (int64_t)Sq * Hq * D; a.q_sh = D; a.q_sr = (int64_t)Hq * D;
+  a.K = k; a.k_sb = (int64_t)Hkv * Skv * D; a.k_sh = (int64_t)Skv * D; a.k_sr = D;
+  a.V = v; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = D;
+  a.O = out; a.o_sb = a.q_sb; a.o_sh = D; a.o_sr = a.q_sr;
+  a.batch = b; a.q_heads = Hq; a.kv_heads = Hkv; a.Sq = Sq; a.Skv = Skv; a.kv_len = kv_len; a.causal = causal; a.q_pos0 = q_pos0; a.scale = scale;
+  a.head_dim = D;
+  return launch_attn_prefill(dtype, a, S(stream));
+}
+
+extern "C" int omchat_op_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, float eps, void* stream) {
+  return launch_layernorm(dtype, x, H, w, b, y, H, rows, H, eps, S(stream));
+}

@@ -57,6 +57,53 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm (InternViT-300M: NORM2FN['layer_norm'] = nn.LayerNorm, intern_vit_300m/modeling_intern_vit.py:61-64,209-210):
+// fp32 mean / biased variance over the row, y = T((x - mean) * rsqrt(var + eps) * w + b)   (one rounding, as ATen)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(const T* x, int ldx, const T* w, const T* b, T* y, int ldy, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  const T* xr = x + (size_t)row * ldx;
+  T* yr = y + (size_t)row * ldy;
+  const int nchunk = H >> 3;
+  float xv[NORM_MAXC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 v = ld8<T>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xv[i][j] = tof(v[j]); sum += xv[i][j]; }
+    }
+  }
+  const float mean = block_sum(sum, red) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float inv = rsqrtf(block_sum(sq, red) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 wv = ld8<T>(w + c * 8), bv = ld8<T>(b + c * 8);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>((xv[i][j] - mean) * inv * tof(wv[j]) + tof(bv[j]));
+      st8<T>(yr + c * 8, o);
+    }
+  }
+}
+
 // decode tail of o_proj / down_proj: add the split-K fp32 slices (fixed order), round like the reference
 // (T(linear) then T(residual + .), modeling_qwen2.py:283-296), then the NEXT RMSNorm of the same row, in one pass.
 template <typename T, int KS>
@@ -368,6 +415,14 @@ inline int grid_for(long n, int threads) {
   if ((dtype) == OMCHAT_F16) { typedef f16 T; CALL; }                \
   else if ((dtype) == OMCHAT_BF16) { typedef bf16 T; CALL; }         \
   else { omchat_set_error("bad dtype"); return 1; }
+
+int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H must be a multiple of 8 and <= 16384");
+  OM_CHECK(w && b, "LayerNorm needs weight and bias");
+  DISPATCH(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (const T*)b, (T*)y, ldy, H, eps));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s) {
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");

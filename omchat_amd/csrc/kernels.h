@@ -54,6 +54,7 @@ void gemv_set_force_mfma(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)
+int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps, hipStream_t stream);
 int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s);
 // decode: x = T(x + T(sum_s part[s])) in place, then xn = rmsnorm(x) * w (w == null: skip the norm).  part fp32 [ks][rows][H]
 int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
@@ -77,6 +78,7 @@ struct AttnArgs {
   int causal;               // key j visible to query i iff j < kv_len and (!causal or j <= i + q_pos0)
   int q_pos0;               // absolute position of query row 0 (0 for a fresh prefill)
   float scale;              // applied to scores in fp32
+  int head_dim;             // 128 (0 = 128) or 64 (InternViT-300M)
 };
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s);
 

@@ -79,11 +79,11 @@ struct omchat_ctx {
   std::unordered_map<std::string, Route> routes;
 
   // derived geometry
-  int v_np = 0, v_ntok = 0, v_Cq = 0, v_kpad = 0;
+  int v_np = 0, v_ntok = 0, v_Cq = 0, v_kpad = 0, v_hd = 128;
   int t_qdim = 0, t_kvdim = 0, t_qkvdim = 0;
 
   // weights (device, compute dtype)
-  struct VitLayer { void *ls1, *ls2, *n1, *n2, *wqkv, *qn, *kn, *wproj, *bproj, *w1, *b1, *w2, *b2; };
+  struct VitLayer { void *ls1, *ls2, *n1, *n2, *n1b, *n2b, *wqkv, *qn, *kn, *wproj, *bproj, *w1, *b1, *w2, *b2; };
   struct DecLayer { void *ln1, *ln2, *wqkv, *bqkv, *wo, *wgu, *wd; };
   // weight-only fp8 replica of the decode-streamed decoder weights (omchat_enable_fp8_decode): OCP e4m3 bytes + one fp32
   // scale per output row; batch-1 decode steps stream these instead of the 16-bit weights, prefill keeps the 16-bit ones
@@ -181,7 +181,8 @@ int build(omchat_ctx* ctx) {
   const int C = c.v_hidden, I = c.v_mlp;
   ctx->v_np = (c.v_image / c.v_patch) * (c.v_image / c.v_patch);
   ctx->v_ntok = ctx->v_np + 1;
-  ctx->v_Cq = c.v_heads * 128;
+  ctx->v_hd = c.v_head_dim ? c.v_head_dim : 128;
+  ctx->v_Cq = c.v_heads * ctx->v_hd;
   const int K = 3 * c.v_patch * c.v_patch;
   ctx->v_kpad = cdiv(K, 64) * 64;
   const std::string TW = "model.vision_tower.vision_tower.";
@@ -202,9 +203,16 @@ int build(omchat_ctx* ctx) {
       TRY(add_route(ctx, P + "ls2", &L.ls2, 1, C, 0.02f, 0.1f));
       TRY(add_route(ctx, P + "norm1.weight", &L.n1, 1, C, 0.05f, 1.f));
       TRY(add_route(ctx, P + "norm2.weight", &L.n2, 1, C, 0.05f, 1.f));
+      L.n1b = L.n2b = L.qn = L.kn = nullptr;
+      if (c.v_norm_type == 1) {
+        TRY(add_route(ctx, P + "norm1.bias", &L.n1b, 1, C, 0.02f, 0.f));
+        TRY(add_route(ctx, P + "norm2.bias", &L.n2b, 1, C, 0.02f, 0.f));
+      }
       TRY(add_route(ctx, P + "attn.qkv.weight", &L.wqkv, 3 * ctx->v_Cq, C, 0.02f, 0.f));
-      TRY(add_route(ctx, P + "attn.q_norm.weight", &L.qn, 1, ctx->v_Cq, 0.05f, 1.f));
-      TRY(add_route(ctx, P + "attn.k_norm.weight", &L.kn, 1, ctx->v_Cq, 0.05f, 1.f));
+      if (!c.v_no_qk_norm) {
+        TRY(add_route(ctx, P + "attn.q_norm.weight", &L.qn, 1, ctx->v_Cq, 0.05f, 1.f));
+        TRY(add_route(ctx, P + "attn.k_norm.weight", &L.kn, 1, ctx->v_Cq, 0.05f, 1.f));
+      }
       TRY(add_route(ctx, P + "attn.proj.weight", &L.wproj, C, ctx->v_Cq, 0.02f, 0.f));
       TRY(add_route(ctx, P + "attn.proj.bias", &L.bproj, 1, C, 0.02f, 0.f));
       TRY(add_route(ctx, P + "mlp.fc1.weight", &L.w1, I, C, 0.02f, 0.f));
@@ -340,6 +348,8 @@ extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_s
   OM_CHECK(cfg->dtype == OMCHAT_F16 || cfg->dtype == OMCHAT_BF16, "dtype must be OMCHAT_F16 or OMCHAT_BF16");
   OM_CHECK(tp_size >= 1 && tp_rank >= 0 && tp_rank < tp_size, "bad tensor-parallel rank/size");
   OM_CHECK(tp_size == 1 || rccl_comm, "tp_size > 1 needs an RCCL communicator");
+  OM_CHECK(cfg->v_head_dim == 0 || cfg->v_head_dim == 128 || cfg->v_head_dim == 64, "v_head_dim must be 128 or 64");
+  OM_CHECK(cfg->v_norm_type == 0 || cfg->v_norm_type == 1, "v_norm_type must be 0 (RMSNorm) or 1 (LayerNorm)");
   OM_CHECK(cfg->v_layers == 0 || (cfg->v_hidden % 64 == 0 && cfg->v_mlp % 64 == 0 && cfg->v_image % cfg->v_patch == 0),
            "vision dims: hidden/mlp % 64, image % patch");
   OM_CHECK(cfg->t_layers == 0 || (cfg->t_hidden % 64 == 0 && cfg->t_mlp % 64 == 0 && cfg->t_heads % cfg->t_kv_heads == 0),
@@ -444,22 +454,33 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
   for (int j = 0; j < n_layers; ++j) {
     auto& L = ctx->vl[j];
     // InternVisionEncoderLayer.forward (modeling_intern_vit.py:210-222)
-    TRY(launch_rmsnorm(ctx->dt, x, C, L.n1, ctx->vw_xn, C, M, C, c.v_eps, s));
+    const int hd = ctx->v_hd;
+    const float qscale = hd == 128 ? 0.08838834764831845f : 0.125f;      // head_dim ** -0.5 (modeling_intern_vit.py:118)
+    auto norm = [&](const void* w, const void* b) -> int {      // InternRMSNorm, or nn.LayerNorm for the 300M tower (NORM2FN)
+      if (c.v_norm_type == 1) return launch_layernorm(ctx->dt, x, C, w, b, ctx->vw_xn, C, M, C, c.v_eps, s);
+      return launch_rmsnorm(ctx->dt, x, C, w, ctx->vw_xn, C, M, C, c.v_eps, s);
+    };
+    TRY(norm(L.n1, L.n1b));
     TRY(gemm(ctx, ctx->vw_xn, C, L.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, nullptr, nullptr, 0, EPI_NONE, s));
-    const float* sumsq = nullptr;
-    if (ctx->tp_size > 1) {     // joint-head norm: sum of squares over ALL ranks' heads
-      TRY(launch_vit_qk_sumsq(ctx->dt, ctx->vw_qkv, 3 * Cq, M, Cq, ctx->vw_sumsq, s));
-      TRY(ctx->allreduce_f32(ctx->vw_sumsq, (size_t)M * 2, s));
-      sumsq = ctx->vw_sumsq;
-    }
-    TRY(launch_vit_qknorm(ctx->dt, ctx->vw_qkv, 3 * Cq, L.qn, L.kn, M, Cq, c.v_qk_channels, c.v_eps, 0.08838834764831845f, sumsq, s));
     AttnArgs a{};
-    a.Q = ctx->vw_qkv; a.q_sb = (int64_t)ntok * 3 * Cq; a.q_sh = 128; a.q_sr = 3 * Cq;
-    a.K = (const char*)ctx->vw_qkv + (size_t)Cq * 2; a.k_sb = a.q_sb; a.k_sh = 128; a.k_sr = 3 * Cq;
-    a.V = (const char*)ctx->vw_qkv + (size_t)2 * Cq * 2; a.v_sb = a.q_sb; a.v_sh = 128; a.v_sr = 3 * Cq;
-    a.O = ctx->vw_ao; a.o_sb = (int64_t)ntok * Cq; a.o_sh = 128; a.o_sr = Cq;
+    if (!c.v_no_qk_norm) {
+      const float* sumsq = nullptr;
+      if (ctx->tp_size > 1) {     // joint-head norm: sum of squares over ALL ranks' heads
+        TRY(launch_vit_qk_sumsq(ctx->dt, ctx->vw_qkv, 3 * Cq, M, Cq, ctx->vw_sumsq, s));
+        TRY(ctx->allreduce_f32(ctx->vw_sumsq, (size_t)M * 2, s));
+        sumsq = ctx->vw_sumsq;
+      }
+      TRY(launch_vit_qknorm(ctx->dt, ctx->vw_qkv, 3 * Cq, L.qn, L.kn, M, Cq, c.v_qk_channels, c.v_eps, qscale, sumsq, s));
+      a.scale = 1.0f;     // q was pre-scaled by the q/k norm kernel (reference order, modeling_intern_vit.py:148)
+    } else {
+      a.scale = qscale;     // q * scale is exact for head_dim 64 (2^-3), so scaling the fp32 scores is the same value
+    }
+    a.Q = ctx->vw_qkv; a.q_sb = (int64_t)ntok * 3 * Cq; a.q_sh = hd; a.q_sr = 3 * Cq;
+    a.K = (const char*)ctx->vw_qkv + (size_t)Cq * 2; a.k_sb = a.q_sb; a.k_sh = hd; a.k_sr = 3 * Cq;
+    a.V = (const char*)ctx->vw_qkv + (size_t)2 * Cq * 2; a.v_sb = a.q_sb; a.v_sh = hd; a.v_sr = 3 * Cq;
+    a.O = ctx->vw_ao; a.o_sb = (int64_t)ntok * Cq; a.o_sh = hd; a.o_sr = Cq;
     a.batch = B; a.q_heads = c.v_heads; a.kv_heads = c.v_heads; a.Sq = ntok; a.Skv = ntok; a.kv_len = nullptr; a.causal = 0; a.q_pos0 = 0;
-    a.scale = 1.0f;     // q was pre-scaled by the q/k norm kernel (reference order, modeling_intern_vit.py:148)
+    a.head_dim = hd;
     TRY(launch_attn_prefill(ctx->dt, a, s));
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID, s));
@@ -468,7 +489,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
       TRY(ctx->allreduce(y, (size_t)M * C, s));
       std::swap(x, y);
     }
-    TRY(launch_rmsnorm(ctx->dt, x, C, L.n2, ctx->vw_xn, C, M, C, c.v_eps, s));
+    TRY(norm(L.n2, L.n2b));
     ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
     TRY(gemm(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, s));
     ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);

@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void tiles_kernel(const unsigned char* __restr
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
   if (x >= tile) return;
   unsigned char px[3] = {0, 0, 0};
-  if (t == 0) {
+  const int first = thumb ? 1 : 0;          // no thumbnail: tile t is canvas tile t
+  if (t < first) {
     const unsigned char* p = thumb + ((size_t)y * tile + x) * 3;
     px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
   } else {
-    const int ty = (t - 1) / tiles_x, tx = (t - 1) % tiles_x;
+    const int ty = (t - first) / tiles_x, tx = (t - first) % tiles_x;
     const int cx = tx * tile + x - x0, cy = ty * tile + y - y0;
     if (cx >= 0 && cx < nw && cy >= 0 && cy < nh) {
       const unsigned char* p = img + ((size_t)cy * nw + cx) * 3;
@@ -219,15 +220,14 @@ extern "C" int omchat_preproc_plan(int W, int H, const int* pinpoints, int n_pin
   return 0;
 }
 
-extern "C" int omchat_preproc_anyres(int dtype, const void* rgb, int rgb_on_device, int W, int H, int best_w, int best_h, int tile,
-                                     const float mean[3], const float std_[3], void* pixels_out, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+// resize to (rw, rh), paste at (x0, y0) on a black (cw x ch) canvas, cut row-major tiles, optional thumbnail first
+static int preproc_tiles(int dtype, const void* rgb, int rgb_on_device, int W, int H, int cw, int ch, int rw, int rh, int x0, int y0, int tile,
+                         int thumbnail, const float mean[3], const float std_[3], void* pixels_out, hipStream_t s) {
   OM_CHECK(rgb && pixels_out && W > 0 && H > 0, "null image");
-  OM_CHECK(best_w > 0 && best_h > 0 && best_w % tile == 0 && best_h % tile == 0, "best resolution must be a multiple of the tile edge");
+  OM_CHECK(cw > 0 && ch > 0 && cw % tile == 0 && ch % tile == 0, "canvas must be a multiple of the tile edge");
+  OM_CHECK(rw > 0 && rh > 0 && x0 >= 0 && y0 >= 0 && x0 + rw <= cw && y0 + rh <= ch, "resized image must fit the canvas");
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == OMCHAT_F32, "bad dtype");
-  int nw, nh;
-  padded_size(W, H, best_w, best_h, &nw, &nh);
-  const int x0 = (best_w - nw) / 2, y0 = (best_h - nh) / 2, tiles_x = best_w / tile, n = 1 + tiles_x * (best_h / tile);
+  const int tiles_x = cw / tile, n = (thumbnail ? 1 : 0) + tiles_x * (ch / tile);
   DevBuf src(s), thumb(s), img(s), lut(s);
   const unsigned char* d_src = (const unsigned char*)rgb;
   if (!rgb_on_device) {
@@ -235,21 +235,43 @@ extern "C" int omchat_preproc_anyres(int dtype, const void* rgb, int rgb_on_devi
     OM_HIP(hipMemcpyAsync(src.p, rgb, (size_t)W * H * 3, hipMemcpyHostToDevice, s));
     d_src = (const unsigned char*)src.p;
   }
-  OM_HIP(thumb.alloc((size_t)tile * tile * 3));
-  OM_HIP(img.alloc((size_t)nw * nh * 3));
+  OM_HIP(img.alloc((size_t)rw * rh * 3));
   OM_HIP(lut.alloc(768 * 4));
   float h_lut[768];
   omchat_normalize_lut(mean, std_, h_lut);
   OM_HIP(hipMemcpyAsync(lut.p, h_lut, sizeof(h_lut), hipMemcpyHostToDevice, s));
-  if (int rc = resize_device(d_src, W, H, (unsigned char*)thumb.p, tile, tile, s)) return rc;
-  if (int rc = resize_device(d_src, W, H, (unsigned char*)img.p, nw, nh, s)) return rc;
+  if (thumbnail) {
+    OM_HIP(thumb.alloc((size_t)tile * tile * 3));
+    if (int rc = resize_device(d_src, W, H, (unsigned char*)thumb.p, tile, tile, s)) return rc;
+  }
+  if (int rc = resize_device(d_src, W, H, (unsigned char*)img.p, rw, rh, s)) return rc;
+  OM_HIP(hipStreamSynchronize(s));       // h_lut / staged host image are consumed
   dim3 grid(cdiv(tile, 256), tile, n);
+  const unsigned char* th = thumbnail ? (const unsigned char*)thumb.p : nullptr;
   if (dtype == OMCHAT_F16)
-    hipLaunchKernelGGL(tiles_kernel<f16>, grid, dim3(256), 0, s, (const unsigned char*)thumb.p, (const unsigned char*)img.p, nw, nh, x0, y0, tiles_x, tile, (const float*)lut.p, (f16*)pixels_out);
+    hipLaunchKernelGGL(tiles_kernel<f16>, grid, dim3(256), 0, s, th, (const unsigned char*)img.p, rw, rh, x0, y0, tiles_x, tile, (const float*)lut.p, (f16*)pixels_out);
   else if (dtype == OMCHAT_BF16)
-    hipLaunchKernelGGL(tiles_kernel<bf16>, grid, dim3(256), 0, s, (const unsigned char*)thumb.p, (const unsigned char*)img.p, nw, nh, x0, y0, tiles_x, tile, (const float*)lut.p, (bf16*)pixels_out);
+    hipLaunchKernelGGL(tiles_kernel<bf16>, grid, dim3(256), 0, s, th, (const unsigned char*)img.p, rw, rh, x0, y0, tiles_x, tile, (const float*)lut.p, (bf16*)pixels_out);
   else
-    hipLaunchKernelGGL(tiles_kernel<float>, grid, dim3(256), 0, s, (const unsigned char*)thumb.p, (const unsigned char*)img.p, nw, nh, x0, y0, tiles_x, tile, (const float*)lut.p, (float*)pixels_out);
+    hipLaunchKernelGGL(tiles_kernel<float>, grid, dim3(256), 0, s, th, (const unsigned char*)img.p, rw, rh, x0, y0, tiles_x, tile, (const float*)lut.p, (float*)pixels_out);
   OM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int omchat_preproc_anyres(int dtype, const void* rgb, int rgb_on_device, int W, int H, int best_w, int best_h, int tile,
+                                     const float mean[3], const float std_[3], void* pixels_out, void* stream) {
+  OM_CHECK(W > 0 && H > 0 && best_w > 0 && best_h > 0 && tile > 0 && best_w % tile == 0 && best_h % tile == 0,
+           "best resolution must be a positive multiple of the tile edge");
+  int nw, nh;
+  padded_size(W, H, best_w, best_h, &nw, &nh);
+  return preproc_tiles(dtype, rgb, rgb_on_device, W, H, best_w, best_h, nw, nh, (best_w - nw) / 2, (best_h - nh) / 2, tile, 1, mean, std_, pixels_out,
+                       (hipStream_t)stream);
+}
+
+extern "C" int omchat_preproc_dynamic(int dtype, const void* rgb, int rgb_on_device, int W, int H, int grid_w, int grid_h, int tile, int thumbnail,
+                                      const float mean[3], const float std_[3], void* pixels_out, void* stream) {
+  OM_CHECK(grid_w > 0 && grid_h > 0 && tile > 0, "bad grid");
+  // dynamic_preprocess (mm_utils.py:276-312): plain resize to the grid (aspect NOT preserved), row-major tiles, thumbnail first
+  return preproc_tiles(dtype, rgb, rgb_on_device, W, H, grid_w * tile, grid_h * tile, grid_w * tile, grid_h * tile, 0, 0, tile, thumbnail ? 1 : 0, mean, std_,
+                       pixels_out, (hipStream_t)stream);
 }

@@ -41,6 +41,9 @@ class Engine:
         c.max_seq = max_seq; c.max_batch = max_batch; c.max_tiles = max_tiles
         c.max_prefill_rows = max_prefill_rows if max_prefill_rows is not None else max_seq * max_batch
         c.dtype = self.dtype_code
+        c.v_head_dim = v.get("head_dim", 128)
+        c.v_norm_type = 1 if v.get("norm_type", "rms_norm") == "layer_norm" else 0
+        c.v_no_qk_norm = 0 if v.get("qk_normalization", True) else 1
         self.c = c
         self.ntok = cfg.num_image_tokens
         h = C.c_void_p()

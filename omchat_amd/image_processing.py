@@ -65,6 +65,30 @@ class HipImageProcessor:
             check(_lib.lib().omchat_preproc_anyres(_lib.dtype_code(dtype), src, int(on_dev), W, H, best[0], best[1], tile, mean, std, ptr(out), cur_stream()))
         return (out, best) if return_best_res else out
 
+    # ------------------------------------------------------------------ dynamic tiling (OmChat-2.1)
+    def process_dynamic(self, image, max_num=6, image_size=None, min_num=1, use_thumbnail=True, dtype=None):
+        """dynamic_preprocess + per-tile preprocess (mm_utils.py:276-323) on the device: [thumbnail? + cols*rows, 3, tile, tile]."""
+        import torch
+        from .mm_utils import dynamic_grid
+        if not torch.cuda.is_available():
+            raise _lib.OmchatError("HipImageProcessor needs a HIP device (no CPU fallback)")
+        tile = self.crop_size["height"]
+        if image_size is not None and image_size != tile:
+            raise ValueError(f"image_size {image_size} differs from the processor's tile edge {tile}")
+        dtype = dtype or torch.float32
+        a, on_dev = _rgb_array(image)
+        H, W = int(a.shape[0]), int(a.shape[1])
+        gw, gh = dynamic_grid((W, H), min_num, max_num, tile)
+        thumb = 1 if (use_thumbnail and gw * gh != 1) else 0
+        dev = torch.device(self.device if self.device is not None else (a.device if on_dev else f"cuda:{torch.cuda.current_device()}"))
+        out = torch.empty(thumb + gw * gh, 3, tile, tile, dtype=dtype, device=dev)
+        mean = (C.c_float * 3)(*self.image_mean)
+        std = (C.c_float * 3)(*self.image_std)
+        src = ptr(a) if isinstance(a, torch.Tensor) else a.ctypes.data_as(C.c_void_p)
+        with torch.cuda.device(dev):
+            check(_lib.lib().omchat_preproc_dynamic(_lib.dtype_code(dtype), src, int(on_dev), W, H, gw, gh, tile, thumb, mean, std, ptr(out), cur_stream()))
+        return out
+
     # ------------------------------------------------------------------ CLIPImageProcessor.preprocess for one tile-sized image
     def preprocess(self, images, return_tensors="pt", **kw):
         """One image (or a list) of exactly crop_size x crop_size: rescale + normalize + CHW (resize / centre-crop are

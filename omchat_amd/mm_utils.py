@@ -67,6 +67,52 @@ def process_anyres_image(image, processor, grid_pinpoints, return_type_list=Fals
     return (out, best) if return_best_res else out
 
 
+def find_closest_aspect_ratio(aspect_ratio, target_ratios, width, height, image_size):
+    """mm_utils.py:326-339."""
+    best_diff, best = float("inf"), (1, 1)
+    area = width * height
+    for r in target_ratios:
+        diff = abs(aspect_ratio - r[0] / r[1])
+        if diff < best_diff:
+            best_diff, best = diff, r
+        elif diff == best_diff and area > 0.5 * image_size * image_size * r[0] * r[1]:
+            best = r
+    return best
+
+
+def dynamic_grid(size, min_num=1, max_num=6, image_size=448):
+    """Grid (cols, rows) that dynamic_preprocess (mm_utils.py:276-292) resizes a (width, height) picture to."""
+    w, h = size
+    ratios = set((i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1) for j in range(1, n + 1)
+                 if min_num <= i * j <= max_num)
+    ratios = sorted(ratios, key=lambda x: x[0] * x[1])
+    return find_closest_aspect_ratio(w / h, ratios, w, h, image_size)
+
+
+def dynamic_preprocess(image, min_num=1, max_num=6, image_size=448, use_thumbnail=False):
+    """mm_utils.py:276-312 (PIL): plain resize to the grid, row-major crops, thumbnail first when there is more than one block."""
+    gw, gh = dynamic_grid(image.size, min_num, max_num, image_size)
+    resized = image.resize((image_size * gw, image_size * gh))
+    out = [resized.crop(((i % gw) * image_size, (i // gw) * image_size, (i % gw + 1) * image_size, (i // gw + 1) * image_size))
+           for i in range(gw * gh)]
+    if use_thumbnail and len(out) != 1:
+        out.insert(0, image.resize((image_size, image_size)))
+    return out
+
+
+def process_dynamic_image(image, processor, max_num=6, image_size=336, grid_pinpoints=None, return_type_list=False, return_best_res=False):
+    """mm_utils.py:315-323."""
+    import torch
+    if hasattr(processor, "process_dynamic"):           # device front-end
+        out = processor.process_dynamic(image, max_num=max_num, image_size=image_size)
+        out = list(out) if return_type_list else out
+        return (out, None) if return_best_res else out
+    tiles = [processor.preprocess(p, return_tensors="pt")["pixel_values"][0]
+             for p in dynamic_preprocess(image, max_num=max_num, image_size=image_size, use_thumbnail=True)]
+    out = tiles if return_type_list else torch.stack(tiles, dim=0)
+    return (out, None) if return_best_res else out
+
+
 def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
     """mm_utils.py:197-230 (the `<image>` branch): tokenise the chunks between `<image>` markers and join them
     with the sentinel; a leading BOS (none for Qwen2) is kept once."""

@@ -14,7 +14,8 @@ from ..engine import Engine
 from .omchat_qwen2 import OmChatQwen2ForCausalLM
 
 _VISION_DEFAULTS = dict(hidden_size=3200, num_attention_heads=25, intermediate_size=12800, num_hidden_layers=45, patch_size=14,
-                        image_size=448, layer_norm_eps=1e-6, qk_normalization=True, qkv_bias=False)   # configuration_intern_vit.py:63-83
+                        image_size=448, layer_norm_eps=1e-6, qk_normalization=True, qkv_bias=False,
+                        norm_type="rms_norm")   # configuration_intern_vit.py:63-83 (300m: intern_vit_300m/configuration_intern_vit.py:60-80)
 
 
 def config_from_json(path):

@@ -66,9 +66,23 @@ class InternVITVisionTower:
         return (self._cfg["image_size"] // self._cfg["patch_size"]) ** 2
 
 
+class InternVIT300mVisionTower(InternVITVisionTower):
+    """InternVIT300mVisionTower (internVIT300m_encoder.py:10-84): same wrapper contract as the 6B tower (CLIP-style processor,
+    hidden_states[select_layer], CLS dropped for 'patch', fp16 cast of the pixels :52); the tower behind it is the
+    LayerNorm / 16 x 64-head / no-q-k-norm variant, selected by the engine's vision config."""
+
+    def __init__(self, vision_tower, args, delay_load=False, engine=None):
+        if engine is not None and (engine.cfg.vision.get("norm_type") != "layer_norm" or engine.cfg.vision.get("head_dim") != 64):
+            raise ValueError("InternVIT300mVisionTower needs an engine built with the InternViT-300M vision config")
+        super().__init__(vision_tower, args, delay_load=delay_load, engine=engine)
+
+
 def build_vision_tower(vision_tower_cfg, engine=None, **kwargs):
-    """multimodal_encoder/builder.py:7-16: dispatch on the tower name; only the InternViT-6B tower is on the hot path."""
+    """multimodal_encoder/builder.py:7-18: dispatch on the tower name (300m before 6b, as the reference); the CLIP / SigLIP
+    towers are outside the hot path."""
     name = getattr(vision_tower_cfg, "mm_vision_tower", getattr(vision_tower_cfg, "vision_tower", None))
+    if name is not None and "internvit-300m" in name.lower():
+        return InternVIT300mVisionTower(name, args=vision_tower_cfg, engine=engine, **kwargs)
     if name is not None and "internvit-6b" in name.lower():
         return InternVITVisionTower(name, args=vision_tower_cfg, engine=engine, **kwargs)
-    raise ValueError(f"Unknown vision tower: {name} (this build implements the internvit-6b tower)")
+    raise ValueError(f"Unknown vision tower: {name} (this build implements the internvit-6b and internvit-300m towers)")

@@ -77,8 +77,12 @@ def tensor_specs(cfg):
         specs += [
             (P + "ls1", (C,), 0.02, 0.1), (P + "ls2", (C,), 0.02, 0.1),
             (P + "norm1.weight", (C,), 0.05, 1.0), (P + "norm2.weight", (C,), 0.05, 1.0),
-            (P + "attn.qkv.weight", (3 * C, C), 0.02, 0.0),
-            (P + "attn.q_norm.weight", (C,), 0.05, 1.0), (P + "attn.k_norm.weight", (C,), 0.05, 1.0),
+            (P + "attn.qkv.weight", (3 * C, C), 0.02, 0.0)]
+        if v.get("norm_type", "rms_norm") == "layer_norm":
+            specs += [(P + "norm1.bias", (C,), 0.02, 0.0), (P + "norm2.bias", (C,), 0.02, 0.0)]
+        if v.get("qk_normalization", True):
+            specs += [(P + "attn.q_norm.weight", (C,), 0.05, 1.0), (P + "attn.k_norm.weight", (C,), 0.05, 1.0)]
+        specs += [
             (P + "attn.proj.weight", (C, C), 0.02, 0.0), (P + "attn.proj.bias", (C,), 0.02, 0.0),
             (P + "mlp.fc1.weight", (I, C), 0.02, 0.0), (P + "mlp.fc1.bias", (I,), 0.02, 0.0),
             (P + "mlp.fc2.weight", (C, I), 0.02, 0.0), (P + "mlp.fc2.bias", (C,), 0.02, 0.0),

@@ -84,13 +84,14 @@ def _shard_np(name, x, cfg, rank, size):
     if ".encoder.layers." in name:
         vh = vit_head_map(cfg, rank, size)
         C = v["hidden_size"]
+        hd = v.get("head_dim", 128)
         if name.endswith("attn.qkv.weight"):
             q, k, vv = x[:C], x[C:2 * C], x[2 * C:]
-            return np.concatenate([_take_heads(q, vh), _take_heads(k, vh), _take_heads(vv, vh)], axis=0)
+            return np.concatenate([_take_heads(q, vh, hd), _take_heads(k, vh, hd), _take_heads(vv, vh, hd)], axis=0)
         if name.endswith("attn.q_norm.weight") or name.endswith("attn.k_norm.weight"):
-            return _take_heads(x, vh)
+            return _take_heads(x, vh, hd)
         if name.endswith("attn.proj.weight"):
-            return _take_heads(x.T, vh).T
+            return _take_heads(x.T, vh, hd).T
         if name.endswith("mlp.fc1.weight") or name.endswith("mlp.fc1.bias"):
             return x[sl(v["intermediate_size"])]
         if name.endswith("mlp.fc2.weight"):

@@ -115,3 +115,19 @@ def anyres_tiles(img, best, tile=448, lut=None):
         for c in range(3):
             out[t, c] = lut[c][a[:, :, c]]
     return out
+
+
+def dynamic_tiles(img, grid, tile=448, thumbnail=True, lut=None):
+    """dynamic_preprocess + process_dynamic_image (mm_utils.py:276-323) on an RGB uint8 array: plain resize to the grid
+    (cols, rows) x tile, row-major tiles, thumbnail first when the grid has more than one block."""
+    lut = normalize_lut() if lut is None else lut
+    gw, gh = grid
+    r = resize_bicubic(img, gw * tile, gh * tile)
+    tiles = [r[(i // gw) * tile:(i // gw + 1) * tile, (i % gw) * tile:(i % gw + 1) * tile] for i in range(gw * gh)]
+    if thumbnail and len(tiles) != 1:
+        tiles.insert(0, resize_bicubic(img, tile, tile))
+    out = np.empty((len(tiles), 3, tile, tile), np.float32)
+    for t, a in enumerate(tiles):
+        for c in range(3):
+            out[t, c] = lut[c][a[:, :, c]]
+    return out

@@ -74,8 +74,14 @@ def vit_mlp(x, w, pfx):
 def vit_layer(x, w, j, num_heads, eps=1e-6):
     """InternVisionEncoderLayer.forward (modeling_intern_vit.py:210-222); drop_path is Identity at rate 0."""
     pfx = f"encoder.layers.{j}."
-    x = x + vit_attention(rms_norm(x, w[pfx + "norm1.weight"], eps), w, pfx, num_heads, eps) * w[pfx + "ls1"]
-    x = x + vit_mlp(rms_norm(x, w[pfx + "norm2.weight"], eps), w, pfx) * w[pfx + "ls2"]
+
+    def norm(h, name):
+        # NORM2FN (intern_vit_300m/modeling_intern_vit.py:61-64,209-210): nn.LayerNorm when the checkpoint carries a norm bias
+        if (pfx + name + ".bias") in w:
+            return F.layer_norm(h, (h.shape[-1],), w[pfx + name + ".weight"], w[pfx + name + ".bias"], eps)
+        return rms_norm(h, w[pfx + name + ".weight"], eps)
+    x = x + vit_attention(norm(x, "norm1"), w, pfx, num_heads, eps) * w[pfx + "ls1"]
+    x = x + vit_mlp(norm(x, "norm2"), w, pfx) * w[pfx + "ls2"]
     return x
 
 

@@ -72,7 +72,8 @@ def test_gemv_fp8_vs_dequantised_reference(gpu_lib, dt, N, K, epi, ks):
     elif epi == "f32":
         bias = rnd(randn((N,), 3, 0.1), dt)
         y = torch.empty(N, dtype=torch.float32, device="cuda")
-        _lib.check(lib.omchat_op_gemv_fp8(CODE[dt], ptr(xd), ptr(w8), ptr(sc), ptr(y), N, K, ptr(dev(bias, dt)), None, 0, 1, 1, None)); sync()
+        bd = dev(bias, dt)
+        _lib.check(lib.omchat_op_gemv_fp8(CODE[dt], ptr(xd), ptr(w8), ptr(sc), ptr(y), N, K, ptr(bd), None, 0, 1, 1, None)); sync()
         assert rel(y, acc + bias.double()) < 2e-5
     elif epi == "none":
         bias = rnd(randn((N,), 3, 0.1), dt)

@@ -86,3 +86,20 @@ def test_mm_utils_and_get_context_use_the_device_front_end():
     _, ids, image_tensor = get_context("hi", _Tok(), image=img, image_processor=proc, image_grid_pinpoints=PINS)
     assert ids.count(-200) == 3 and image_tensor.dtype == torch.float16 and image_tensor.is_cuda and tuple(image_tensor.shape) == (3, 3, 448, 448)
     assert torch.equal(image_tensor.cpu(), torch.from_numpy(ref).half())      # make_context.py:25 `.half()`
+
+
+@pytest.mark.parametrize("w,h", [(700, 400), (448, 448), (300, 900), (2000, 600)])
+def test_dynamic_tiling_matches_oracle_bit_exact(w, h):
+    """dynamic_preprocess + process_dynamic_image (mm_utils.py:276-323; OmChat-2.1 tiling) on the device"""
+    from omchat_amd.mm_utils import dynamic_grid, process_dynamic_image
+    a = np.random.default_rng(w + 7 * h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    proc = _proc()
+    out = proc.process_dynamic(a, max_num=6)
+    grid = dynamic_grid((w, h), max_num=6, image_size=448)
+    ref = opp.dynamic_tiles(a, grid)
+    assert tuple(out.shape) == ref.shape and np.array_equal(out.cpu().numpy(), ref)
+    from PIL import Image
+    via = process_dynamic_image(Image.fromarray(a), proc, max_num=6, image_size=448)
+    assert torch.equal(via, out)
+    with pytest.raises(ValueError):
+        proc.process_dynamic(a, image_size=336)

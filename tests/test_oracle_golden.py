@@ -61,6 +61,36 @@ def test_tower_wrapper_select(sel, feat):
     assert rel_err(f16.float(), g["feats_half"]) < 2e-3
 
 
+def test_vit300m_tiny_layers():
+    """InternViT-300M variant (LayerNorm, 64-wide heads, no q/k norm) against the reference's intern_vit_300m modeling file"""
+    from omchat_amd.config import tiny300m
+    import torch.nn.functional as F
+    g = golden("vit300m_tiny")
+    cfg = tiny300m()
+    w = _sub(sd_torch(cfg, int(g["seed"]), synth.TOWER), TOWER_PFX)
+    assert "encoder.layers.0.norm1.bias" in w and "encoder.layers.0.attn.q_norm.weight" not in w
+    px = T(g["pixels"])
+    assert rel_err(oracle.vit_embeddings(px, w, 14, 56), g["hs0"]) < FP32_TOL
+    hs = oracle.vit_encoder(T(g["hs0"]), w, 2, cfg.vision["num_attention_heads"])
+    assert rel_err(hs[1], g["hs1"]) < FP32_TOL and rel_err(hs[2], g["hs2"]) < FP32_TOL
+    n1 = F.layer_norm(T(g["hs0"]), (256,), w["encoder.layers.0.norm1.weight"], w["encoder.layers.0.norm1.bias"], 1e-6)
+    assert rel_err(n1, g["l0_norm1"]) < 1e-6
+    assert rel_err(oracle.vit_attention(n1, w, "encoder.layers.0.", 4), g["l0_attn"]) < FP32_TOL
+
+
+@pytest.mark.parametrize("sel,feat", [(-1, "patch"), (-2, "cls_patch")])
+def test_tower300m_wrapper_select(sel, feat):
+    from omchat_amd.config import tiny300m
+    g = golden(f"tower300m_wrapper_L{sel}_{feat}")
+    cfg = tiny300m()
+    w = _sub(sd_torch(cfg, 0, synth.TOWER), TOWER_PFX)
+    f32 = oracle.vision_tower_forward(T(g["pixels"]), w, cfg.vision, sel, feat)
+    assert f32.shape == g["feats_half"].shape and rel_err(f32, g["feats_half"]) < 3e-3
+    wh = {k: v.half() for k, v in w.items()}
+    f16 = oracle.vision_tower_forward(T(g["pixels"]).half(), wh, cfg.vision, sel, feat)
+    assert f16.dtype == torch.float16 and rel_err(f16.float(), g["feats_half"]) < 2e-3
+
+
 def test_vit_embed_bicubic_resize():
     g = golden("vit_embed_resize")
     cfg = tiny(image_size=112)

@@ -82,3 +82,27 @@ def test_oracle_anyres_is_the_reference_pipeline(w, h):
     tiles, best = process_anyres_image(Image.fromarray(a), proc, [tuple(p) for p in PINS], return_best_res=True)
     got = opp.anyres_tiles(a, best)
     assert got.shape == tuple(tiles.shape) and np.array_equal(got, tiles.numpy())
+
+
+def test_dynamic_grid_and_oracle_match_the_reference_recipe():
+    """dynamic_preprocess (mm_utils.py:276-312) restated: grid choice on a sweep of sizes, and oracle.dynamic_tiles == the PIL
+    pipeline (resize -> crop -> CLIPImageProcessor) with the thumbnail first"""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    from omchat_amd.mm_utils import dynamic_grid, dynamic_preprocess, process_dynamic_image
+    assert [dynamic_grid(s, max_num=6) for s in [(448, 448), (900, 448), (448, 1400), (1000, 700), (3000, 1000), (100, 100)]] == \
+        [(1, 1), (2, 1), (1, 3), (3, 2), (3, 1), (1, 1)]
+    # expected grids captured from the reference's find_closest_aspect_ratio (imported in the build container); the tie rule
+    # (:336-338) moves large pictures to the larger grid of the same aspect
+    assert dynamic_grid((1000, 1000), max_num=6) == (2, 2) and dynamic_grid((1000, 1000), max_num=12) == (3, 3)
+    assert dynamic_grid((2000, 1000), max_num=6) == (2, 1) and dynamic_grid((2000, 1000), max_num=12) == (4, 2)
+    proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
+                              image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)
+    for w, h in [(700, 400), (448, 448), (300, 900)]:
+        a = np.random.default_rng(w + 3 * h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img = Image.fromarray(a)
+        grid = dynamic_grid((w, h), max_num=6, image_size=448)
+        pil = dynamic_preprocess(img, max_num=6, image_size=448, use_thumbnail=True)
+        assert len(pil) == grid[0] * grid[1] + (grid[0] * grid[1] != 1) and all(p.size == (448, 448) for p in pil)
+        tiles = process_dynamic_image(img, proc, max_num=6, image_size=448)
+        assert np.array_equal(opp.dynamic_tiles(a, grid), tiles.numpy())
