@@ -1,4 +1,4 @@
-// Weight-streaming skinny GEMM for decode:  Y[b,N] = epi(X[b,K] @ W[N,K]^T), b <= 16.  HBM-bound: every weight byte
+// Weight-streaming skinny GEMM for decode:  Y[b,N] = epi(X[b,K] @ W[N,K]^T), b <= 32 (one or two 16-row batch tiles).  HBM-bound: every weight byte
 // is read exactly once, straight from global memory into MFMA A-operand registers (no LDS round trip:
 // cdna_hip_programming.md §5 "GEMV / M <= 16 decode weights").
 //
@@ -19,10 +19,11 @@ struct GemvP {
   const float* w_scale;
 };
 
-template <typename T, int NTILE, int N, int WAVES, bool NTL>
-__device__ __forceinline__ void gemv_group(f32x4 (&acc)[NTILE], const T* const (&wrow)[NTILE], const T* xrow, int k0, bool xvalid) {
+template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
+__device__ __forceinline__ void gemv_group(f32x4 (&acc)[NTILE][NB], const T* const (&wrow)[NTILE], const T* const (&xrow)[NB], int k0,
+                                           const bool (&xvalid)[NB]) {
   typedef typename V8<T>::type frag_t;
-  frag_t wf[N][NTILE][2], xf[N][2];
+  frag_t wf[N][NTILE][2], xf[N][NB][2];
 #pragma unroll
   for (int u = 0; u < N; ++u) {
     const int k = k0 + u * WAVES * 64;
@@ -36,35 +37,43 @@ __device__ __forceinline__ void gemv_group(f32x4 (&acc)[NTILE], const T* const (
         wf[u][t][1] = ld8<T>(wrow[t] + k + 32);
       }
     }
-    xf[u][0] = ld8<T>(xrow + k);
-    xf[u][1] = ld8<T>(xrow + k + 32);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      xf[u][nb][0] = ld8<T>(xrow[nb] + k);
+      xf[u][nb][1] = ld8<T>(xrow[nb] + k + 32);
+    }
   }
   frag_t zero;
 #pragma unroll
   for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
 #pragma unroll
   for (int u = 0; u < N; ++u) {
-    if (!xvalid) { xf[u][0] = zero; xf[u][1] = zero; }
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      acc[t] = mfma16(wf[u][t][0], xf[u][0], acc[t]);
-      acc[t] = mfma16(wf[u][t][1], xf[u][1], acc[t]);
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!xvalid[nb]) { xf[u][nb][0] = zero; xf[u][nb][1] = zero; }
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        acc[t][nb] = mfma16(wf[u][t][0], xf[u][nb][0], acc[t][nb]);
+        acc[t][nb] = mfma16(wf[u][t][1], xf[u][nb][1], acc[t][nb]);
+      }
     }
   }
 }
 
-template <typename T, int NTILE, int N, int WAVES, bool NTL>
-__device__ __forceinline__ void gemv_tail(int rem, f32x4 (&acc)[NTILE], const T* const (&wrow)[NTILE], const T* xrow, int k0, bool xvalid) {
+template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
+__device__ __forceinline__ void gemv_tail(int rem, f32x4 (&acc)[NTILE][NB], const T* const (&wrow)[NTILE], const T* const (&xrow)[NB], int k0,
+                                          const bool (&xvalid)[NB]) {
   if constexpr (N > 0) {
-    if (rem == N) gemv_group<T, NTILE, N, WAVES, NTL>(acc, wrow, xrow, k0, xvalid);
-    else gemv_tail<T, NTILE, N - 1, WAVES, NTL>(rem, acc, wrow, xrow, k0, xvalid);
+    if (rem == N) gemv_group<T, NTILE, N, WAVES, NTL, NB>(acc, wrow, xrow, k0, xvalid);
+    else gemv_tail<T, NTILE, N - 1, WAVES, NTL, NB>(rem, acc, wrow, xrow, k0, xvalid);
   }
 }
 
-template <typename T, int NTILE, int EPI, int GV_WAVES = 8, int GV_UNROLL = 4, bool NTL = false>
+// NB = batch tiles of 16 rows sharing every weight fragment (b <= 16 * NB): the weights are still read exactly once
+template <typename T, int NTILE, int EPI, int GV_WAVES = 8, int GV_UNROLL = 4, bool NTL = false, int NB = 1>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   typedef typename V8<T>::type frag_t;
-  __shared__ float red[GV_WAVES][NTILE][256];
+  __shared__ float red[GV_WAVES][NTILE * NB][256];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,12 +88,19 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
     int r = n0 + t * 16 + fr; r = r < p.N ? r : p.N - 1;
     wrow[t] = W + (size_t)r * p.ldw + fg * 8;
   }
-  const bool xvalid = fr < p.b;
-  const T* xrow = X + (size_t)(xvalid ? fr : 0) * p.ldx + fg * 8;
-
-  f32x4 acc[NTILE];
+  bool xvalid[NB];
+  const T* xrow[NB];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int nb = 0; nb < NB; ++nb) {
+    xvalid[nb] = nb * 16 + fr < p.b;
+    xrow[nb] = X + (size_t)(xvalid[nb] ? nb * 16 + fr : 0) * p.ldx + fg * 8;
+  }
+
+  f32x4 acc[NTILE][NB];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // K slice of this workgroup (blockIdx.y of ksplit): chunks [c_lo, c_hi)
   const int nchunk_all = p.K / 64;
@@ -96,60 +112,65 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
   const int n_w = first < nchunk ? (nchunk - first + GV_WAVES - 1) / GV_WAVES : 0;
   int g = 0;
   for (; g + GV_UNROLL <= n_w; g += GV_UNROLL)
-    gemv_group<T, NTILE, GV_UNROLL, GV_WAVES, NTL>(acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
-  gemv_tail<T, NTILE, GV_UNROLL - 1, GV_WAVES, NTL>(n_w - g, acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
+    gemv_group<T, NTILE, GV_UNROLL, GV_WAVES, NTL, NB>(acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
+  gemv_tail<T, NTILE, GV_UNROLL - 1, GV_WAVES, NTL, NB>(n_w - g, acc, wrow, xrow, (first + g * GV_WAVES) * 64, xvalid);
 
-  // acc[t][r] = Y^T[n = n0 + t*16 + 4*fg + r][batch = fr]
+  // acc[t][nb][r] = Y^T[n = n0 + t*16 + 4*fg + r][batch = 16*nb + fr]
 #pragma unroll
   for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][t][(fg * 4 + r) * 16 + fr] = acc[t][r];
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t * NB + nb][(fg * 4 + r) * 16 + fr] = acc[t][nb][r];
   __syncthreads();
   if (wave != 0) return;
 
   // wave 0: lane -> 4 (n, batch) pairs per tile; element e = lane + 64*i : n_local = e >> 4, batch = e & 15
-  float v[NTILE][4];
-#pragma unroll
-  for (int t = 0; t < NTILE; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < GV_WAVES; ++w) s += red[w][t][lane + 64 * i];
-      v[t][i] = s;
-    }
   const T* bias = (const T*)p.bias;
   const T* R = (const T*)p.resid;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = lane + 64 * i, nl = e >> 4, bi = e & 15;
-    if (bi >= p.b) continue;
-    if constexpr (EPI == EPI_PARTIAL) {
-      // raw fp32 K-slice sums, layout [ksplit][b][ldy]; the consumer (resid_rmsnorm) adds the slices in a fixed order
+  for (int nb = 0; nb < NB; ++nb) {
+    float v[NTILE][4];
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        const int n = n0 + t * 16 + nl;
-        if (n < p.N) ((float*)p.Y)[((size_t)blockIdx.y * p.b + bi) * p.ldy + n] = v[t][i];
-      }
-    } else if constexpr (EPI == EPI_SWIGLU) {
-      // tile 0 = 16 gate rows, tile 1 = the matching 16 up rows
-      const int n = (n0 >> 1) + nl;
-      if (n0 + 16 + nl < p.N) {
-        const float g = rnd<T>(v[0][i]), u = rnd<T>(v[1][i]);
-        ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(rnd<T>(silu(g)) * u);
-      }
-    } else {
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        const int n = n0 + t * 16 + nl;
-        if (n >= p.N) continue;
-        float y = v[t][i] + (bias ? tof(bias[n]) : 0.f);
-        if (p.out_f32) {
-          ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
-        } else {
-          y = rnd<T>(y);
-          if constexpr (EPI == EPI_RESID) y = tof(R[(size_t)bi * p.ldr + n]) + y;
-          ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < GV_WAVES; ++w) s += red[w][t * NB + nb][lane + 64 * i];
+        v[t][i] = s;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i, nl = e >> 4, bi = nb * 16 + (e & 15);
+      if (bi >= p.b) continue;
+      if constexpr (EPI == EPI_PARTIAL) {
+        // raw fp32 K-slice sums, layout [ksplit][b][ldy]; the consumer (resid_rmsnorm) adds the slices in a fixed order
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          const int n = n0 + t * 16 + nl;
+          if (n < p.N) ((float*)p.Y)[((size_t)blockIdx.y * p.b + bi) * p.ldy + n] = v[t][i];
+        }
+      } else if constexpr (EPI == EPI_SWIGLU) {
+        // tile 0 = 16 gate rows, tile 1 = the matching 16 up rows
+        const int n = (n0 >> 1) + nl;
+        if (n0 + 16 + nl < p.N) {
+          const float g = rnd<T>(v[0][i]), u = rnd<T>(v[1][i]);
+          ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(rnd<T>(silu(g)) * u);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          const int n = n0 + t * 16 + nl;
+          if (n >= p.N) continue;
+          float y = v[t][i] + (bias ? tof(bias[n]) : 0.f);
+          if (p.out_f32) {
+            ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
+          } else {
+            y = rnd<T>(y);
+            if constexpr (EPI == EPI_RESID) y = tof(R[(size_t)bi * p.ldr + n]) + y;
+            ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
+          }
         }
       }
     }
@@ -375,6 +396,14 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     OM_LAUNCH_CHECK();
     return 0;
   }
+  if (a.b > 16) {       // two batch tiles per weight fragment: weights still stream once for b <= 32
+    if (a.epi == EPI_PARTIAL) hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_PARTIAL, 8, 4, false, 2>), dim3(cdiv(a.N, 16), ks), dim3(512), 0, s, p);
+    else if (a.epi == EPI_SWIGLU) hipLaunchKernelGGL((gemv_kernel<T, 2, EPI_SWIGLU, 8, 4, false, 2>), dim3(cdiv(a.N, 32)), dim3(512), 0, s, p);
+    else if (a.epi == EPI_RESID) hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_RESID, 8, 4, false, 2>), dim3(cdiv(a.N, 16)), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemv_kernel<T, 2, EPI_NONE, 8, 4, false, 2>), dim3(cdiv(a.N, 32)), dim3(512), 0, s, p);
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.epi == EPI_PARTIAL) {
     if (a.K / 64 / ks <= 32)
       hipLaunchKernelGGL((gemv_kernel<T, 1, EPI_PARTIAL, 4, 8>), dim3(cdiv(a.N, 16), ks), dim3(256), 0, s, p);
@@ -443,7 +472,7 @@ int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void*
 }
 
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
-  OM_CHECK(a.b >= 1 && a.b <= 16, "batch must be 1..16 per call");
+  OM_CHECK(a.b >= 1 && a.b <= 32, "batch must be 1..32 per call");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
   OM_CHECK(!a.w_scale || a.b == 1, "fp8 weights: batch 1 only");
   OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU || a.epi == EPI_PARTIAL, "bad epilogue");

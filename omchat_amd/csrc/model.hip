@@ -632,8 +632,8 @@ extern "C" int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, c
 // ---------------------------------------------------------------------------------------------------------
 static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s, bool fp8 = false) {
   const int H = ctx->c.t_hidden, V = ctx->c.t_vocab;
-  for (int r0 = 0; r0 < n; r0 += 16) {
-    const int R = std::min(16, n - r0);
+  for (int r0 = 0; r0 < n; r0 += 32) {
+    const int R = std::min(32, n - r0);
     GemvArgs g{(const char*)hidden + (size_t)r0 * H * 2, H, ctx->t_lm, H, logits + (size_t)r0 * V, V, R, V, H, nullptr, nullptr, 0, EPI_NONE, 1};
     if (fp8 && n == 1) { g.W = ctx->t_lm8; g.w_scale = ctx->t_lm8_s; }
     TRY(launch_gemv(ctx->dt, g, s));
@@ -783,8 +783,8 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   const bool f8 = ctx->fp8_decode && b == 1 && ctx->tp_size == 1;
   auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi,
                   const void* W8 = nullptr, const float* sc = nullptr) -> int {
-    for (int r0 = 0; r0 < b; r0 += 16) {
-      const int R = std::min(16, b - r0);
+    for (int r0 = 0; r0 < b; r0 += 32) {
+      const int R = std::min(32, b - r0);
       GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
                  resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
       if (f8 && W8) { g.W = W8; g.w_scale = sc; }
@@ -794,12 +794,12 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   };
   // split-K over workgroups: fp32 slices [ks][b][H], summed by the fused residual + RMSNorm kernel
   auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks, const void* W8 = nullptr, const float* sc = nullptr) -> int {
-    OM_CHECK(b <= 16, "split-K decode path handles b <= 16");
+    OM_CHECK(b <= 32, "split-K decode path handles b <= 32");
     GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
     if (f8 && W8) { g.W = W8; g.w_scale = sc; }
     return launch_gemv(ctx->dt, g, s);
   };
-  const bool fused = ctx->tp_size == 1 && b <= 16;
+  const bool fused = ctx->tp_size == 1 && b <= 32;
   // K slices: batch 1 (whole-row streaming form) wants <= 8 chunks of 512 per slice and >= ~2500 waves in the grid;
   // the MFMA form (b > 1) wants ~2-3 workgroups per CU
   // (tools/tune_rows.hip: down_proj 18944 -> 8 slices 23.3 us vs 5 slices 27.6 us; o_proj is latency-bound, 1-3 slices alike)

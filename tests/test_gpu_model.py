@@ -249,3 +249,31 @@ def test_engine_argument_errors(gpu_lib):
     with pytest.raises(ValueError):
         e.load_tensor("no.such.tensor", np.ones(7, np.float32))
     e.close()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batched_decode_beyond_16_sequences(gpu_lib, dt):
+    """b = 20 right-padded sequences (BASELINE configs[2] decodes 32 at once): one weight pass per step, every row equals
+    the oracle run of that sequence alone"""
+    cfg = tiny()
+    b = 20
+    e = Engine(cfg, dtype=dt, max_seq=48, max_batch=b, vision=False)
+    e.load_state_dict(synth.state_dict(cfg, 5))
+    x = rnd(torch.randn(b, 16, 256, generator=torch.Generator().manual_seed(0)), dt)
+    lens = [16 - (i % 5) for i in range(b)]
+    logits, _ = e.prefill(x, lengths=lens); sync()
+    toks = torch.arange(3, 3 + b)
+    nxt, lg = e.decode_step(toks, want_logits=True); sync()
+    nxt2, lg2 = e.decode_step(nxt, want_logits=True); sync()
+    sd = sd32(cfg, 5)
+    for i in (0, 7, 15, 16, 19):
+        cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+        h = oracle.qwen2_model(x[i:i + 1, :lens[i]], sd, cfg.text, cache)
+        assert rel(logits[i], oracle.lm_head(h, sd)[0, -1]) < TOL_DEEP[dt]
+        ref = oracle.decode_step(torch.tensor([[int(toks[i])]]), sd, cfg.text, cache)[0, 0]
+        assert rel(lg[i], ref) < TOL_DEEP[dt], (i, rel(lg[i], ref))
+        assert int(nxt[i]) == int(torch.argmax(lg[i]))
+        ref2 = oracle.decode_step(torch.tensor([[int(nxt[i])]]), sd, cfg.text, cache)[0, 0]
+        assert rel(lg2[i], ref2) < TOL_DEEP[dt]
+    assert e.kv_lengths(b) == [n + 2 for n in lens]
+    e.close()

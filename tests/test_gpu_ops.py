@@ -143,7 +143,8 @@ def test_gemm_in_place_residual(gpu_lib, dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("form", ["auto", "mfma"])
-@pytest.mark.parametrize("b,N,K", [(1, 100, 256), (5, 4608, 3584), (16, 320, 512), (1, 3584, 18944), (3, 160, 64), (1, 37888, 3584), (1, 96, 2368)])
+@pytest.mark.parametrize("b,N,K", [(1, 100, 256), (5, 4608, 3584), (16, 320, 512), (1, 3584, 18944), (3, 160, 64), (1, 37888, 3584), (1, 96, 2368),
+                                      (17, 320, 512), (32, 4608, 3584), (24, 160, 18944)])       # two batch tiles per weight fragment
 def test_gemv(gpu_lib, dt, form, b, N, K):
     """b == 1 takes the whole-row streaming (v_dot2) form unless the MFMA form is forced; both must agree with the reference"""
     gpu_lib.omchat_op_set_tuning(1, 1 if form == "mfma" else 0)
