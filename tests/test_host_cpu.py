@@ -230,3 +230,23 @@ def test_keywords_stopping_criteria_semantics():
     assert c(torch.tensor([[9, 9, 9, 97, 98, 50]]), None)                       # substring of the decoded tail
     assert not c(torch.tensor([[9, 9, 9, 97, 50, 98]]), None)
     assert not c(torch.tensor([[9, 9, 9, 35, 35, 35], [9, 9, 9, 1, 2, 3]]), None)   # every row must hit
+
+
+def test_fast_gelu_formula_accuracy():
+    """csrc/common.h gelu_erf (erfc through t * exp(-z^2 + P9(t))) restated in numpy float32 against float64 erf GELU:
+    far below the rounding of a 16-bit output, and the negative tail keeps its relative accuracy"""
+    from scipy.special import erfc
+    x = np.linspace(-6, 6, 400001).astype(np.float32)
+    z = np.abs(x) * np.float32(0.70710678118654752440)
+    t = np.float32(1) / (np.float32(1) + np.float32(0.5) * z)
+    c = [-1.26551223, 1.00002368, 0.37409196, 0.09678418, -0.18628806, 0.27886807, -1.13520398, 1.48851587, -0.82215223, 0.17087277]
+    p = np.float32(c[9])
+    for k in range(8, -1, -1):
+        p = (p * t + np.float32(c[k])).astype(np.float32)
+    e = (np.float32(0.5) * t * np.exp((-z * z + p).astype(np.float32))).astype(np.float32)
+    got = (x * np.where(x >= 0, np.float32(1) - e, e)).astype(np.float64)
+    xd = x.astype(np.float64)
+    ref = xd * 0.5 * erfc(-xd / np.sqrt(2))               # x * Phi(x) without cancellation in the tail
+    nz = np.abs(ref) > 0
+    assert np.abs(got - ref).max() < 5e-7
+    assert (np.abs(got - ref)[nz] / np.abs(ref)[nz]).max() < 1e-5
