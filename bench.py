@@ -31,6 +31,8 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--graph", action="store_true", help="replay each decode step as one captured hipGraph instead of ~230 eager launches "
+                    "(measured SLOWER on ROCm 7.2 / MI355X: 3.21 vs 2.96 ms per token, so it is off by default)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the (untimed) weight-only fp8 decode measurement")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -147,6 +149,8 @@ def main():
     eng = Engine(cfg, dtype=a.dtype, max_seq=S + a.gen + 8, max_batch=1, max_tiles=n_tiles, max_prefill_rows=S,
                  tp_rank=rank, tp_size=world, comm=comm)
     eng.fill_synthetic(0)
+    if a.graph and world == 1:
+        eng.enable_decode_graph(True)      # one graph launch per token; every 8th step stays eager for the HIP-event brackets
 
     # synthetic inputs, resident in HBM before the timed region
     px = torch.from_numpy(synth.pixels(n_tiles, cfg.vision["image_size"], 0)).to("cuda", eng.torch_dtype)
@@ -256,6 +260,7 @@ def main():
         "decode_hbm_frac": (14.14e9 / world + 57344.0 * S) / (med(dec_ms) / 1e3 / (a.gen - 1)) / 1e9 / HBM_PEAK_GBS if not a.tiny else None,
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
+        "decode_graph": eng.decode_graph_stats() if (a.graph and world == 1) else None,
     }
     # weight-only fp8 decode (row f-2 / configs[4]), outside the timed region: same prompt, 64 greedy tokens on the e4m3 replica
     if world == 1 and not a.no_fp8:

@@ -114,6 +114,18 @@ int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, vo
 int omchat_greedy(omchat_ctx* ctx, const float* logits, int b, int32_t* next_tokens, void* stream);
 int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
 
+/* ---- decode step as a hipGraph ------------------------------------------------------------------------------------ */
+/* With on != 0, omchat_decode_step on a TP = 1 context (b <= 32) replays one captured graph per step instead of issuing its
+ * ~230 kernel launches (same kernels, same results: tests compare bit for bit).  Captured on a context-owned stream that is
+ * ordered after / before the caller's `stream` with events; re-captured when a sequence outgrows the captured split-KV grid
+ * (every 1024 tokens) or the batch size / fp8 mode changes.  While profiling is enabled every 8th step runs eagerly so the
+ * HIP-event brackets still sample the timed region.
+ * Measured on ROCm 7.2 / MI355X (bench.py --graph): replay is SLOWER than the eager stream (3.21 vs 2.96 ms per token at
+ * TP = 1: graph nodes are dispatched with a barrier packet each), so it is opt-in -- useful when the host, not the GPU,
+ * bounds the step (small per-rank kernels under tensor parallelism, a busy Python thread). */
+int omchat_enable_decode_graph(omchat_ctx* ctx, int on);
+int omchat_decode_graph_stats(omchat_ctx* ctx, long* steps, long* replays, long* captures);
+
 /* ---- weight-only fp8 for decode (BASELINE configs[4]) -------------------------------------------- */
 /* Builds (once) an OCP e4m3 replica of the decoder weights that a decode step streams (fused qkv, o, gate|up, down,
  * lm_head): per output row scale = absmax / 448, W8 = e4m3_rne(W / scale).  With on != 0, batch-1 decode steps on a

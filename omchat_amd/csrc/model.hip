@@ -91,6 +91,17 @@ struct omchat_ctx {
   std::vector<DecLayer8> dl8;
   void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
   bool fp8_decode = false;
+  // decode step as a hipGraph (omchat_enable_decode_graph): ~230 launches per token replayed as one graph launch.  Captured on a
+  // context-owned stream (the caller's may be the legacy null stream, which cannot capture) with context-owned token / logits
+  // buffers so that every kernel argument is replay-invariant; the split-KV attention grid is captured for `cap_len` keys
+  // (empty splits exit at once) and the graph is re-captured when a sequence outgrows it.
+  struct DecodeGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int cap_len = 0; };
+  std::unordered_map<int, DecodeGraph> graphs;      // key = b * 2 + fp8
+  bool graph_on = false;
+  hipStream_t graph_stream = nullptr;
+  hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
+  int32_t *d_tok_in = nullptr, *d_tok_out = nullptr;
+  long graph_steps = 0, graph_replays = 0, graph_captures = 0;
   void *v_cls = nullptr, *v_pos = nullptr, *v_wpatch = nullptr, *v_bpatch = nullptr;
   std::vector<VitLayer> vl;
   void *p_w0 = nullptr, *p_b0 = nullptr, *p_w2 = nullptr, *p_b2 = nullptr;
@@ -372,6 +383,13 @@ extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
   if (!ctx) return;
   for (void* p : ctx->allocs) hipFree(p);
   for (auto& pr : ctx->prof) for (hipEvent_t e : pr.ev) hipEventDestroy(e);
+  for (auto& kv : ctx->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  if (ctx->graph_ev_in) (void)hipEventDestroy(ctx->graph_ev_in);
+  if (ctx->graph_ev_out) (void)hipEventDestroy(ctx->graph_ev_out);
+  if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
   if (ctx->stage_f32) hipFree(ctx->stage_f32);
   if (ctx->stage_t) hipFree(ctx->stage_t);
   delete ctx;
@@ -765,15 +783,10 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
   return 0;
 }
 
-extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream) {
-  OM_CHECK(ctx && tokens, "null argument");
+// One decode step on stream s.  Lmax = upper bound of the key count (sizes the split-KV grid; the kernels read the true
+// lengths from d_len).  Every argument is a context pointer or a step-invariant scalar when called for graph capture.
+static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, float* logits, int32_t* next_tokens, hipStream_t s, bool allow_prof) {
   const omchat_config& c = ctx->c;
-  OM_CHECK(c.t_layers > 0, "context has no decoder");
-  OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
-  int Lmax = 0;
-  for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
-  OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
-  hipStream_t s = (hipStream_t)stream;
   const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   const bool lead = ctx->tp_rank == 0;
   void* x = ctx->tw_x;
@@ -840,7 +853,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
     // HIP-event bracket on ONE layer per token only: each event record costs ~1-2 us of launch-stream time, and 56 of them
     // per token would themselves slow the measured decode by a few per cent
-    const bool mark = i == c.t_layers / 2;
+    const bool mark = allow_prof && i == c.t_layers / 2;
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu));
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
@@ -862,6 +875,80 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
+  return 0;
+}
+
+static void destroy_graph(omchat_ctx::DecodeGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g = omchat_ctx::DecodeGraph{};
+}
+
+extern "C" int omchat_enable_decode_graph(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null ctx");
+  OM_CHECK(ctx->c.t_layers > 0, "context has no decoder");
+  if (on && !ctx->graph_stream) {
+    OM_HIP(hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking));
+    OM_HIP(hipEventCreateWithFlags(&ctx->graph_ev_in, hipEventDisableTiming));
+    OM_HIP(hipEventCreateWithFlags(&ctx->graph_ev_out, hipEventDisableTiming));
+    TRY(ctx->alloc((void**)&ctx->d_tok_in, (size_t)ctx->c.max_batch * 4));
+    TRY(ctx->alloc((void**)&ctx->d_tok_out, (size_t)ctx->c.max_batch * 4));
+  }
+  ctx->graph_on = on != 0;
+  return 0;
+}
+
+extern "C" int omchat_decode_graph_stats(omchat_ctx* ctx, long* steps, long* replays, long* captures) {
+  OM_CHECK(ctx, "null ctx");
+  if (steps) *steps = ctx->graph_steps;
+  if (replays) *replays = ctx->graph_replays;
+  if (captures) *captures = ctx->graph_captures;
+  return 0;
+}
+
+extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && tokens, "null argument");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
+  int Lmax = 0;
+  for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
+  OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
+  hipStream_t s = (hipStream_t)stream;
+  ctx->graph_steps++;
+  // graph replay needs replay-invariant arguments: single-GPU fused path only; with profiling on, every 8th step runs eagerly
+  // so that the HIP-event brackets of the dominant kernel are still recorded inside the timed region
+  const bool graph = ctx->graph_on && ctx->tp_size == 1 && b <= 32 && !(ctx->prof_on && ctx->graph_steps % 8 == 0);
+  if (!graph) {
+    TRY(decode_body(ctx, tokens, b, Lmax, logits, next_tokens, s, true));
+  } else {
+    const bool f8 = ctx->fp8_decode && b == 1;
+    omchat_ctx::DecodeGraph& g = ctx->graphs[b * 2 + (f8 ? 1 : 0)];
+    hipStream_t gs = ctx->graph_stream;
+    OM_HIP(hipEventRecord(ctx->graph_ev_in, s));
+    OM_HIP(hipStreamWaitEvent(gs, ctx->graph_ev_in, 0));
+    OM_HIP(hipMemcpyAsync(ctx->d_tok_in, tokens, (size_t)b * 4, hipMemcpyDeviceToDevice, gs));
+    if (!g.exec || Lmax > g.cap_len) {
+      destroy_graph(g);
+      const int cap = std::min(c.max_seq, (Lmax + 1024 + 63) / 64 * 64);
+      OM_HIP(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+      const int rc = decode_body(ctx, ctx->d_tok_in, b, cap, ctx->tw_logits, ctx->d_tok_out, gs, false);
+      hipGraph_t graph_h = nullptr;
+      const hipError_t e = hipStreamEndCapture(gs, &graph_h);
+      if (rc) { if (graph_h) (void)hipGraphDestroy(graph_h); return rc; }
+      OM_HIP(e);
+      g.graph = graph_h;
+      OM_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+      g.cap_len = cap;
+      ctx->graph_captures++;
+    }
+    OM_HIP(hipGraphLaunch(g.exec, gs));
+    ctx->graph_replays++;
+    if (next_tokens) OM_HIP(hipMemcpyAsync(next_tokens, ctx->d_tok_out, (size_t)b * 4, hipMemcpyDeviceToDevice, gs));
+    if (logits) OM_HIP(hipMemcpyAsync(logits, ctx->tw_logits, (size_t)b * c.t_vocab * 4, hipMemcpyDeviceToDevice, gs));
+    OM_HIP(hipEventRecord(ctx->graph_ev_out, gs));
+    OM_HIP(hipStreamWaitEvent(s, ctx->graph_ev_out, 0));
+  }
   for (int i = 0; i < b; ++i) ctx->h_len[i] += 1;
   return 0;
 }

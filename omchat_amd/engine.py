@@ -94,6 +94,15 @@ class Engine:
         """Weight-only OCP e4m3 replica of the decode-streamed decoder weights (quantised on first call); batch-1 decode only."""
         check(self.lib.omchat_enable_fp8_decode(self.h, int(on)))
 
+    def enable_decode_graph(self, on=True):
+        """Replay each decode step as one hipGraph launch (TP = 1, b <= 32); same kernels and results as the eager step."""
+        check(self.lib.omchat_enable_decode_graph(self.h, int(on)))
+
+    def decode_graph_stats(self):
+        st, rp, cp = C.c_long(0), C.c_long(0), C.c_long(0)
+        check(self.lib.omchat_decode_graph_stats(self.h, C.byref(st), C.byref(rp), C.byref(cp)))
+        return dict(steps=st.value, replays=rp.value, captures=cp.value)
+
     def prof_enable(self, on=True):
         check(self.lib.omchat_prof_enable(self.h, int(on)))
 
