@@ -1,0 +1,16 @@
+# Final per-round evidence (run on the GPU box through gpurun):  bash tools/collect_profiles.sh <tag>
+# kernel stats (rocprofv3 --kernel-trace --stats), HBM traffic (two separate --pmc passes), the bench line with the CPU baseline.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${1:-r01_x}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --gen 32 --no-cpu-baseline --no-fp8 > $O/stats.json 2> $O/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 > $O/write.json 2> $O/write.err
+cd $R
+python3 tools/pmc_summary.py $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json      # the bench line below reads the newest profiles/*pmc_traffic.json
+python3 bench.py > $O/bench.json 2> $O/bench.err
+head -c 600 $O/bench.json; echo; head -12 $O/pmc_summary.txt
