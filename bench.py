@@ -220,7 +220,7 @@ def main():
         avg_s = ms / n / 1e3
         roof = {"bound": "hbm", "kernel": "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream)", "achieved": gu_bytes / avg_s / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"])     # <T, EPI_SWIGLU = 4, RR = 4, WAVES = 4> if (world == 1 and not a.tiny) else None,
+                "traffic": pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if (world == 1 and not a.tiny) else None,     # <T, EPI_SWIGLU=4, RR=4, WAVES=4>
                 "avg_launch_us": avg_s * 1e6, "launches": n, "bytes_per_launch": gu_bytes}
     ms, n = prof[_lib.PROF_PREFILL_GATEUP]
     roof_pre = None

@@ -211,6 +211,8 @@ int omchat_normalize_lut(const float mean[3], const float std_[3], float lut[768
 /* ---- tensor-parallel bootstrap (RCCL over xGMI; one process per GPU) -------------------------------------------- */
 int omchat_comm_unique_id(char id[128]);
 int omchat_comm_init(const char id[128], int rank, int size, void** comm_out);
+/* the collective of the tensor-parallel data path, callable on its own: in-place sum over the ranks of `comm` */
+int omchat_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream);
 void omchat_comm_destroy(void* comm);
 
 /* Test seam: replace the RCCL all-reduce of a tensor-parallel context by a caller-supplied function (sum over ranks,

@@ -79,6 +79,7 @@ _SIGS = {
     "omchat_normalize_lut": (_i, [_vp, _vp, _vp]),
     "omchat_comm_unique_id": (_i, [C.c_char_p]),
     "omchat_comm_init": (_i, [C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "omchat_comm_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
     "omchat_comm_destroy": (None, [_vp]),
 }
 EXPORTS = sorted(_SIGS)

@@ -1007,6 +1007,14 @@ extern "C" int omchat_comm_init(const char id[128], int rank, int size, void** c
   *comm_out = comm;
   return 0;
 }
+extern "C" int omchat_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream) {
+  OM_CHECK(comm && buf, "null argument");
+  const ncclDataType_t t = dtype == OMCHAT_F16 ? ncclFloat16 : dtype == OMCHAT_BF16 ? ncclBfloat16 : ncclFloat32;
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == OMCHAT_F32, "bad dtype");
+  ncclResult_t r = ncclAllReduce(buf, buf, count, t, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+  if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
+  return 0;
+}
 extern "C" void omchat_comm_destroy(void* comm) {
   if (comm) ncclCommDestroy((ncclComm_t)comm);
 }

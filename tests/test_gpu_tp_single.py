@@ -120,4 +120,11 @@ def test_rccl_bootstrap_single_rank(gpu_lib):
     comm = C.c_void_p()
     _lib.check(gpu_lib.omchat_comm_init(bytes(buf.raw), 0, 1, C.byref(comm)))
     assert comm.value
+    # the data-path collective on that communicator (sum over 1 rank = identity) for the three dtypes the path reduces
+    for dt, code in ((torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16), (torch.float32, _lib.F32)):
+        x = torch.randn(3584 * 3, device="cuda").to(dt)
+        y = x.clone()
+        _lib.check(gpu_lib.omchat_comm_allreduce(comm, C.c_void_p(y.data_ptr()), y.numel(), code, None))
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
     gpu_lib.omchat_comm_destroy(comm)
