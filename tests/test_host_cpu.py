@@ -250,3 +250,14 @@ def test_fast_gelu_formula_accuracy():
     nz = np.abs(ref) > 0
     assert np.abs(got - ref).max() < 5e-7
     assert (np.abs(got - ref)[nz] / np.abs(ref)[nz]).max() < 1e-5
+
+
+def test_entry_scripts_parse_and_bench_cli():
+    """bench.py / __graft_entry__.py / tools/*.py must at least compile (a stray edit once broke the bench line), and the bench CLI
+    keeps the driver's contract flags"""
+    import ast, glob, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + glob.glob(os.path.join(root, "tools", "*.py")):
+        ast.parse(open(f).read(), filename=f)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and all(flag in out.stdout for flag in ("--gpus", "--steps", "--warmup"))
