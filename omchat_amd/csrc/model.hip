@@ -152,6 +152,11 @@ struct omchat_ctx {
 
   omchat_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
+  // tensor-parallel prefill / ViT: the all-reduce of a row-parallel projection runs on its own stream, one row chunk behind the GEMM
+  static constexpr int AR_CHUNKS = 4;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_chunk[AR_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_comm_done = nullptr;
   int allreduce(void* buf, size_t count, hipStream_t s) {
     if (tp_size == 1) return 0;
     if (hook) return hook(hook_user, buf, count, dt, s);
@@ -374,6 +379,15 @@ extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_s
   omchat_ctx* ctx = new omchat_ctx();
   ctx->c = *cfg; ctx->dt = cfg->dtype; ctx->tp_rank = tp_rank; ctx->tp_size = tp_size; ctx->comm = (ncclComm_t)rccl_comm;
   int rc = build(ctx);
+  if (rc == 0 && tp_size > 1) {      // communication stream + events of the pipelined all-reduce (gemm_allreduce)
+    auto mk = [&]() -> int {
+      OM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+      for (auto& e : ctx->ev_chunk) OM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      OM_HIP(hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
+      return 0;
+    };
+    rc = mk();
+  }
   if (rc) { omchat_ctx_destroy(ctx); return rc; }
   *out = ctx;
   return 0;
@@ -390,6 +404,9 @@ extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
   if (ctx->graph_ev_in) (void)hipEventDestroy(ctx->graph_ev_in);
   if (ctx->graph_ev_out) (void)hipEventDestroy(ctx->graph_ev_out);
   if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
+  for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->stage_f32) hipFree(ctx->stage_f32);
   if (ctx->stage_t) hipFree(ctx->stage_t);
   delete ctx;
@@ -459,6 +476,38 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
+int g_ar_min_rows = 1024;      // rows from which a projection is pipelined in 2 (x3: 4) chunks; tests lower it (omchat_op_set_tuning key 4)
+void model_set_ar_min_rows(int v) { g_ar_min_rows = v > 8 ? v : 8; }
+
+// Row-parallel projection (proj / fc2 / o_proj / down_proj under tensor parallelism): Y = epi(A W^T) holds this rank's partial
+// sums and is all-reduced in place.  The rows are cut into up to AR_CHUNKS chunks of whole 256-row tiles; the all-reduce of
+// chunk i is enqueued on the communication stream behind an event and runs under the GEMM of chunk i + 1 (RCCL's ring kernels
+// take a few CUs, the GEMM the rest).  The launch stream resumes after the last chunk's all-reduce.
+static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* Y, int N, int M, int K, const void* bias,
+                          const void* ls, const void* resid, int epi, hipStream_t s) {
+  int nch = M >= 3 * g_ar_min_rows ? 4 : (M >= g_ar_min_rows ? 2 : 1);
+  if (!ctx->comm_stream) nch = 1;
+  if (nch == 1) {
+    TRY(gemm(ctx, A, lda, W, ldw, Y, N, M, N, K, bias, ls, resid, N, epi, s));
+    return ctx->allreduce(Y, (size_t)M * N, s);
+  }
+  const int align = g_ar_min_rows >= 256 ? 256 : 8;
+  const int rows_per = cdiv(cdiv(M, nch), align) * align;
+  int i = 0;
+  for (int r0 = 0; r0 < M; r0 += rows_per, ++i) {
+    const int rows = std::min(rows_per, M - r0);
+    char* y = (char*)Y + (size_t)r0 * N * 2;
+    TRY(gemm(ctx, (const char*)A + (size_t)r0 * lda * 2, lda, W, ldw, y, N, rows, N, K, bias, ls,
+             resid ? (const char*)resid + (size_t)r0 * N * 2 : nullptr, N, epi, s));
+    OM_HIP(hipEventRecord(ctx->ev_chunk[i], s));
+    OM_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_chunk[i], 0));
+    TRY(ctx->allreduce(y, (size_t)rows * N, ctx->comm_stream));
+  }
+  OM_HIP(hipEventRecord(ctx->ev_comm_done, ctx->comm_stream));
+  OM_HIP(hipStreamWaitEvent(s, ctx->ev_comm_done, 0));
+  return 0;
+}
+
 static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hipStream_t s, void** x_out) {
   const omchat_config& c = ctx->c;
   const int C = c.v_hidden, I = c.v_mlp, Cq = ctx->v_Cq, np = ctx->v_np, ntok = ctx->v_ntok, M = B * ntok;
@@ -503,8 +552,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID, s));
     } else {
-      TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, C, Cq, lead ? L.bproj : nullptr, L.ls1, lead ? x : nullptr, C, EPI_LS_RESID, s));
-      TRY(ctx->allreduce(y, (size_t)M * C, s));
+      TRY(gemm_allreduce(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, Cq, lead ? L.bproj : nullptr, L.ls1, lead ? x : nullptr, EPI_LS_RESID, s));
       std::swap(x, y);
     }
     TRY(norm(L.n2, L.n2b));
@@ -514,8 +562,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, EPI_LS_RESID, s));
     } else {
-      TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, y, C, M, C, I, lead ? L.b2 : nullptr, L.ls2, lead ? x : nullptr, C, EPI_LS_RESID, s));
-      TRY(ctx->allreduce(y, (size_t)M * C, s));
+      TRY(gemm_allreduce(ctx, ctx->vw_h, I, L.w2, I, y, C, M, I, lead ? L.b2 : nullptr, L.ls2, lead ? x : nullptr, EPI_LS_RESID, s));
       std::swap(x, y);
     }
   }
@@ -753,8 +800,7 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, x, H, rows, H, qd, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
-      TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, H, qd, nullptr, nullptr, lead ? x : nullptr, H, EPI_RESID, s));
-      TRY(ctx->allreduce(y, (size_t)rows * H, s));
+      TRY(gemm_allreduce(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, qd, nullptr, nullptr, lead ? x : nullptr, EPI_RESID, s));
       std::swap(x, y);
     }
     TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
@@ -764,8 +810,7 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
-      TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, H, It, nullptr, nullptr, lead ? x : nullptr, H, EPI_RESID, s));
-      TRY(ctx->allreduce(y, (size_t)rows * H, s));
+      TRY(gemm_allreduce(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, It, nullptr, nullptr, lead ? x : nullptr, EPI_RESID, s));
       std::swap(x, y);
     }
   }

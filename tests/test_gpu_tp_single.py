@@ -111,6 +111,47 @@ def test_tp2_on_one_gpu_equals_tp1(gpu_lib, dt, q, kv, hv):
         e.close()
 
 
+@pytest.mark.parametrize("min_rows", [8, 16])
+def test_tp2_with_pipelined_allreduce_chunks(gpu_lib, min_rows):
+    """the row-parallel projections cut into 2 / 4 row chunks with the all-reduce on the communication stream (gemm_allreduce):
+    same results as the unchunked TP run, and more all-reduce calls"""
+    cfg = tiny(q_heads=4, kv_heads=2, heads_v=2)
+    sd = synth.state_dict(cfg, 13)
+    px = T32(synth.pixels(2, 56, 1))
+    ids = torch.tensor([[3, -200, 17, -200, 19, 20]])
+
+    def run_all(knob):
+        gpu_lib.omchat_op_set_tuning(4, knob)
+        grp = Group(2)
+        engines, hooks = [], []
+        for r in range(2):
+            e = Engine(cfg, dtype="bf16", max_seq=128, max_batch=1, max_tiles=2, tp_rank=r, tp_size=2, comm=C.c_void_p(1))
+            h = grp.hook_for(r)
+            _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+            e.load_state_dict(sd)
+            engines.append(e); hooks.append(h)
+
+        def run(r):
+            e = engines[r]
+            feats = e.encode_images(px)
+            embeds, lengths, _ = e.splice(ids, None, feats)
+            logits, _ = e.prefill(embeds, lengths)
+            torch.cuda.synchronize()
+            return feats.float().cpu(), logits.float().cpu()
+        res = _run_ranks(run, 2)
+        for e in engines:
+            e.close()
+        return res, grp.calls
+    try:
+        base, calls0 = run_all(1 << 20)
+        chunked, calls1 = run_all(min_rows)
+    finally:
+        gpu_lib.omchat_op_set_tuning(4, 1024)
+    assert calls1 > calls0
+    for r in range(2):
+        assert torch.equal(base[r][0], chunked[r][0]) and torch.equal(base[r][1], chunked[r][1])
+
+
 def test_rccl_bootstrap_single_rank(gpu_lib):
     """omchat_comm_unique_id / omchat_comm_init / omchat_comm_destroy through the ctypes binding (world of 1: the multi-GPU
     RCCL data path itself is exercised by `bench.py --gpus N` under torchrun)"""
