@@ -298,14 +298,14 @@ def main():
         res["cpu_baseline"] = cpu_baseline(cfg, S, a.gen, n_tiles)
         from PIL import Image
         from transformers import CLIPImageProcessor
-        from omchat_amd.mm_utils import process_anyres_image
+        from oracle.preproc import pil_process_anyres_image      # the reference's PIL recipe (checker side), timed as the CPU baseline
         cp = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
                                 image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)
         img = Image.fromarray(rgb)
-        process_anyres_image(img, cp, pins)
+        pil_process_anyres_image(img, cp, pins)
         t0 = time.perf_counter()
         for _ in range(3):
-            process_anyres_image(img, cp, pins)
+            pil_process_anyres_image(img, cp, pins)
         res["cpu_baseline"]["frontend_ms"] = (time.perf_counter() - t0) / 3 * 1e3
     print(json.dumps(res))
 

@@ -1,5 +1,6 @@
-"""Host-side (CPU, integer/PIL) helpers on the caller side of the hot path; counterparts of the reference's
-omchat/mm_utils.py.  They decide the ViT batch shape (tile count + order) and the `-200` sentinel layout."""
+"""Host-side (CPU, integer) helpers on the caller side of the hot path; counterparts of the reference's
+omchat/mm_utils.py.  They decide the ViT batch shape (tile count + order) and the `-200` sentinel layout.  Pixel work (resize /
+pad / tile / normalise) is NOT here: it runs on the device (image_processing.py -> csrc/preproc.hip)."""
 import math
 from .constants import IMAGE_TOKEN_INDEX
 
@@ -29,41 +30,20 @@ def padded_size(original_size, target_resolution):
     return min(math.ceil(ow * sh), tw), th
 
 
-def resize_and_pad_image(image, target_resolution):
-    """mm_utils.py:42-74 (PIL): resize keeping aspect, paste centred on a black canvas."""
-    from PIL import Image
-    tw, th = target_resolution
-    nw, nh = padded_size(image.size, target_resolution)
-    canvas = Image.new("RGB", (tw, th), (0, 0, 0))
-    canvas.paste(image.resize((nw, nh)), ((tw - nw) // 2, (th - nh) // 2))
-    return canvas
-
-
-def divide_to_patches(image, patch_size):
-    """mm_utils.py:77-96: row-major crops."""
-    w, h = image.size
-    return [image.crop((j, i, j + patch_size, i + patch_size)) for i in range(0, h, patch_size) for j in range(0, w, patch_size)]
-
-
 def anyres_tile_count(image_size, grid_pinpoints, tile=448):
     w, h = select_best_resolution(image_size, grid_pinpoints)
     return 1 + (w // tile) * (h // tile)
 
 
 def process_anyres_image(image, processor, grid_pinpoints, return_type_list=False, return_best_res=False):
-    """mm_utils.py:119-158: [thumbnail] + tiles of the resized/padded canvas, each through `processor.preprocess`."""
-    import torch
-    if hasattr(processor, "process_anyres"):            # device front-end (image_processing.HipImageProcessor): same tiles, on the GPU
-        out, best = processor.process_anyres(image, grid_pinpoints, return_best_res=True)
-        out = list(out) if return_type_list else out
-        return (out, best) if return_best_res else out
-    best = select_best_resolution(image.size, grid_pinpoints)
-    padded = resize_and_pad_image(image, best)
-    edge = processor.crop_size["height"] if hasattr(processor, "crop_size") else processor.size["height"]
-    patches = divide_to_patches(padded, edge)
-    thumb = image.resize((edge, edge))
-    tiles = [processor.preprocess(p, return_tensors="pt")["pixel_values"][0] for p in [thumb] + patches]
-    out = tiles if return_type_list else torch.stack(tiles, dim=0)
+    """mm_utils.py:119-158: [thumbnail] + tiles of the resized / padded canvas, normalised.  The pixels are produced on the device
+    by `processor` (image_processing.HipImageProcessor -> csrc/preproc.hip, bit-identical to the reference's PIL + CLIPImageProcessor
+    result); there is no CPU path in the product -- the PIL restatement lives in oracle/preproc.py for the tests."""
+    if not hasattr(processor, "process_anyres"):
+        raise TypeError("process_anyres_image needs the device image processor (omchat_amd.image_processing.HipImageProcessor); "
+                        "the HIP path has no CPU fallback")
+    out, best = processor.process_anyres(image, grid_pinpoints, return_best_res=True)
+    out = list(out) if return_type_list else out
     return (out, best) if return_best_res else out
 
 
@@ -89,27 +69,12 @@ def dynamic_grid(size, min_num=1, max_num=6, image_size=448):
     return find_closest_aspect_ratio(w / h, ratios, w, h, image_size)
 
 
-def dynamic_preprocess(image, min_num=1, max_num=6, image_size=448, use_thumbnail=False):
-    """mm_utils.py:276-312 (PIL): plain resize to the grid, row-major crops, thumbnail first when there is more than one block."""
-    gw, gh = dynamic_grid(image.size, min_num, max_num, image_size)
-    resized = image.resize((image_size * gw, image_size * gh))
-    out = [resized.crop(((i % gw) * image_size, (i // gw) * image_size, (i % gw + 1) * image_size, (i // gw + 1) * image_size))
-           for i in range(gw * gh)]
-    if use_thumbnail and len(out) != 1:
-        out.insert(0, image.resize((image_size, image_size)))
-    return out
-
-
 def process_dynamic_image(image, processor, max_num=6, image_size=336, grid_pinpoints=None, return_type_list=False, return_best_res=False):
-    """mm_utils.py:315-323."""
-    import torch
-    if hasattr(processor, "process_dynamic"):           # device front-end
-        out = processor.process_dynamic(image, max_num=max_num, image_size=image_size)
-        out = list(out) if return_type_list else out
-        return (out, None) if return_best_res else out
-    tiles = [processor.preprocess(p, return_tensors="pt")["pixel_values"][0]
-             for p in dynamic_preprocess(image, max_num=max_num, image_size=image_size, use_thumbnail=True)]
-    out = tiles if return_type_list else torch.stack(tiles, dim=0)
+    """mm_utils.py:315-323 (dynamic_preprocess :276-312 + per-tile preprocess) on the device; no CPU path in the product."""
+    if not hasattr(processor, "process_dynamic"):
+        raise TypeError("process_dynamic_image needs the device image processor (omchat_amd.image_processing.HipImageProcessor)")
+    out = processor.process_dynamic(image, max_num=max_num, image_size=image_size)
+    out = list(out) if return_type_list else out
     return (out, None) if return_best_res else out
 
 

@@ -131,3 +131,48 @@ def dynamic_tiles(img, grid, tile=448, thumbnail=True, lut=None):
         for c in range(3):
             out[t, c] = lut[c][a[:, :, c]]
     return out
+
+
+# ---- the reference's own PIL pipelines, restated with PIL (the pin for the numpy functions above and the CPU baseline of bench.py)
+def pil_resize_and_pad(image, target_resolution):
+    """resize_and_pad_image (mm_utils.py:42-74): aspect-preserving Image.resize, pasted centred on a black canvas."""
+    from PIL import Image
+    from omchat_amd.mm_utils import padded_size
+    tw, th = target_resolution
+    nw, nh = padded_size(image.size, target_resolution)
+    canvas = Image.new("RGB", (tw, th), (0, 0, 0))
+    canvas.paste(image.resize((nw, nh)), ((tw - nw) // 2, (th - nh) // 2))
+    return canvas
+
+
+def pil_process_anyres_image(image, processor, grid_pinpoints, return_best_res=False):
+    """process_anyres_image (mm_utils.py:119-158) with a CPU `processor` (the reference's CLIPImageProcessor): thumbnail + tiles."""
+    import torch
+    from omchat_amd.mm_utils import select_best_resolution
+    best = select_best_resolution(image.size, grid_pinpoints)
+    padded = pil_resize_and_pad(image, best)
+    edge = processor.crop_size["height"]
+    w, h = padded.size
+    patches = [padded.crop((j, i, j + edge, i + edge)) for i in range(0, h, edge) for j in range(0, w, edge)]      # divide_to_patches :77-96
+    thumb = image.resize((edge, edge))
+    tiles = torch.stack([processor.preprocess(p, return_tensors="pt")["pixel_values"][0] for p in [thumb] + patches], dim=0)
+    return (tiles, best) if return_best_res else tiles
+
+
+def pil_dynamic_preprocess(image, min_num=1, max_num=6, image_size=448, use_thumbnail=False):
+    """dynamic_preprocess (mm_utils.py:276-312): plain resize to the grid, row-major crops, thumbnail first when > 1 block."""
+    from omchat_amd.mm_utils import dynamic_grid
+    gw, gh = dynamic_grid(image.size, min_num, max_num, image_size)
+    resized = image.resize((image_size * gw, image_size * gh))
+    out = [resized.crop(((i % gw) * image_size, (i // gw) * image_size, (i % gw + 1) * image_size, (i // gw + 1) * image_size))
+           for i in range(gw * gh)]
+    if use_thumbnail and len(out) != 1:
+        out.insert(0, image.resize((image_size, image_size)))
+    return out
+
+
+def pil_process_dynamic_image(image, processor, max_num=6, image_size=448):
+    """process_dynamic_image (mm_utils.py:315-323) with a CPU processor."""
+    import torch
+    return torch.stack([processor.preprocess(p, return_tensors="pt")["pixel_values"][0]
+                        for p in pil_dynamic_preprocess(image, max_num=max_num, image_size=image_size, use_thumbnail=True)], dim=0)

@@ -129,17 +129,23 @@ def test_anyres_tile_counts():
 
 
 def test_anyres_tiles_for_reference_sample_image():
-    """tile count/order/shape for a 570x380 picture (the size of the reference's images/extreme_ironing.jpg)"""
+    """tile count/order/shape for a 570x380 picture (the size of the reference's images/extreme_ironing.jpg), PIL restatement;
+    the product entry refuses a CPU processor (the pixels are produced on the device only)"""
     from PIL import Image
-    from omchat_amd.mm_utils import process_anyres_image
     from transformers import CLIPImageProcessor
+    from oracle.preproc import pil_process_anyres_image
+    from omchat_amd.mm_utils import process_anyres_image, process_dynamic_image
     proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
                               image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)      # internVIT_encoder.py:25-29
     rng = np.random.default_rng(0)
     img = Image.fromarray(rng.integers(0, 255, (380, 570, 3), dtype=np.uint8))
     pin = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
-    tiles, best = process_anyres_image(img, proc, pin, True, return_best_res=True)
-    assert best == (896, 448) and len(tiles) == 3 and all(t.shape == (3, 448, 448) for t in tiles)
+    tiles, best = pil_process_anyres_image(img, proc, pin, return_best_res=True)
+    assert best == (896, 448) and tuple(tiles.shape) == (3, 3, 448, 448)
+    with pytest.raises(TypeError):
+        process_anyres_image(img, proc, pin)
+    with pytest.raises(TypeError):
+        process_dynamic_image(img, proc)
 
 
 def test_key_layout_roundtrip():

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import preproc as opp
 from omchat_amd import _lib
-from omchat_amd.mm_utils import select_best_resolution, process_anyres_image
+from omchat_amd.mm_utils import select_best_resolution
 
 PINS = [[448, 896], [896, 448], [896, 896], [1344, 448], [448, 1344], [1344, 1344]]
 SIZES = [(300, 500, 448, 448), (1000, 1500, 448, 896), (448, 448, 448, 448), (97, 61, 448, 448), (1344, 700, 231, 448),
@@ -73,13 +73,13 @@ def test_plan_matches_select_best_resolution():
 
 @pytest.mark.parametrize("w,h", [(570, 380), (333, 999), (448, 448)])
 def test_oracle_anyres_is_the_reference_pipeline(w, h):
-    """oracle.anyres_tiles == process_anyres_image with the reference's CLIPImageProcessor (PIL resize / paste / crop + transformers)"""
+    """oracle.anyres_tiles (numpy) == the reference recipe run with PIL + the reference's CLIPImageProcessor (resize / paste / crop + transformers)"""
     from PIL import Image
     from transformers import CLIPImageProcessor
     proc = CLIPImageProcessor(crop_size=448, do_center_crop=True, do_normalize=True, do_resize=True,
                               image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], size=448)
     a = np.random.default_rng(w + h).integers(0, 256, (h, w, 3), dtype=np.uint8)
-    tiles, best = process_anyres_image(Image.fromarray(a), proc, [tuple(p) for p in PINS], return_best_res=True)
+    tiles, best = opp.pil_process_anyres_image(Image.fromarray(a), proc, [tuple(p) for p in PINS], return_best_res=True)
     got = opp.anyres_tiles(a, best)
     assert got.shape == tuple(tiles.shape) and np.array_equal(got, tiles.numpy())
 
@@ -89,7 +89,7 @@ def test_dynamic_grid_and_oracle_match_the_reference_recipe():
     pipeline (resize -> crop -> CLIPImageProcessor) with the thumbnail first"""
     from PIL import Image
     from transformers import CLIPImageProcessor
-    from omchat_amd.mm_utils import dynamic_grid, dynamic_preprocess, process_dynamic_image
+    from omchat_amd.mm_utils import dynamic_grid
     assert [dynamic_grid(s, max_num=6) for s in [(448, 448), (900, 448), (448, 1400), (1000, 700), (3000, 1000), (100, 100)]] == \
         [(1, 1), (2, 1), (1, 3), (3, 2), (3, 1), (1, 1)]
     # expected grids captured from the reference's find_closest_aspect_ratio (imported in the build container); the tie rule
@@ -102,7 +102,7 @@ def test_dynamic_grid_and_oracle_match_the_reference_recipe():
         a = np.random.default_rng(w + 3 * h).integers(0, 256, (h, w, 3), dtype=np.uint8)
         img = Image.fromarray(a)
         grid = dynamic_grid((w, h), max_num=6, image_size=448)
-        pil = dynamic_preprocess(img, max_num=6, image_size=448, use_thumbnail=True)
+        pil = opp.pil_dynamic_preprocess(img, max_num=6, image_size=448, use_thumbnail=True)
         assert len(pil) == grid[0] * grid[1] + (grid[0] * grid[1] != 1) and all(p.size == (448, 448) for p in pil)
-        tiles = process_dynamic_image(img, proc, max_num=6, image_size=448)
+        tiles = opp.pil_process_dynamic_image(img, proc, max_num=6, image_size=448)
         assert np.array_equal(opp.dynamic_tiles(a, grid), tiles.numpy())
