@@ -103,3 +103,33 @@ def test_dynamic_tiling_matches_oracle_bit_exact(w, h):
     assert torch.equal(via, out)
     with pytest.raises(ValueError):
         proc.process_dynamic(a, image_size=336)
+
+
+def test_hf_image_processor_and_processor_on_device():
+    """omchat_amd.processing.OmChatImageProcessor / OmChatProcessor (hf_example.py flow) against the bytes and ids captured from the
+    reference's HF classes (tests/golden/hf_image_processor.json)"""
+    import hashlib, json, os, types
+    from omchat_amd.processing import OmChatImageProcessor, OmChatProcessor
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hf_image_processor.json")))
+    ip = OmChatImageProcessor(image_grid_pinpoints=fx["pinpoints"])
+    arrays = {}
+    for c in fx["cases"]:
+        a = np.random.default_rng(c["seed"]).integers(0, 256, (c["h"], c["w"], 3), dtype=np.uint8)
+        arrays[c["seed"]] = a
+        r = ip(a)
+        n = int(r["num_patches"][0])
+        pv = np.ascontiguousarray(r["pixel_values"][0, :n].cpu().numpy())
+        assert n == c["n"] and pv.dtype == np.float32 and hashlib.sha256(pv.tobytes()).hexdigest() == c["sha256"], c
+
+    class Tok:
+        bos_token_id = None
+        pad_token_id = 0
+        def __call__(self, s):
+            return types.SimpleNamespace(input_ids=[1000 + ord(ch) for ch in s])
+        def encode(self, s):
+            return [1000 + ord(ch) for ch in s]
+    proc = OmChatProcessor(ip, Tok())
+    for pr in fx["prompts"]:
+        images = arrays[0] if pr["n_images"] == 1 else [arrays[0], arrays[1]]
+        out = proc(text=pr["text"], images=images)
+        assert out["input_ids"][0].tolist() == pr["input_ids"] and list(out["images"].shape) == pr["images_shape"] and out["images"].is_cuda

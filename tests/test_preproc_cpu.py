@@ -106,3 +106,55 @@ def test_dynamic_grid_and_oracle_match_the_reference_recipe():
         assert len(pil) == grid[0] * grid[1] + (grid[0] * grid[1] != 1) and all(p.size == (448, 448) for p in pil)
         tiles = opp.pil_process_dynamic_image(img, proc, max_num=6, image_size=448)
         assert np.array_equal(opp.dynamic_tiles(a, grid), tiles.numpy())
+
+
+def _hf_fixture():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hf_image_processor.json")))
+
+
+def test_oracle_matches_the_reference_hf_image_processor():
+    """tests/golden/hf_image_processor.json holds sha256 of the pixel bytes produced by the reference's OmChatImageProcessor
+    (tools/make_golden_hfproc.py); the oracle reproduces them with the pinpoints read as (height, width) pairs"""
+    import hashlib
+    fx = _hf_fixture()
+    pins_wh = [(p[1], p[0]) for p in fx["pinpoints"]]
+    for c in fx["cases"]:
+        a = np.random.default_rng(c["seed"]).integers(0, 256, (c["h"], c["w"], 3), dtype=np.uint8)
+        best = select_best_resolution((c["w"], c["h"]), pins_wh)
+        t = opp.anyres_tiles(a, best)
+        assert t.shape[0] == c["n"] and hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() == c["sha256"], c
+    sq = next(c for c in fx["cases"] if c["w"] == c["h"] == 448)       # the tie case that separates the HF and the mm_utils conventions
+    assert select_best_resolution((448, 448), pins_wh) == (896, 448) and select_best_resolution((448, 448), [tuple(p) for p in fx["pinpoints"]]) == (448, 896)
+
+
+def test_hf_processor_prompt_layout_matches_reference():
+    """OmChatProcessor.__call__ (hf/processing_omchat.py:171-253): single- and multi-image prompt -> ids, against ids captured from
+    the reference with the same stub tokenizer; the pixel side is faked here (no GPU): only the tile counts matter for the layout"""
+    import types
+    import torch
+    from omchat_amd.processing import OmChatProcessor
+    fx = _hf_fixture()
+
+    class Tok:
+        bos_token_id = None
+        pad_token_id = 0
+        def __call__(self, s):
+            return types.SimpleNamespace(input_ids=[1000 + ord(ch) for ch in s])
+        def encode(self, s):
+            return [1000 + ord(ch) for ch in s]
+
+    counts = {c["seed"]: c["n"] for c in fx["cases"]}
+
+    class FakeIP:
+        def __call__(self, images, return_tensors="pt"):
+            imgs = images if isinstance(images, list) else [images]
+            n = torch.tensor([counts[i] for i in imgs])
+            return {"pixel_values": torch.zeros(len(imgs), int(n.max()), 3, 2, 2), "num_patches": n}
+    proc = OmChatProcessor(FakeIP(), Tok())
+    for pr in fx["prompts"]:
+        images = 0 if pr["n_images"] == 1 else [0, 1]                 # stand-ins keyed by the fixture's seeds
+        out = proc(text=pr["text"], images=images)
+        assert out["input_ids"][0].tolist() == pr["input_ids"]
+        assert out["images"].shape[0] == pr["images_shape"][0] == pr["input_ids"].count(-200)
+    assert proc(text="hello <image>")["input_ids"].shape[0] == 1 and "images" not in proc(text="hello")
