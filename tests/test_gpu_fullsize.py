@@ -90,3 +90,43 @@ def test_full_size_greedy_run_is_reproducible(eng13b):
         outs.append(seq)
     assert outs[0] == outs[1]
     assert eng13b.kv_lengths(1) == [4 + 1024 + 12]
+
+
+def test_long_context_decode_16k_one_full_width_layer(gpu_lib):
+    """BASELINE configs[4] shape on one Qwen2-7B-width layer: 16 k tokens of context in the KV cache (prefill in one pass), then
+    decode steps with the 16-bit weights against the oracle (257 split-KV partials per head merged).  The oracle's eager
+    attention cannot materialise 16 k x 16 k scores, so its KV cache is built directly (layer 0's K / V depend only on the
+    input rows: norm -> k/v projection -> RoPE) and only the decode steps (1 x 16 k scores) go through it."""
+    from omchat_amd.config import omchat13b
+    from oracle import KVCache, decode_step
+    from oracle.decoder import rope_cos_sin, apply_rope
+    from oracle.vit import rms_norm
+    import numpy as np
+    import torch.nn.functional as F
+    T32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    cfg = omchat13b()
+    cfg.text["num_hidden_layers"] = 1
+    cfg.text["vocab_size"] = 2048
+    S = 16400
+    e = Engine(cfg, dtype="bf16", max_seq=S + 64, max_batch=1, vision=False)
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 0).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    e.load_state_dict(sd)
+    x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(1)) * 0.5).bfloat16().float()
+    logits, _ = e.prefill(x); torch.cuda.synchronize()
+    assert torch.isfinite(logits).all()
+    P = "model.layers.0."
+    xn = rms_norm(x, sd[P + "input_layernorm.weight"], 1e-6)
+    k = F.linear(xn, sd[P + "self_attn.k_proj.weight"], sd[P + "self_attn.k_proj.bias"]).view(1, S, 4, 128).transpose(1, 2)
+    v = F.linear(xn, sd[P + "self_attn.v_proj.weight"], sd[P + "self_attn.v_proj.bias"]).view(1, S, 4, 128).transpose(1, 2)
+    cos, sin = rope_cos_sin(torch.arange(S)[None], 128, cfg.text["rope_theta"], torch.float32)
+    _, k = apply_rope(k, k, cos, sin)
+    cache = KVCache(1)
+    cache.update(k, v, 0)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    for tok in (5, 9):
+        nxt, lg = e.decode_step(torch.tensor([tok]), want_logits=True); torch.cuda.synchronize()
+        r = decode_step(torch.tensor([[tok]]), sd, cfg.text, cache)[0, 0]
+        assert rel(lg[0], r) < 3e-2, rel(lg[0], r)
+        assert int(nxt[0]) == int(torch.argmax(lg[0]))
+    assert e.kv_lengths(1) == [S + 2] and cache.get_seq_length() == S + 2
+    e.close()
