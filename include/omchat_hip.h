@@ -146,6 +146,10 @@ int omchat_prof_read(omchat_ctx* ctx, int cat, double* total_ms, long* launches,
 /* ---- the one native op seam of the reference: FlashAttention.forward (intern_vit_6b/flash_attention.py:30-75) --- */
 /* qkv packed [B, S, 3, H, 128] -> out [B, S, H, 128]; softmax_scale <= 0 means 1/sqrt(128). */
 int omchat_mha_fwd(const void* qkv, int B, int S, int H, float softmax_scale, int causal, void* out, int dtype, void* stream);
+/* same seam with head dim D = 128 | 64 and the key_padding_mask branch (:56-67) for right-padded batches: seqlens int32 [B] on the
+ * device (NULL = all S); keys >= seqlens[b] are masked, rows of padded queries are left to the caller to zero (pad_input) */
+int omchat_mha_fwd_varlen(const void* qkv, int B, int S, int H, int D, const int32_t* seqlens, float softmax_scale, int causal,
+                          void* out, int dtype, void* stream);
 
 /* ---- op-level entry points (unit parity tests, benches) --------------------------------------------------------- */
 int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,

@@ -52,6 +52,7 @@ _SIGS = {
     "omchat_prof_enable": (_i, [_vp, _i]),
     "omchat_prof_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
     "omchat_mha_fwd": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
+    "omchat_mha_fwd_varlen": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _i, _vp]),
     "omchat_op_gemm": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_set_tuning": (_i, [_i, _i]),
     "omchat_op_gemm_sk_ws": (_sz, []),

@@ -118,6 +118,24 @@ extern "C" int omchat_mha_fwd(const void* qkv, int B, int Sq, int H, float softm
   return launch_attn_prefill(dtype, a, S(stream));
 }
 
+// packed qkv [B, S, 3, H, D] (D = 128 or 64) with optional per-sequence valid lengths (keys >= seqlens[b] masked; the caller zeroes
+// the rows of padded queries, as flash-attn's pad_input does)
+extern "C" int omchat_mha_fwd_varlen(const void* qkv, int B, int Sq, int H, int D, const int32_t* seqlens, float softmax_scale, int causal,
+                                     void* out, int dtype, void* stream) {
+  OM_CHECK(qkv && out, "null argument");
+  OM_CHECK(D == 128 || D == 64, "head_dim must be 128 or 64");
+  AttnArgs a{};
+  const int64_t row = (int64_t)3 * H * D;
+  a.Q = qkv; a.q_sb = Sq * row; a.q_sh = D; a.q_sr = row;
+  a.K = (const char*)qkv + (size_t)H * D * 2; a.k_sb = a.q_sb; a.k_sh = D; a.k_sr = row;
+  a.V = (const char*)qkv + (size_t)2 * H * D * 2; a.v_sb = a.q_sb; a.v_sh = D; a.v_sr = row;
+  a.O = out; a.o_sb = (int64_t)Sq * H * D; a.o_sh = D; a.o_sr = (int64_t)H * D;
+  a.batch = B; a.q_heads = H; a.kv_heads = H; a.Sq = Sq; a.Skv = Sq; a.kv_len = seqlens; a.causal = causal; a.q_pos0 = 0;
+  a.scale = softmax_scale > 0.f ? softmax_scale : (D == 128 ? 0.08838834764831845f : 0.125f);
+  a.head_dim = D;
+  return launch_attn_prefill(dtype, a, S(stream));
+}
+
 extern "C" int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float* scale, void* stream) {
   return launch_quant_fp8_rows(dtype, W, K, N, K, W8, K, scale, S(stream));
 }

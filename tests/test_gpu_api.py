@@ -141,3 +141,46 @@ def test_text_only_and_bf16(ckpt):
     ref, _, _ = oracle.prefill(ids, None, sd, cfg.vision, cfg.text)
     sync()
     assert rel(out.logits[0, 0], ref[0, -1]) < TOL_DEEP["bf16"]
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_flash_attention_seam_class(gpu_lib, D):
+    """FlashAttention(softmax_scale, attention_dropout).forward(qkv, key_padding_mask, causal, cu_seqlens, max_s, need_weights)
+    (intern_vit_6b/flash_attention.py:25-75): the three input forms, the asserts and the (out, None) return"""
+    from omchat_amd.model import FlashAttention
+    from test_gpu_ops import _attn_ref
+    B, S, H = 2, 70, 3
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, S, 3, H, D, generator=g).half()
+    fa = FlashAttention(softmax_scale=None)
+    out, none = fa(qkv.cuda())
+    assert none is None and out.shape == (B, S, H, D)
+    q, k, v = qkv.float().unbind(2)
+    ref = _attn_ref(q, k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), D ** -0.5, 0, 0, [S] * B)
+    rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+    assert rel(out, ref) < 2.5e-3
+    # key_padding_mask (right padding): valid rows equal attention over the valid prefix, padded rows are zero (pad_input)
+    lens = [S, 41]
+    mask = torch.arange(S)[None, :] < torch.tensor(lens)[:, None]
+    outm, _ = fa(qkv.cuda(), key_padding_mask=mask.cuda())
+    refm = _attn_ref(q, k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), D ** -0.5, 0, 0, lens)
+    assert rel(outm[1, :41], refm[1, :41]) < 2.5e-3 and float(outm[1, 41:].abs().max()) == 0.0 and rel(outm[0], refm[0]) < 2.5e-3
+    # packed varlen form (nnz, 3, H, D) + cu_seqlens
+    packed = torch.cat([qkv[0, :S], qkv[1, :41]], dim=0).cuda()
+    cu = torch.tensor([0, S, S + 41], dtype=torch.int32).cuda()
+    outp, _ = fa(packed, cu_seqlens=cu, max_s=S)
+    assert rel(outp[:S], refm[0]) < 2.5e-3 and rel(outp[S:], refm[1, :41]) < 2.5e-3
+    # causal + explicit scale
+    outc, _ = FlashAttention(softmax_scale=0.2)(qkv.cuda(), causal=True)
+    refc = _attn_ref(q, k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), 0.2, 1, 0, [S] * B)
+    assert rel(outc, refc) < 2.5e-3
+    # the reference's asserts (:39-41) and the unsupported mask shape
+    with pytest.raises(AssertionError):
+        fa(qkv.cuda(), need_weights=True)
+    with pytest.raises(AssertionError):
+        fa(qkv.cuda().float())
+    with pytest.raises(AssertionError):
+        fa(qkv)
+    holes = mask.clone(); holes[0, 3] = False
+    with pytest.raises(NotImplementedError):
+        fa(qkv.cuda(), key_padding_mask=holes.cuda())
