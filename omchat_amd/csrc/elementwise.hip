@@ -170,8 +170,8 @@ __global__ __launch_bounds__(NORM_THREADS) void vit_qknorm_kernel(T* qkv, int ld
   __shared__ float red[NORM_THREADS / 64];
   const int row = blockIdx.x;
   const int nchunk = C >> 3;
-#pragma unroll 1
-  for (int part = 0; part < 2; ++part) {       // 0 = q, 1 = k
+  {
+    const int part = blockIdx.y;               // 0 = q, 1 = k: one workgroup each (twice the rows in flight, half the serial chain)
     T* xr = qkv + (size_t)row * ld + part * C;
     const T* w = part == 0 ? wq : wk;
     v8 xv[NORM_MAXC];
@@ -436,7 +436,7 @@ int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* 
                       float q_scale, const float* sumsq_in, hipStream_t s) {
   OM_CHECK(C % 8 == 0 && C <= NORM_THREADS * NORM_MAXC * 8 && ld % 8 == 0, "C % 8, C <= 16384, ld % 8");
   if (rows == 0) return 0;
-  DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows, 2), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
                                      C, C_total, eps, q_scale, sumsq_in));
   OM_LAUNCH_CHECK();
   return 0;
