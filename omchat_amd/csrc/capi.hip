@@ -15,6 +15,7 @@ extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, 
 extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 0) { gemm_set_skew(value); return 0; }
   if (key == 1) { gemv_set_force_mfma(value); return 0; }
+  if (key == 5) { gemm_set_autotune(value); return 0; }
   if (key == 4) { model_set_ar_min_rows(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;

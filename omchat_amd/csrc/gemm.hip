@@ -12,6 +12,11 @@
 // lands under the 64 (256^2 tile) or 32 (128^2 tile) MFMAs per wave of tile t.  Grid is 1-D with a bijective
 // XCD remap so that the workgroups sharing an XCD's L2 walk neighbouring tiles (M fastest).
 #include "kernels.h"
+#include <array>
+#include <stdio.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -583,6 +588,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     case 4: return launch_cfg<T, 224, 256, 2, 4, EPI>(a, stream);
     case 5: return launch_cfg<T, 192, 256, 2, 4, EPI>(a, stream);
     case 6: return launch_cfg<T, 256, 256, 2, 4, EPI>(a, stream);     // one-barrier-per-K-step structure (kept for A/B)
+    case 7: return launch_cfg<T, 256, 192, 4, 3, EPI>(a, stream);     // 12 waves of 64x64: 3 waves per SIMD
+    case 8: return launch_cfg<T, 256, 256, 4, 4, EPI>(a, stream);     // 16 waves of 64x64: 4 waves per SIMD
+    case 9: return launch_cfg<T, 192, 256, 3, 4, EPI>(a, stream);
     default: return launch_cfg8<T, EPI>(a, stream);
   }
 }
@@ -603,6 +611,65 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 void gemm_set_skew(int v) { g_gemm_skew = v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Tile choice by measurement.  Which kernel wins depends on the shape in ways a fill-the-last-round model does not capture
+// (MI355X, bf16, r01: the staggered 8-wave 256^2 kernel wins on long-K and exactly-one-round shapes; the 16-wave 256^2 one-barrier
+// kernel -- 4 waves per SIMD -- is 14 % faster on the ViT qkv shape and 15 % on o_proj; the 12-wave 192x256 kernel is 13-17 %
+// faster on the N = 3200 shapes).  So the first time a (dtype, epilogue, ceil(M/256), N, K) problem is seen, the candidates are
+// timed on the caller's own A / W with a scratch C (the real C may alias the residual input, so it is never written while
+// tuning) and the winner is cached for the life of the process.  All kernels accumulate every output element over K in the same
+// order, so the choice changes the speed and nothing else.  omchat_op_set_tuning(key 5, 0) falls back to the cost model.
+// ---------------------------------------------------------------------------------------------------------
+static int g_autotune = getenv("OMCHAT_GEMM_AUTOTUNE") ? atoi(getenv("OMCHAT_GEMM_AUTOTUNE")) : 1;
+void gemm_set_autotune(int v) { g_autotune = v; }
+
+static std::mutex g_tune_mu;
+static std::map<std::array<int, 5>, int> g_tuned;
+
+static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
+  const std::array<int, 5> key{dtype * 8 + a.epi, cdiv(a.M, 256), a.N, a.K, a.ldc};
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  auto it = g_tuned.find(key);
+  if (it != g_tuned.end()) return it->second;
+  const int heuristic = pick_tile(a.M, a.N, a.epi);
+  if ((double)a.M * a.N * a.K < 4e9) return g_tuned[key] = heuristic;            // < 8 GFLOP: launch-bound, nothing to choose
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic;      // cannot time inside a capture
+  GemmArgs t = a;
+  t.M = a.M < 8192 ? a.M : 8192;                                                 // enough rounds to rank the kernels, bounded scratch
+  void* scratch = nullptr;
+  if (hipMalloc(&scratch, (size_t)t.M * a.ldc * 2) != hipSuccess) { (void)hipGetLastError(); return g_tuned[key] = heuristic; }
+  t.C = scratch;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  int cands[5] = {2, 8, 9, 7, 3};
+  int best = heuristic;
+  float best_ms = 1e30f;
+  for (int c : cands) {
+    if (c == 3 && a.epi == EPI_SWIGLU) continue;                                  // 48 columns per wave would split gate|up pairs
+    t.force_tile = c;
+    bool ok = true;
+    auto run = [&]() {
+      int rc = 1;
+      if (dtype == OMCHAT_F16) rc = launch_t<f16>(t, stream);
+      else if (dtype == OMCHAT_BF16) rc = launch_t<bf16>(t, stream);
+      ok = ok && rc == 0;
+    };
+    run();
+    (void)hipEventRecord(e0, stream);
+    for (int i = 0; i < 3; ++i) run();
+    (void)hipEventRecord(e1, stream);
+    if (hipEventSynchronize(e1) != hipSuccess || !ok) { (void)hipGetLastError(); continue; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (getenv("OMCHAT_TUNE_LOG")) fprintf(stderr, "[omchat tune] M=%d N=%d K=%d epi=%d tile %d: %.1f us\n", a.M, a.N, a.K, a.epi, c, ms * 1e3f / 3.f);
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  return g_tuned[key] = best;
+}
 size_t gemm_sk_ws_bytes() { return (size_t)SK_MAX_WG * SK_SLAB_BYTES + 4096; }
 
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
@@ -612,8 +679,9 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "A/W must be 16-byte aligned");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
   OM_CHECK(a.epi != EPI_LS_RESID || a.ls, "layer-scale epilogue needs ls");
-  if (dtype == OMCHAT_F16) return launch_t<f16>(a, stream);
-  if (dtype == OMCHAT_BF16) return launch_t<bf16>(a, stream);
-  omchat_set_error("launch_gemm: bad dtype");
-  return 1;
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16, "bad dtype");
+  GemmArgs b = a;
+  if (!a.force_tile && g_autotune && a.stream_k <= 0) b.force_tile = tuned_tile(dtype, a, stream);
+  if (dtype == OMCHAT_F16) return launch_t<f16>(b, stream);
+  return launch_t<bf16>(b, stream);
 }

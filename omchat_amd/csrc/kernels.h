@@ -51,6 +51,7 @@ int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
 // W8[n][k] = e4m3_rne(W[n][k] / scale[n])
 int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t stream);
 void gemv_set_force_mfma(int v);
+void gemm_set_autotune(int v);
 void model_set_ar_min_rows(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
