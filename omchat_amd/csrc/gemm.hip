@@ -641,6 +641,12 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   void* scratch = nullptr;
   if (hipMalloc(&scratch, (size_t)t.M * a.ldc * 2) != hipSuccess) { (void)hipGetLastError(); return g_tuned[key] = heuristic; }
   t.C = scratch;
+  // In the model every GEMM meets its weights cold (27 GB stream through a 256 MB Infinity Cache between two uses), while
+  // back-to-back timing runs would find them cached and rank the kernels differently (o_proj: 102 us warm, 120 us in place).
+  // So each timed run is preceded by a write sweep over a buffer larger than the cache.
+  constexpr size_t FLUSH_BYTES = (size_t)384 << 20;
+  void* flush = nullptr;
+  if (hipMalloc(&flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); flush = nullptr; }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   int cands[5] = {2, 8, 9, 7, 3};
@@ -656,18 +662,25 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
       else if (dtype == OMCHAT_BF16) rc = launch_t<bf16>(t, stream);
       ok = ok && rc == 0;
     };
-    run();
-    (void)hipEventRecord(e0, stream);
-    for (int i = 0; i < 3; ++i) run();
-    (void)hipEventRecord(e1, stream);
-    if (hipEventSynchronize(e1) != hipSuccess || !ok) { (void)hipGetLastError(); continue; }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (getenv("OMCHAT_TUNE_LOG")) fprintf(stderr, "[omchat tune] M=%d N=%d K=%d epi=%d tile %d: %.1f us\n", a.M, a.N, a.K, a.epi, c, ms * 1e3f / 3.f);
+    run();                                                                        // first launch of an instantiation (attribute set-up)
+    float ms = 1e30f;
+    for (int i = 0; i < 3 && ok; ++i) {
+      if (flush) (void)hipMemsetAsync(flush, i, FLUSH_BYTES, stream);
+      (void)hipEventRecord(e0, stream);
+      run();
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+      float one = 0.f;
+      (void)hipEventElapsedTime(&one, e0, e1);
+      ms = one < ms ? one : ms;
+    }
+    if (!ok) continue;
+    if (getenv("OMCHAT_TUNE_LOG")) fprintf(stderr, "[omchat tune] M=%d N=%d K=%d epi=%d tile %d: %.1f us\n", a.M, a.N, a.K, a.epi, c, ms * 1e3f);
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(scratch);
+  if (flush) (void)hipFree(flush);
   return g_tuned[key] = best;
 }
 size_t gemm_sk_ws_bytes() { return (size_t)SK_MAX_WG * SK_SLAB_BYTES + 4096; }
