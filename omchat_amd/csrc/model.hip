@@ -855,9 +855,13 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     OM_CHECK(b <= 32, "split-K decode path handles b <= 32");
     GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
     if (f8 && W8) { g.W = W8; g.w_scale = sc; }
-    return launch_gemv(ctx->dt, g, s);
+    TRY(launch_gemv(ctx->dt, g, s));
+    // tensor parallelism: the slices hold this rank's partial sums; they are all-reduced in fp32 (<= 3 x 3584 floats at batch 1,
+    // latency-bound like any small message) and the same fused residual + RMSNorm kernel then runs identically on every rank
+    if (ctx->tp_size > 1) TRY(ctx->allreduce_f32(ctx->tw_part, (size_t)ks * b * H, s));
+    return 0;
   };
-  const bool fused = ctx->tp_size == 1 && b <= 32;
+  const bool fused = b <= 32;
   // K slices: batch 1 (whole-row streaming form) wants <= 8 chunks of 512 per slice and >= ~2500 waves in the grid;
   // the MFMA form (b > 1) wants ~2-3 workgroups per CU
   // (tools/tune_rows.hip: down_proj 18944 -> 8 slices 23.3 us vs 5 slices 27.6 us; o_proj is latency-bound, 1-3 slices alike)
