@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libomchat_hip.so")
+LIB_PATH = os.environ.get("OMCHAT_LIB") or os.path.join(HERE, "lib", "libomchat_hip.so")      # OMCHAT_LIB: A/B another build of the same ABI
 _lib = None
 
 F16, BF16, F32 = 0, 1, 2

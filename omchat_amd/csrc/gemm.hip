@@ -49,6 +49,78 @@ __device__ __forceinline__ void tile_coords(int M, int N, int BM, int BN, int& m
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// ---------------------------------------------------------------------------------------------------------
+// Shared epilogue.  acc[i][j][r] = C[rowu + i*16 + 4*fg + r][colu + j*16 + fr]   (rowu / colu: wave-uniform corner of the wave tile)
+// VALU does not overlap MFMA on a SIMD, so epilogue instructions are paid in full: the first version spent, per element, a
+// 64-bit multiply-add for the address, a compare + exec-mask branch for the row bound and a 2-byte flat store (796 VALU + 133
+// branches per thread for the plain epilogue, 1700 with a residual).  Here C and the residual are addressed through buffer
+// resources that start at the wave tile's first row and end after its last valid row: the hardware drops out-of-range rows, the
+// per-element address is one 32-bit add, bias / layer-scale are per column (hoisted), and the rounding points are unchanged.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ unsigned short bits16(T v) { return __builtin_bit_cast(unsigned short, v); }
+template <typename T> __device__ __forceinline__ float from_bits16(unsigned short v) { return tof(__builtin_bit_cast(T, v)); }
+
+template <typename T, int MR, int NR, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int rowu_, int colu_, int fg, int fr) {
+  const int rowu = __builtin_amdgcn_readfirstlane(rowu_), colu = __builtin_amdgcn_readfirstlane(colu_);      // SGPRs: scalar offsets, scalar resources
+  const int rows_valid = p.M - rowu < MR * 16 ? p.M - rowu : MR * 16;
+  if (rows_valid <= 0) return;                                                   // wave-uniform
+  const T* __restrict__ bias = (const T*)p.bias;
+  // byte ranges of the wave tile's rows (< 2^32: at most 128 rows of one matrix row stride each)
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((T*)p.C + (size_t)rowu * p.ldc, 0, rows_valid * p.ldc * 2, 0x00020000);
+  const int c_lane = (fg * 4 * p.ldc + fr) * 2;                                  // lane part of the byte offset inside C's range
+  if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+    for (int j = 0; j < NR; j += 2) {
+      if (colu + j * 16 + 16 + fr < p.N) {                                       // gate column in the fused layout (up = +16)
+        const int oc = ((colu + j * 16) >> 1) * 2;                               // byte offset of the output column block
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = rnd<T>(acc[i][j][r]), u = rnd<T>(acc[i][j + 1][r]);
+            __builtin_amdgcn_raw_buffer_store_b16(bits16<T>(fromf<T>(rnd<T>(silu(g)) * u)), crs, c_lane + (i * 16 + r) * p.ldc * 2 + oc, 0, 0);
+          }
+      }
+    }
+  } else {
+    const T* __restrict__ ls = (const T*)p.ls;
+    const bool has_r = (EPI == EPI_LS_RESID || EPI == EPI_RESID) && p.resid != nullptr;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(has_r ? (T*)p.resid + (size_t)rowu * p.ldr : (T*)p.C, 0,
+                                                                        has_r ? rows_valid * p.ldr * 2 : 0, 0x00020000);
+    const int r_lane = (fg * 4 * p.ldr + fr) * 2;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int col = colu + j * 16 + fr;
+      if (col < p.N) {
+        const float bv = bias ? tof(bias[col]) : 0.f;
+        float lsv = 1.f;
+        if constexpr (EPI == EPI_LS_RESID) lsv = tof(ls[col]);
+        const int cj = c_lane + (colu + j * 16) * 2, rj = r_lane + (colu + j * 16) * 2;
+        // all residual elements of this column block in flight before the first use (no residual: the resource has zero
+        // records and the loads return 0 -- no branch either way)
+        unsigned short rb[MR][4];
+        if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rb[i][r] = __builtin_amdgcn_raw_buffer_load_b16(rrs, rj + (i * 16 + r) * p.ldr * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = rnd<T>(acc[i][j][r] + bv);
+            if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
+            if constexpr (EPI == EPI_LS_RESID) v = from_bits16<T>(rb[i][r]) + rnd<T>(v * lsv);
+            if constexpr (EPI == EPI_RESID) v = from_bits16<T>(rb[i][r]) + v;
+            __builtin_amdgcn_raw_buffer_store_b16(bits16<T>(fromf<T>(v)), crs, cj + (i * 16 + r) * p.ldc * 2, 0, 0);
+          }
+      }
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
   constexpr int NT = WM * WN * 64;
@@ -140,110 +212,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue.  acc[i][j][r] = C[row0 + i*16 + 4*fg + r][col0 + j*16 + fr]
-  const int row0 = m0 + wm * WTM + fg * 4;
-  const int col0 = n0 + wn * WTN + fr;
-  const T* __restrict__ bias = (const T*)p.bias;
-  T* C = (T*)p.C;
-  if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-    for (int j = 0; j < NR; j += 2) {
-      const int colg = col0 + j * 16;            // gate column in the fused layout (up = +16)
-      if (colg + 16 < p.N) {
-        const int oc = ((n0 + wn * WTN + j * 16) >> 1) + fr;
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + r;
-            if (row < p.M) {
-              const float g = rnd<T>(acc[i][j][r]), u = rnd<T>(acc[i][j + 1][r]);
-              C[(size_t)row * p.ldc + oc] = fromf<T>(rnd<T>(silu(g)) * u);
-            }
-          }
-      }
-    }
-  } else {
-    const T* __restrict__ ls = (const T*)p.ls;
-    const T* R = (const T*)p.resid;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int col = col0 + j * 16;
-      if (col < p.N) {
-        const float bv = bias ? tof(bias[col]) : 0.f;
-        float lsv = 1.f;
-        if constexpr (EPI == EPI_LS_RESID) lsv = tof(ls[col]);
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + r;
-            if (row < p.M) {
-              float v = rnd<T>(acc[i][j][r] + bv);
-              if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
-              if constexpr (EPI == EPI_LS_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + rnd<T>(v * lsv);
-              if constexpr (EPI == EPI_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + v;
-              C[(size_t)row * p.ldc + col] = fromf<T>(v);
-            }
-          }
-      }
-    }
-  }
+  gemm_epilogue<T, MR, NR, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fg, fr);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------
-// Shared epilogue: acc[i][j][r] = C[row0 + i*16 + r][col0 + j*16] for the lane (row0/col0 include the lane offsets)
-// ---------------------------------------------------------------------------------------------------------
-template <typename T, int MR, int NR, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int row0, int col0, int ncol_base, int fr) {
-  const T* __restrict__ bias = (const T*)p.bias;
-  T* C = (T*)p.C;
-  if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-    for (int j = 0; j < NR; j += 2) {
-      const int colg = col0 + j * 16;
-      if (colg + 16 < p.N) {
-        const int oc = ((ncol_base + j * 16) >> 1) + fr;
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + r;
-            if (row < p.M) {
-              const float g = rnd<T>(acc[i][j][r]), u = rnd<T>(acc[i][j + 1][r]);
-              C[(size_t)row * p.ldc + oc] = fromf<T>(rnd<T>(silu(g)) * u);
-            }
-          }
-      }
-    }
-  } else {
-    const T* __restrict__ ls = (const T*)p.ls;
-    const T* R = (const T*)p.resid;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int col = col0 + j * 16;
-      if (col < p.N) {
-        const float bv = bias ? tof(bias[col]) : 0.f;
-        float lsv = 1.f;
-        if constexpr (EPI == EPI_LS_RESID) lsv = tof(ls[col]);
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = row0 + i * 16 + r;
-            if (row < p.M) {
-              float v = rnd<T>(acc[i][j][r] + bv);
-              if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
-              if constexpr (EPI == EPI_LS_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + rnd<T>(v * lsv);
-              if constexpr (EPI == EPI_RESID) v = (R ? tof(R[(size_t)row * p.ldr + col]) : 0.f) + v;
-              C[(size_t)row * p.ldc + col] = fromf<T>(v);
-            }
-          }
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves (2 M x 4 N), 4 phases per K-tile, the two wave groups (wm = 0 / 1) staggered by one
@@ -404,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   gemm8_segment<T>(p, m0, n0, 0, p.K / 64, smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
-  gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128 + fg * 4, n0 + wn * 64 + fr, n0 + wn * 64, fr);
+  gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -491,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(GemmP p, SkP sk) {
           covered = e < tile_end ? e : tile_end;
         }
       }
-      gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128 + fg * 4, n0 + wn * 64 + fr, n0 + wn * 64, fr);
+      gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
     }
     it += k1 - k0;
   }
