@@ -110,7 +110,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = rnd<T>(acc[i][j][r] + bv);
+            float v = acc[i][j][r] + bv;
+            if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
             if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
             if constexpr (EPI == EPI_LS_RESID) v = from_bits16<T>(rb[i][r]) + rnd<T>(v * lsv);
             if constexpr (EPI == EPI_RESID) v = from_bits16<T>(rb[i][r]) + v;
