@@ -7,11 +7,12 @@ shapes = [("vit_qkv", 3075, 9600, 3200, 0), ("vit_proj", 3075, 3200, 3200, 2), (
           ("dec_qkv", 3584, 4608, 3584, 0), ("dec_o", 3584, 3584, 3584, 3), ("dec_gateup", 3584, 37888, 3584, 4), ("dec_down", 3584, 3584, 18944, 3),
           ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0)]
 tiles = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 6, 3, 1]
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0      # operand magnitude: uniform(-scale, scale); power (and so the clock) depends on it
 p = lambda t: C.c_void_p(t.data_ptr())
 wsb = lib.omchat_op_gemm_sk_ws()
 ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
 for name, M, N, K, epi in shapes:
-    A = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); W = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
+    A = ((torch.rand(M, K, device="cuda") * 2 - 1) * scale).bfloat16(); W = ((torch.rand(N, K, device="cuda") * 2 - 1) * scale).bfloat16()
     bias = torch.zeros(N, device="cuda", dtype=torch.bfloat16); ls = torch.ones(N, device="cuda", dtype=torch.bfloat16)
     No = N // 2 if epi == 4 else N
     out = torch.zeros(M, No, device="cuda", dtype=torch.bfloat16); res = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
@@ -26,7 +27,7 @@ for name, M, N, K, epi in shapes:
             tile_code = tile
         def run():
             if tile == 20:      # 256^2 staggered kernel + stream-K tail
-                _lib.check(lib.omchat_op_gemm_sk(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, 2, p(ws), wsb, 0, None))
+                _lib.check(lib.omchat_op_gemm_sk(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, 2, p(ws), wsb, 1, None))
             else:
                 _lib.check(lib.omchat_op_gemm(_lib.BF16, p(A), K, p(W), K, p(out), No, M, N, K, p(bias) if epi in (1, 2) else None, p(ls), p(res), N, epi, tile_code, None))
         for _ in range(3): run()
