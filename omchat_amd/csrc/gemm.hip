@@ -661,6 +661,8 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "empty problem");
   OM_CHECK(a.K % 64 == 0, "K must be a multiple of 64");
   OM_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, "lda/ldw must be multiples of 8 elements (16-byte rows)");
+  OM_CHECK(a.ldc % 2 == 0 && (!a.resid || a.ldr % 2 == 0) && ((uintptr_t)a.C & 3) == 0 && ((uintptr_t)a.resid & 3) == 0,
+           "C / residual rows must start on 4-byte boundaries (the epilogue addresses them through buffer resources)");
   OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "A/W must be 16-byte aligned");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
   OM_CHECK(a.epi != EPI_LS_RESID || a.ls, "layer-scale epilogue needs ls");
