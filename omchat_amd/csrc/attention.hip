@@ -199,6 +199,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   const int vrow_lo = 4 * fg + tq;                       // (+32*ks, +16 for the second read)
   const int vswz = swz_v<D>(vrow_lo);                    // rows +16 / +32 keep the swizzle
 
+  const bool wave_active = q0 + wave * NQ * 16 < p.Sq;        // wave-uniform
   // tile t lives in buffer t & 1.  Iteration t: wait for own DMA of tile t, barrier (tile t visible to everyone, buffer
   // (t+1)&1 no longer read by anyone), issue tile t+1, then S^T, softmax and PV from buffer t & 1.
   if (t_end > 0) issue_tile(0, 0);
@@ -209,6 +210,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);
+    // a wave whose 16 * NQ queries all lie beyond Sq (the ViT's 1025 = 8 x 128 + 1 rows leave three such waves in the last query
+    // block) keeps staging and the barriers but skips the arithmetic
+    if (!wave_active) continue;
 
     // ---- S^T = K Q^T
     f32x4 s[NQ][4];
