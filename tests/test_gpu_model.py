@@ -277,3 +277,26 @@ def test_batched_decode_beyond_16_sequences(gpu_lib, dt):
         assert rel(lg2[i], ref2) < TOL_DEEP[dt]
     assert e.kv_lengths(b) == [n + 2 for n in lens]
     e.close()
+
+
+@pytest.mark.parametrize("S", [1, 2, 5, 63, 64, 65, 127, 129, 257])
+def test_prefill_ragged_lengths_then_decode(gpu_lib, S):
+    """prompt lengths around the 64-key / 128-query / 256-row tile edges (and the degenerate 1-token prompt): prefill logits and
+    two decode steps against the oracle"""
+    cfg = tiny()
+    dt = "bf16"
+    e = Engine(cfg, dtype=dt, max_seq=S + 8, max_batch=1, vision=False)
+    e.load_state_dict(synth.state_dict(cfg, 9))
+    sd = sd32(cfg, 9)
+    x = rnd(torch.randn(1, S, 256, generator=torch.Generator().manual_seed(S)) * 0.5, dt)
+    logits, hidden = e.prefill(x, want_hidden=True); sync()
+    cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+    h = oracle.qwen2_model(x, sd, cfg.text, cache)
+    assert rel(hidden, h) < TOL_DEEP[dt], rel(hidden, h)
+    assert rel(logits[0], oracle.lm_head(h, sd)[0, -1]) < TOL_DEEP[dt]
+    for tok in (4, 17):
+        nxt, lg = e.decode_step(torch.tensor([tok]), want_logits=True); sync()
+        ref = oracle.decode_step(torch.tensor([[tok]]), sd, cfg.text, cache)[0, 0]
+        assert rel(lg[0], ref) < TOL_DEEP[dt], rel(lg[0], ref)
+    assert e.kv_lengths(1) == [S + 2]
+    e.close()
