@@ -300,3 +300,19 @@ def test_prefill_ragged_lengths_then_decode(gpu_lib, S):
         assert rel(lg[0], ref) < TOL_DEEP[dt], rel(lg[0], ref)
     assert e.kv_lengths(1) == [S + 2]
     e.close()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pos_embed_resize_path_vs_reference_golden(gpu_lib, dt):
+    """checkpoint trained on a 112 px grid (8 x 8 patches) served at 56 px tiles (4 x 4): the position table is bicubic-resized at
+    load (InternVisionEmbeddings._get_pos_embed, modeling_intern_vit.py:82-88); embeddings against the reference's own output"""
+    g = golden("vit_embed_resize")
+    cfg_ckpt = tiny(image_size=112)
+    cfg_run = tiny(image_size=56)
+    sd = synth.state_dict(cfg_ckpt, int(g["seed"]))
+    assert sd[synth.TOWER + "embeddings.position_embedding"].shape[1] == 65
+    e = Engine(cfg_run, dtype=dt, max_seq=32, max_tiles=1, text=False)
+    e.load_state_dict(sd)
+    emb = e.vit_forward(T32(g["pixels"]), select_layer=0, select_feature="cls_patch"); sync()
+    assert emb.shape == (1, 17, 256) and rel(emb, T32(g["emb"])) < TOL[dt], rel(emb, T32(g["emb"]))
+    e.close()
