@@ -267,3 +267,16 @@ def test_entry_scripts_parse_and_bench_cli():
         ast.parse(open(f).read(), filename=f)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and all(flag in out.stdout for flag in ("--gpus", "--steps", "--warmup"))
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/omchat_hip.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in the signatures)"""
+    import os, shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "omchat_hip.h"\nint main(void) { omchat_config c; (void)c; return omchat_version() == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o", str(tmp_path / "hdr.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
