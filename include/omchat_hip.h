@@ -66,7 +66,7 @@ const char* omchat_last_error(void);
 const char* omchat_version(void);
 
 /* ---- loader: stands behind load_pretrained_model (omchat/model/builder.py:22-35) -------------------------------- */
-/* rccl_comm: ncclComm_t of the tensor-parallel group or NULL (tp_size == 1). */
+/* rccl_comm: ncclComm_t of the tensor-parallel group or NULL (tp_size == 1, or a peer group is attached with omchat_ctx_set_peer). */
 int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_size, void* rccl_comm, omchat_ctx** out);
 void omchat_ctx_destroy(omchat_ctx* ctx);
 /* name: omchat-native checkpoint key, e.g. "model.layers.3.mlp.gate_proj.weight";
@@ -220,6 +220,35 @@ int omchat_comm_init(const char id[128], int rank, int size, void** comm_out);
 /* the collective of the tensor-parallel data path, callable on its own: in-place sum over the ranks of `comm` */
 int omchat_comm_allreduce(void* comm, void* buf, size_t count, int dtype, void* stream);
 void omchat_comm_destroy(void* comm);
+
+int omchat_comm_count(void* comm, int* nranks);                  /* ncclCommCount: ranks of the communicator */
+
+/* ---- peer all-reduce over IPC-mapped buffers (xGMI P2P), csrc/comm.hip ------------------------------------------ */
+/* The decode-sized collective of SURVEY.md 8e: one-shot (every rank reads every rank's slot and sums in rank order: all ranks
+ * get identical bits) up to `oneshot_max` bytes, two-shot (reduce-scatter + all-gather by peer reads) above it.  One process
+ * per GPU: omchat_peer_create allocates the rank's shared buffer (capacity `cap_bytes` per message piece; longer messages are
+ * cut into pieces) and returns its 64-byte hipIpcMemHandle_t; the caller ships the handles of all ranks (any bootstrap channel;
+ * tp.py uses torch.distributed) and passes the `size` x 64-byte table to omchat_peer_connect.  omchat_peer_connect_local is the
+ * same-process variant (rank contexts in threads: pointers instead of IPC handles). */
+typedef struct omchat_peer omchat_peer;
+int omchat_peer_create(int rank, int size, size_t cap_bytes, omchat_peer** out, char handle_out[64]);
+int omchat_peer_connect(omchat_peer* p, const char* all_handles);
+void* omchat_peer_base(omchat_peer* p);
+int omchat_peer_connect_local(omchat_peer* p, void* const* bases);
+/* fast != 0: drop the one-lane system-scope release / acquire fences around the flag barrier (payload stays sc0 sc1);
+ * oneshot_max_bytes != 0: one-shot / two-shot switch point (default 256 KiB); max_blocks != 0: workgroups per call (default 64,
+ * <= 128; every workgroup of a call must be resident on every rank at once, so rank contexts that SHARE a GPU keep it small) */
+int omchat_peer_set_mode(omchat_peer* p, int fast, size_t oneshot_max_bytes, int max_blocks);
+size_t omchat_peer_capacity(omchat_peer* p);
+/* in-place sum over the ranks, `count` elements of OMCHAT_F16 / BF16 / F32; buf 16-byte aligned, byte count % 16 == 0 */
+int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, int dtype, void* stream);
+/* synchronises the device; *err_out = 1 when a barrier spin timed out (a peer died or never arrived) since the last call */
+int omchat_peer_error(omchat_peer* p, int* err_out);
+void omchat_peer_destroy(omchat_peer* p);
+/* use `peer` for the tensor-parallel sums of `ctx`: messages <= max_bytes (0 = keep 256 KiB), every size when all_sizes != 0
+ * or when the context has no RCCL communicator */
+int omchat_ctx_set_peer(omchat_ctx* ctx, omchat_peer* peer, size_t max_bytes, int all_sizes);
+int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls);
 
 /* Test seam: replace the RCCL all-reduce of a tensor-parallel context by a caller-supplied function (sum over ranks,
  * in place, `count` elements of dtype OMCHAT_F16/BF16/F32, ordered on `stream`).  Lets the whole TP dataflow be

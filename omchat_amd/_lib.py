@@ -82,6 +82,18 @@ _SIGS = {
     "omchat_comm_init": (_i, [C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "omchat_comm_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
     "omchat_comm_destroy": (None, [_vp]),
+    "omchat_comm_count": (_i, [_vp, C.POINTER(_i)]),
+    "omchat_peer_create": (_i, [_i, _i, _sz, C.POINTER(_vp), C.c_char_p]),
+    "omchat_peer_connect": (_i, [_vp, C.c_char_p]),
+    "omchat_peer_base": (_vp, [_vp]),
+    "omchat_peer_connect_local": (_i, [_vp, C.POINTER(_vp)]),
+    "omchat_peer_set_mode": (_i, [_vp, _i, _sz, _i]),
+    "omchat_peer_capacity": (_sz, [_vp]),
+    "omchat_peer_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "omchat_peer_error": (_i, [_vp, C.POINTER(_i)]),
+    "omchat_peer_destroy": (None, [_vp]),
+    "omchat_ctx_set_peer": (_i, [_vp, _vp, _sz, _i]),
+    "omchat_ctx_comm_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -6,7 +6,7 @@ SRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomchat_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

@@ -1,0 +1,301 @@
+// Peer all-reduce over IPC-mapped device buffers (xGMI peer-to-peer, one process per GPU) -- the tensor-parallel collective
+// for decode-sized messages ("custom peer-store + flag one-shot kernel"), with a two-shot form for large ones.
+// New functionality: the reference has no tensor parallelism.  RCCL (model.hip) stays available for every size.
+//
+// Every rank owns ONE shared allocation (uncached / fine-grained device memory, exported with hipIpcGetMemHandle and mapped by
+// every other rank):   [ flags: PEER_MAX_BLOCKS x PEER_MAX_RANKS u32 | data slot 0 | data slot 1 ],  slot = in[cap] + res[cap].
+//
+// One-shot (<= oneshot_max bytes): block i copies chunk i of the input into its OWN slot (write-through stores), the blocks
+// with index i of all ranks meet at a flag barrier, then every rank reads chunk i of EVERY rank's slot and sums in rank order
+// 0..n-1 in fp32 (so all ranks produce bit-identical results, and the same bits as a gather-then-sum), one rounding at the end.
+// Two-shot: copy-in, barrier, rank r reduces segment r (1/n of the message) from all slots into its result area, barrier,
+// every rank gathers the n reduced segments.  Per link and direction that is 2/n of the message, as a ring would move.
+//
+// Slots alternate with the call parity, which makes ONE barrier per call enough: a rank overwrites slot k&1 in call k+2 only
+// after it has left the barrier of call k+1, which every peer enters after its kernel of call k (its reads of that slot) is
+// complete (kernels of one rank are stream-ordered).  Barrier = per (block, source rank) monotonic epoch flags; the epoch
+// lives in a private per-block counter that the kernel itself advances (replay-invariant arguments: hipGraph-safe).
+// Visibility: payload stores are sc0 sc1 (system-scope write-through) and drained (vmcnt(0)) by every storing wave before the
+// workgroup barrier that precedes the flag stores; payload loads are sc0 sc1 (bypass L1 / L2).  Unless the `fast` mode is set,
+// one lane additionally issues a system-scope release before the flags and a system-scope acquire after the poll
+// (cdna_hip_programming.md Guideline 16).  Every spin is bounded by wall time; a timeout sets a sticky error word that the
+// host reads with omchat_peer_error().
+#include "kernels.h"
+#include "../../include/omchat_hip.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int PEER_MAX_RANKS = 8;
+constexpr int PEER_MAX_BLOCKS = 128;
+constexpr size_t PEER_FLAG_BYTES = 64 * 1024;      // >= PEER_MAX_BLOCKS * PEER_MAX_RANKS * 4, keeps the data 64-KiB aligned
+constexpr int PEER_THREADS = 512;
+constexpr unsigned long long PEER_TIMEOUT_TICKS = 10ull * 100000000ull;      // 10 s of the 100 MHz wall clock
+
+struct PeerK {
+  char* base[PEER_MAX_RANKS];      // every rank's shared allocation as mapped here (base[rank] = own)
+  unsigned* ctr;                   // private: per-block barrier epochs
+  unsigned* err;                   // private: sticky error word
+  int rank, size, fast;
+  size_t cap;                      // bytes of one `in` (= one `res`) area
+};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int AUX_SYS = 17;        // sc0 | sc1: system scope (write-through stores, cache-bypassing loads)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : bytes), 0x00020000);
+}
+
+// all workgroups with this block index, one per rank, meet here.  Called by every thread of the block.
+__device__ __forceinline__ void peer_barrier(const PeerK& k) {
+  __shared__ unsigned s_epoch;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned e = k.ctr[blockIdx.x] + 1u;
+    k.ctr[blockIdx.x] = e;
+    s_epoch = e;
+    if (!k.fast) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  const unsigned e = s_epoch;
+  if ((int)threadIdx.x < k.size) {
+    unsigned* theirs = reinterpret_cast<unsigned*>(k.base[threadIdx.x]) + blockIdx.x * PEER_MAX_RANKS + k.rank;
+    __hip_atomic_store(theirs, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned* mine = reinterpret_cast<unsigned*>(k.base[k.rank]) + blockIdx.x * PEER_MAX_RANKS + threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 1023u) == 0u && wall_clock64() - t0 > PEER_TIMEOUT_TICKS) { atomicExch(k.err, 1u); break; }
+    }
+  }
+  if (!k.fast && threadIdx.x == 0) {
+    // lane 0 polled its own flag above; the other pollers are in the same wave (size <= 8), so this fence follows every poll
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+template <typename T> struct Acc8;      // 16 bytes of T <-> fp32 lanes
+template <> struct Acc8<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void add(float (&a)[8], u32x4_t v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += __uint_as_float(v[j]);
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float (&a)[8]) {
+    return (u32x4_t){__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])};
+  }
+};
+template <typename T> struct Acc8 {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void add(float (&a)[8], u32x4_t v) {
+    const typename V8<T>::type x = __builtin_bit_cast(typename V8<T>::type, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += tof(x[j]);
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float (&a)[8]) {
+    typename V8<T>::type x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = fromf<T>(a[j]);
+    return __builtin_bit_cast(u32x4_t, x);
+  }
+};
+
+// sum of the 16-byte pieces at byte offset `off` of area `area_off` of every rank's slot, ranks in ascending order
+template <typename T>
+__device__ __forceinline__ u32x4_t peer_sum16(const PeerK& k, size_t area_off, int off) {
+  u32x4_t v[PEER_MAX_RANKS];
+#pragma unroll
+  for (int r = 0; r < PEER_MAX_RANKS; ++r)
+    if (r < k.size) v[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(k.base[r] + area_off, k.cap), off, 0, AUX_SYS);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < PEER_MAX_RANKS; ++r)
+    if (r < k.size) Acc8<T>::add(a, v[r]);
+  return Acc8<T>::pack(a);
+}
+
+// bytes: message size, multiple of 16.  parity: slot of this call.  Chunks of 16 B are dealt to (block, thread) round-robin.
+template <typename T>
+__global__ __launch_bounds__(PEER_THREADS) void peer_oneshot_kernel(PeerK k, void* buf, int bytes, int parity) {
+  const size_t slot = PEER_FLAG_BYTES + (size_t)parity * 2 * k.cap;
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(k.base[k.rank] + slot, k.cap);
+  const int n16 = bytes >> 4;
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>(buf);
+  for (int i = blockIdx.x * PEER_THREADS + threadIdx.x; i < n16; i += gridDim.x * PEER_THREADS)
+    __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, i << 4, 0, AUX_SYS);
+  peer_barrier(k);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(buf);
+  for (int i = blockIdx.x * PEER_THREADS + threadIdx.x; i < n16; i += gridDim.x * PEER_THREADS) dst[i] = peer_sum16<T>(k, slot, i << 4);
+}
+
+// two-shot: segment r = 16-B pieces [r * seg16, min((r+1) * seg16, n16))
+template <typename T>
+__global__ __launch_bounds__(PEER_THREADS) void peer_twoshot_kernel(PeerK k, void* buf, int bytes, int parity) {
+  const size_t slot = PEER_FLAG_BYTES + (size_t)parity * 2 * k.cap;
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(k.base[k.rank] + slot, 2 * k.cap);
+  const int n16 = bytes >> 4;
+  const int seg16 = (n16 + k.size - 1) / k.size;
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>(buf);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>(buf);
+  const int stride = gridDim.x * PEER_THREADS, t0 = blockIdx.x * PEER_THREADS + threadIdx.x;
+  for (int i = t0; i < n16; i += stride) __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, i << 4, 0, AUX_SYS);
+  peer_barrier(k);
+  // reduce my segment into my result area (and into the output)
+  const int lo = k.rank * seg16, hi = lo + seg16 < n16 ? lo + seg16 : n16;
+  for (int i = lo + t0; i < hi; i += stride) {
+    const u32x4_t s = peer_sum16<T>(k, slot, i << 4);
+    __builtin_amdgcn_raw_buffer_store_b128(s, mine, (int)k.cap + (i << 4), 0, AUX_SYS);
+    dst[i] = s;
+  }
+  peer_barrier(k);
+  // gather the other segments: piece j of segment r was reduced by rank r's thread with the same (block, thread) mapping
+  for (int rr = 1; rr < k.size; ++rr) {
+    const int r = (k.rank + rr) % k.size;            // start with the next rank: spreads the reads over the links
+    const int l2 = r * seg16, h2 = l2 + seg16 < n16 ? l2 + seg16 : n16;
+    const __amdgpu_buffer_rsrc_t theirs = rsrc_of(k.base[r] + slot + k.cap, k.cap);
+    for (int i = l2 + t0; i < h2; i += stride) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(theirs, i << 4, 0, AUX_SYS);
+  }
+}
+
+}  // namespace
+
+struct omchat_peer {
+  int rank = 0, size = 1, fast = 0;
+  size_t cap = 0, total = 0;
+  void* local = nullptr;
+  void* base[PEER_MAX_RANKS] = {};
+  bool opened[PEER_MAX_RANKS] = {};
+  unsigned* ctr = nullptr;
+  unsigned* err = nullptr;
+  unsigned long calls = 0;
+  size_t oneshot_max = 256 * 1024;
+  int max_blocks = 64;
+};
+
+extern "C" int omchat_peer_create(int rank, int size, size_t cap_bytes, omchat_peer** out, char handle_out[64]) {
+  OM_CHECK(out && handle_out, "null argument");
+  OM_CHECK(size >= 1 && size <= PEER_MAX_RANKS && rank >= 0 && rank < size, "rank / size out of range (<= 8 ranks)");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  static_assert(PEER_MAX_BLOCKS * PEER_MAX_RANKS * 4 <= PEER_FLAG_BYTES, "flag area too small");
+  cap_bytes = (cap_bytes + 65535) / 65536 * 65536;
+  OM_CHECK(cap_bytes >= 65536 && cap_bytes <= ((size_t)512 << 20), "capacity must be 64 KiB .. 512 MiB (32-bit buffer offsets)");
+  omchat_peer* p = new omchat_peer();
+  p->rank = rank; p->size = size; p->cap = cap_bytes; p->total = PEER_FLAG_BYTES + 4 * cap_bytes;
+  hipError_t e = hipExtMallocWithFlags(&p->local, p->total, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p->local, p->total, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p->local, p->total); }
+  if (e != hipSuccess) { delete p; omchat_set_error(std::string("omchat_peer_create: allocation failed: ") + hipGetErrorString(e)); return 2; }
+  auto fail = [&](const char* what, hipError_t er) { omchat_set_error(std::string("omchat_peer_create: ") + what + ": " + hipGetErrorString(er)); (void)hipFree(p->local); delete p; return 2; };
+  if ((e = hipMemset(p->local, 0, PEER_FLAG_BYTES)) != hipSuccess) return fail("memset", e);
+  if ((e = hipMalloc((void**)&p->ctr, (PEER_MAX_BLOCKS + 16) * 4)) != hipSuccess) return fail("hipMalloc", e);
+  if ((e = hipMemset(p->ctr, 0, (PEER_MAX_BLOCKS + 16) * 4)) != hipSuccess) return fail("memset", e);
+  p->err = p->ctr + PEER_MAX_BLOCKS;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail("sync", e);
+  hipIpcMemHandle_t h;
+  memset(&h, 0, sizeof(h));
+  if (size > 1) {
+    e = hipIpcGetMemHandle(&h, p->local);
+    if (e != hipSuccess) { (void)hipGetLastError(); memset(&h, 0, sizeof(h)); }      // same-process groups connect by pointer instead
+  }
+  memcpy(handle_out, &h, 64);
+  p->base[rank] = p->local;
+  *out = p;
+  return 0;
+}
+
+extern "C" int omchat_peer_connect(omchat_peer* p, const char* all_handles) {
+  OM_CHECK(p && all_handles, "null argument");
+  for (int r = 0; r < p->size; ++r) {
+    if (r == p->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, all_handles + (size_t)r * 64, 64);
+    void* q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { omchat_set_error(std::string("omchat_peer_connect: hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e)); return 2; }
+    p->base[r] = q; p->opened[r] = true;
+  }
+  return 0;
+}
+
+extern "C" void* omchat_peer_base(omchat_peer* p) { return p ? p->local : nullptr; }
+
+extern "C" int omchat_peer_connect_local(omchat_peer* p, void* const* bases) {
+  OM_CHECK(p && bases, "null argument");
+  for (int r = 0; r < p->size; ++r) if (r != p->rank) { OM_CHECK(bases[r], "null peer base"); p->base[r] = bases[r]; }
+  return 0;
+}
+
+extern "C" int omchat_peer_set_mode(omchat_peer* p, int fast, size_t oneshot_max_bytes, int max_blocks) {
+  OM_CHECK(p, "null argument");
+  OM_CHECK(max_blocks >= 0 && max_blocks <= PEER_MAX_BLOCKS, "max_blocks out of range (<= 128)");
+  p->fast = fast != 0;
+  if (oneshot_max_bytes) p->oneshot_max = oneshot_max_bytes;
+  if (max_blocks) p->max_blocks = max_blocks;
+  return 0;
+}
+
+extern "C" size_t omchat_peer_capacity(omchat_peer* p) { return p ? p->cap : 0; }
+
+extern "C" int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, int dtype, void* stream) {
+  OM_CHECK(p && buf, "null argument");
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == 2, "bad dtype");
+  if (p->size == 1 || count == 0) return 0;
+  for (int r = 0; r < p->size; ++r) OM_CHECK(p->base[r], "peer group is not connected");
+  const size_t esz = dtype == 2 ? 4 : 2;
+  OM_CHECK(((uintptr_t)buf & 15) == 0 && (count * esz) % 16 == 0, "buffer and byte count must be multiples of 16");
+  hipStream_t s = (hipStream_t)stream;
+  PeerK k{};
+  for (int r = 0; r < p->size; ++r) k.base[r] = (char*)p->base[r];
+  k.ctr = p->ctr; k.err = p->err; k.rank = p->rank; k.size = p->size; k.fast = p->fast; k.cap = p->cap;
+  size_t done = 0;
+  const size_t total = count * esz;
+  while (done < total) {
+    const size_t piece = total - done < p->cap ? total - done : p->cap;
+    const int parity = (int)(p->calls++ & 1);
+    char* b = (char*)buf + done;
+    const bool one = piece <= p->oneshot_max;
+    int grid = (int)((piece / 16 + PEER_THREADS * 4 - 1) / (PEER_THREADS * 4));       // ~4 x 16 B per thread
+    grid = grid < 1 ? 1 : (grid > p->max_blocks ? p->max_blocks : grid);
+#define OM_PEER_LAUNCH(T)                                                                                                   \
+  do {                                                                                                                      \
+    if (one) hipLaunchKernelGGL(peer_oneshot_kernel<T>, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, parity);   \
+    else hipLaunchKernelGGL(peer_twoshot_kernel<T>, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, parity);       \
+  } while (0)
+    if (dtype == 2) OM_PEER_LAUNCH(float);
+    else if (dtype == OMCHAT_F16) OM_PEER_LAUNCH(f16);
+    else OM_PEER_LAUNCH(bf16);
+#undef OM_PEER_LAUNCH
+    OM_LAUNCH_CHECK();
+    done += piece;
+  }
+  return 0;
+}
+
+// blocks until the device is idle; returns 0 and *err_out = 1 when a barrier spin timed out since the last call (sticky, cleared here)
+extern "C" int omchat_peer_error(omchat_peer* p, int* err_out) {
+  OM_CHECK(p && err_out, "null argument");
+  unsigned e = 0;
+  OM_HIP(hipDeviceSynchronize());
+  OM_HIP(hipMemcpy(&e, p->err, 4, hipMemcpyDeviceToHost));
+  if (e) OM_HIP(hipMemset(p->err, 0, 4));
+  *err_out = (int)e;
+  return 0;
+}
+
+extern "C" void omchat_peer_destroy(omchat_peer* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < p->size; ++r) if (p->opened[r]) (void)hipIpcCloseMemHandle(p->base[r]);
+  if (p->local) (void)hipFree(p->local);
+  if (p->ctr) (void)hipFree(p->ctr);
+  delete p;
+}

@@ -157,20 +157,32 @@ struct omchat_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_chunk[AR_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_comm_done = nullptr;
-  int allreduce(void* buf, size_t count, hipStream_t s) {
+  // transports of the tensor-parallel sum, in order of precedence: the test hook; the peer (IPC / xGMI) all-reduce of comm.hip for
+  // messages up to peer_max bytes (one-shot: decode-sized) or for every size when there is no RCCL communicator / peer_all is set;
+  // RCCL otherwise.  Every buffer passed here is context-owned with >= 16 bytes of slack, so the peer path may round the count up
+  // to whole 16-byte pieces (the extra elements are summed and never read).
+  omchat_peer* peer = nullptr;
+  size_t peer_max = 256 * 1024;
+  bool peer_all = false;
+  long n_ar_peer = 0, n_ar_rccl = 0;
+  int allreduce_any(void* buf, size_t count, int dtype, hipStream_t s) {
     if (tp_size == 1) return 0;
-    if (hook) return hook(hook_user, buf, count, dt, s);
-    ncclResult_t r = ncclAllReduce(buf, buf, count, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, ncclSum, comm, s);
+    if (hook) return hook(hook_user, buf, count, dtype, s);
+    const size_t esz = dtype == OMCHAT_F32 ? 4 : 2;
+    if (peer && (count * esz <= peer_max || !comm || peer_all)) {
+      const size_t per16 = 16 / esz;
+      ++n_ar_peer;
+      return omchat_peer_allreduce(peer, buf, (count + per16 - 1) / per16 * per16, dtype, s);
+    }
+    if (!comm) { omchat_set_error("tensor-parallel context without a transport: pass an RCCL communicator or call omchat_ctx_set_peer"); return 1; }
+    ++n_ar_rccl;
+    const ncclDataType_t t = dtype == OMCHAT_F32 ? ncclFloat32 : (dtype == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16);
+    ncclResult_t r = ncclAllReduce(buf, buf, count, t, ncclSum, comm, s);
     if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
     return 0;
   }
-  int allreduce_f32(float* buf, size_t count, hipStream_t s) {
-    if (tp_size == 1) return 0;
-    if (hook) return hook(hook_user, buf, count, OMCHAT_F32, s);
-    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, s);
-    if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
-    return 0;
-  }
+  int allreduce(void* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, dt, s); }
+  int allreduce_f32(float* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, OMCHAT_F32, s); }
 };
 
 namespace {
@@ -299,7 +311,7 @@ int build(omchat_ctx* ctx) {
     TRY(ctx->alloc(&ctx->vw_h, M * I * 2));
     TRY(ctx->alloc(&ctx->vw_feat, M * C * 2));
     TRY(ctx->alloc(&ctx->vw_proj, M * c.t_hidden * 2));
-    TRY(ctx->alloc((void**)&ctx->vw_sumsq, M * 2 * 4));
+    TRY(ctx->alloc((void**)&ctx->vw_sumsq, M * 2 * 4 + 64));
   }
   if (c.t_layers > 0) {
     const size_t R = (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch);
@@ -363,7 +375,6 @@ extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_s
   OM_CHECK(cfg && out, "null argument");
   OM_CHECK(cfg->dtype == OMCHAT_F16 || cfg->dtype == OMCHAT_BF16, "dtype must be OMCHAT_F16 or OMCHAT_BF16");
   OM_CHECK(tp_size >= 1 && tp_rank >= 0 && tp_rank < tp_size, "bad tensor-parallel rank/size");
-  OM_CHECK(tp_size == 1 || rccl_comm, "tp_size > 1 needs an RCCL communicator");
   OM_CHECK(cfg->v_head_dim == 0 || cfg->v_head_dim == 128 || cfg->v_head_dim == 64, "v_head_dim must be 128 or 64");
   OM_CHECK(cfg->v_norm_type == 0 || cfg->v_norm_type == 1, "v_norm_type must be 0 (RMSNorm) or 1 (LayerNorm)");
   OM_CHECK(cfg->v_layers == 0 || (cfg->v_hidden % 64 == 0 && cfg->v_mlp % 64 == 0 && cfg->v_image % cfg->v_patch == 0),
@@ -1002,6 +1013,21 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   return 0;
 }
 
+extern "C" int omchat_ctx_set_peer(omchat_ctx* ctx, omchat_peer* peer, size_t max_bytes, int all_sizes) {
+  OM_CHECK(ctx, "null ctx");
+  ctx->peer = peer;
+  if (max_bytes) ctx->peer_max = max_bytes;
+  ctx->peer_all = all_sizes != 0;
+  return 0;
+}
+
+extern "C" int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls) {
+  OM_CHECK(ctx, "null ctx");
+  if (peer_calls) *peer_calls = ctx->n_ar_peer;
+  if (rccl_calls) *rccl_calls = ctx->n_ar_rccl;
+  return 0;
+}
+
 extern "C" int omchat_set_allreduce_hook(omchat_ctx* ctx, omchat_allreduce_fn fn, void* user) {
   OM_CHECK(ctx, "null ctx");
   ctx->hook = fn; ctx->hook_user = user;
@@ -1062,6 +1088,12 @@ extern "C" int omchat_comm_allreduce(void* comm, void* buf, size_t count, int dt
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == OMCHAT_F32, "bad dtype");
   ncclResult_t r = ncclAllReduce(buf, buf, count, t, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
   if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
+  return 0;
+}
+extern "C" int omchat_comm_count(void* comm, int* nranks) {
+  OM_CHECK(comm && nranks, "null argument");
+  ncclResult_t r = ncclCommCount((ncclComm_t)comm, nranks);
+  if (r != ncclSuccess) { omchat_set_error(std::string("ncclCommCount: ") + ncclGetErrorString(r)); return 3; }
   return 0;
 }
 extern "C" void omchat_comm_destroy(void* comm) {

@@ -88,7 +88,38 @@ class Engine:
                 raise KeyError(self.lib.omchat_last_error().decode())
 
     def fill_synthetic(self, seed=0):
-        check(self.lib.omchat_fill_synthetic(self.h, seed))
+        """Deterministic synthetic weights (omchat_amd/synth.py's generator, evaluated on the device).  Under tensor parallelism
+        every rank generates each FULL tensor on its GPU and keeps its shard (tp.shard_tensor semantics: zero-padded heads,
+        replicated kv heads), so a TP = N group computes the same function as the TP = 1 context filled with the same seed."""
+        if self.tp_size == 1:
+            check(self.lib.omchat_fill_synthetic(self.h, seed))
+            return
+        import math
+        torch = _torch()
+        from . import synth
+        from .tp import shard_tensor
+        with torch.cuda.device(self.device):
+            for key, shape, std, off in synth.tensor_specs(self.cfg):
+                vis = key.startswith(synth.TOWER) or key.startswith("model.mm_projector")
+                if (vis and self.c.v_layers == 0) or (not vis and self.c.t_layers == 0):
+                    continue
+                n = int(np.prod(shape))
+                full = torch.empty(n, dtype=self.torch_dtype, device=self.device)
+                scale = float(np.float32(std)) * math.sqrt(3.0)      # same arithmetic as omchat_fill_synthetic (model.hip)
+                check(self.lib.omchat_op_fill_uniform(self.dtype_code, ptr(full), n, (synth.fnv1a64(key) ^ seed) & 0xFFFFFFFFFFFFFFFF,
+                                                      scale, off, cur_stream()))
+                torch.cuda.current_stream().synchronize()
+                self.load_tensor(key, shard_tensor(key, full.view(*shape), self.cfg, self.tp_rank, self.tp_size))
+                del full
+
+    def set_peer(self, peer, max_bytes=0, all_sizes=False):
+        """attach a peer all-reduce group member (tp.init_peer) for the tensor-parallel sums of this context"""
+        check(self.lib.omchat_ctx_set_peer(self.h, peer, max_bytes, int(all_sizes)))
+
+    def comm_stats(self):
+        a, b = C.c_long(0), C.c_long(0)
+        check(self.lib.omchat_ctx_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(peer_allreduces=a.value, rccl_allreduces=b.value)
 
     def enable_fp8_decode(self, on=True):
         """Weight-only OCP e4m3 replica of the decode-streamed decoder weights (quantised on first call); batch-1 decode only."""

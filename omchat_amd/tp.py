@@ -58,28 +58,46 @@ def vit_head_map(cfg, rank, size):
     return list(range(start, start + n)) + [-1] * (hl - n)
 
 
+def _is_torch(x):
+    try:
+        import torch
+        return torch.is_tensor(x)
+    except ImportError:
+        return False
+
+
+def _cat(parts):
+    if _is_torch(parts[0]):
+        import torch
+        return torch.cat(parts, dim=0)
+    return np.concatenate(parts, axis=0)
+
+
+def _t(x):
+    return x.t() if _is_torch(x) else x.T
+
+
 def _take_heads(x, heads, axis_len_per_head=128):
-    """x [..heads*128.., cols] along axis 0 -> rows of the selected heads (zeros for -1)."""
-    x = np.asarray(x)
+    """x [..heads*hd.., cols] along axis 0 -> rows of the selected heads (zeros for -1).  numpy or torch (any device / dtype)."""
+    if not _is_torch(x):
+        x = np.asarray(x)
     blocks = x.reshape(-1, axis_len_per_head, *x.shape[1:])
-    z = np.zeros_like(blocks[0])
-    return np.concatenate([blocks[h] if h >= 0 else z for h in heads], axis=0)
+    z = blocks[0] * 0
+    return _cat([blocks[h] if h >= 0 else z for h in heads])
 
 
 def shard_tensor(name, tensor, cfg, rank, size):
-    """Full tensor (numpy or torch) -> the rank-local tensor the C ABI expects under the same name."""
+    """Full tensor (numpy or torch, host or device) -> the rank-local tensor the C ABI expects under the same name.
+    torch tensors keep their dtype and device (the 13B synthetic weights are sharded on the GPU), numpy goes through fp32."""
     if size == 1:
         return tensor
-    import torch
-    is_torch = torch.is_tensor(tensor)
-    x = tensor.detach().cpu().float().numpy() if is_torch else np.asarray(tensor, dtype=np.float32)
-    out = _shard_np(name, x, cfg, rank, size)
-    return torch.from_numpy(np.ascontiguousarray(out)) if is_torch else np.ascontiguousarray(out)
+    if _is_torch(tensor):
+        return _shard(name, tensor, cfg, rank, size).contiguous()
+    return np.ascontiguousarray(_shard(name, np.asarray(tensor, dtype=np.float32), cfg, rank, size))
 
 
-def _shard_np(name, x, cfg, rank, size):
+def _shard(name, x, cfg, rank, size):
     v, t = cfg.vision, cfg.text
-    d = local_dims(cfg, rank, size)
     sl = lambda n: slice(rank * (n // size), (rank + 1) * (n // size))
     if ".encoder.layers." in name:
         vh = vit_head_map(cfg, rank, size)
@@ -87,11 +105,11 @@ def _shard_np(name, x, cfg, rank, size):
         hd = v.get("head_dim", 128)
         if name.endswith("attn.qkv.weight"):
             q, k, vv = x[:C], x[C:2 * C], x[2 * C:]
-            return np.concatenate([_take_heads(q, vh, hd), _take_heads(k, vh, hd), _take_heads(vv, vh, hd)], axis=0)
+            return _cat([_take_heads(q, vh, hd), _take_heads(k, vh, hd), _take_heads(vv, vh, hd)])
         if name.endswith("attn.q_norm.weight") or name.endswith("attn.k_norm.weight"):
             return _take_heads(x, vh, hd)
         if name.endswith("attn.proj.weight"):
-            return _take_heads(x.T, vh, hd).T
+            return _t(_take_heads(_t(x), vh, hd))
         if name.endswith("mlp.fc1.weight") or name.endswith("mlp.fc1.bias"):
             return x[sl(v["intermediate_size"])]
         if name.endswith("mlp.fc2.weight"):
@@ -104,7 +122,7 @@ def _shard_np(name, x, cfg, rank, size):
         if "k_proj" in name or "v_proj" in name:
             return _take_heads(x, kvs)
         if name.endswith("o_proj.weight"):
-            return _take_heads(x.T, qs).T
+            return _t(_take_heads(_t(x), qs))
         if "gate_proj" in name or "up_proj" in name:
             return x[sl(t["intermediate_size"])]
         if name.endswith("down_proj.weight"):
@@ -113,6 +131,19 @@ def _shard_np(name, x, cfg, rank, size):
     if name == "lm_head.weight":
         return x[sl(t["vocab_size"])]
     return x
+
+
+def rccl_libraries_mapped():
+    """paths of every librccl mapped into this process (two different RCCL builds in one process are a bug: VERDICT r01)"""
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    out.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(out)
 
 
 def init_comm(rank, size):
@@ -132,4 +163,55 @@ def init_comm(rank, size):
     raw = bytes(t.tolist())
     comm = C.c_void_p()
     _lib.check(lib.omchat_comm_init(raw, rank, size, C.byref(comm)))
+    libs = rccl_libraries_mapped()
+    if len(libs) > 1:
+        raise _lib.OmchatError(f"more than one RCCL build is mapped into this process: {libs}")
+    n = C.c_int(0)
+    _lib.check(lib.omchat_comm_count(comm, C.byref(n)))
+    if n.value != size:
+        raise _lib.OmchatError(f"RCCL communicator has {n.value} ranks, expected {size}")
     return comm
+
+
+def init_peer(rank, size, cap_bytes=64 << 20, fast=False, oneshot_max=0, max_blocks=0):
+    """Create this rank's peer all-reduce group member (csrc/comm.hip): allocate the shared buffer, exchange the 64-byte IPC
+    handles over the initialised torch.distributed group (bootstrap plumbing), map every peer's buffer."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    lib = _lib.lib()
+    peer = C.c_void_p()
+    hbuf = C.create_string_buffer(64)
+    _lib.check(lib.omchat_peer_create(rank, size, cap_bytes, C.byref(peer), hbuf))
+    mine = torch.tensor(list(hbuf.raw), dtype=torch.uint8)
+    table = [torch.empty(64, dtype=torch.uint8) for _ in range(size)]
+    dist.all_gather(table, mine)
+    raw = b"".join(bytes(t.tolist()) for t in table)
+    _lib.check(lib.omchat_peer_connect(peer, raw))
+    _lib.check(lib.omchat_peer_set_mode(peer, int(fast), oneshot_max, max_blocks))
+    dist.barrier()          # nobody launches a kernel that touches a peer buffer before every mapping exists
+    return peer
+
+
+def peer_selftest(peer, rank, size, iters=64, sizes=(16, 3584 * 4, 3 * 3584 * 4, 1 << 20, 5 << 20)):
+    """Run the peer all-reduce on data whose sum every rank can compute by itself (small integers: exact in fp32, bf16 and f16)
+    and compare on the device.  Returns (ok, detail).  Catches stale reads / lost flags on the hardware it runs on."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.lib()
+    bad = 0
+    for it in range(iters):
+        for nbytes in sizes:
+            for dt, code in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16)):
+                n = nbytes // (4 if dt == torch.float32 else 2)
+                i = torch.arange(n, device="cuda", dtype=torch.int64)
+                val = lambda r: (((i * 7 + it * 13 + r * 5) % 31) - 15).to(torch.float32)      # |sum over 8 ranks| <= 120: exact in bf16
+                x = val(rank).to(dt).contiguous()
+                _lib.check(lib.omchat_peer_allreduce(peer, _lib.ptr(x), n, code, _lib.cur_stream()))
+                ref = sum(val(r) for r in range(size))
+                bad += int((x.to(torch.float32) != ref).sum())
+    err = C.c_int(0)
+    _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
+    return bad == 0 and err.value == 0, dict(mismatched_elements=bad, timeout=bool(err.value), iters=iters)

@@ -1,0 +1,226 @@
+"""GPU (one device): the peer all-reduce of csrc/comm.hip (IPC-mapped buffers + flag barrier; the xGMI collective for
+decode-sized tensor-parallel sums).
+
+Exercised three ways on ONE GPU: (1) rank members in threads of one process (pointers exchanged directly), (2) rank members in
+separate PROCESSES that map each other's buffers with hipIpcGetMemHandle / hipIpcOpenMemHandle exactly as one-process-per-GPU
+tensor parallelism does, (3) two tensor-parallel engine processes whose every all-reduce goes through it, against the TP = 1
+engine.  Sums are checked bit for bit (fixed rank order, fp32, one rounding)."""
+import ctypes as C
+import os
+import socket
+import threading
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from omchat_amd import _lib, synth, tp
+from omchat_amd.config import tiny
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _local_group(lib, n, cap, max_blocks=16, fast=False, oneshot_max=0):
+    peers = []
+    for r in range(n):
+        p = C.c_void_p(); h = C.create_string_buffer(64)
+        _lib.check(lib.omchat_peer_create(r, n, cap, C.byref(p), h))
+        peers.append(p)
+    bases = (C.c_void_p * n)(*[lib.omchat_peer_base(p) for p in peers])
+    for p in peers:
+        _lib.check(lib.omchat_peer_connect_local(p, bases))
+        _lib.check(lib.omchat_peer_set_mode(p, int(fast), oneshot_max, max_blocks))
+    return peers
+
+
+def _threads(fn, n):
+    out, err = [None] * n, [None] * n
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[r] = fn(r)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:      # noqa
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+# Rank members in THREADS of one process only work for 2 ranks: HIP multiplexes the streams of a process onto a few hardware queues,
+# and two spin-waiting kernels that land in the same queue wait for each other until the timeout (measured: 4 threads -> every call
+# ran into the 10 s bound).  One process per rank -- the deployment shape -- has a queue set per rank: the process tests below cover
+# 2 and 4 ranks.
+@pytest.mark.parametrize("n,fast", [(2, False), (2, True)])
+def test_peer_allreduce_threads_bit_exact(gpu_lib, n, fast):
+    peers = _local_group(gpu_lib, n, 4 << 20, max_blocks=8, fast=fast)
+    res = _threads(lambda r: tp.peer_selftest(peers[r], r, n, iters=3, sizes=(16, 3584 * 4, 40000, 300 * 1024, 3 << 20)), n)
+    for ok, detail in res:
+        assert ok, detail
+    for p in peers:
+        gpu_lib.omchat_peer_destroy(p)
+
+
+def test_peer_allreduce_random_values_equal_ordered_fp32_sum(gpu_lib):
+    """random bf16 / f16 / fp32 payloads: the result is the fp32 sum in rank order rounded once (what gather + sum gives)"""
+    n = 2
+    peers = _local_group(gpu_lib, n, 2 << 20, max_blocks=8)
+    cases = [(torch.bfloat16, _lib.BF16, 3584 * 5), (torch.float16, _lib.F16, 3200 * 7), (torch.float32, _lib.F32, 3 * 3584), (torch.bfloat16, _lib.BF16, 1 << 20)]
+    data = {(r, i): torch.randn(c[2], generator=torch.Generator().manual_seed(100 * r + i)).to(c[0]) for r in range(n) for i, c in enumerate(cases)}
+
+    def run(r):
+        outs = []
+        for i, (dt, code, cnt) in enumerate(cases):
+            x = data[(r, i)].cuda()
+            _lib.check(gpu_lib.omchat_peer_allreduce(peers[r], _lib.ptr(x), cnt, code, _lib.cur_stream()))
+            torch.cuda.current_stream().synchronize()
+            outs.append(x.cpu())
+        return outs
+    res = _threads(run, n)
+    for i, (dt, code, cnt) in enumerate(cases):
+        acc = torch.zeros(cnt, dtype=torch.float32)
+        for r in range(n):
+            acc = acc + data[(r, i)].float()
+        want = acc.to(dt)
+        for r in range(n):
+            assert torch.equal(res[r][i], want), (i, r)
+    for p in peers:
+        gpu_lib.omchat_peer_destroy(p)
+
+
+def test_peer_timeout_is_reported_not_hung(gpu_lib):
+    """a rank that never arrives: the waiting kernel gives up after its wall-clock bound and raises the sticky error word"""
+    if os.environ.get("OMCHAT_SKIP_SLOW"):
+        pytest.skip("slow")
+    peers = _local_group(gpu_lib, 2, 1 << 20, max_blocks=2)
+    x = torch.ones(4096, device="cuda")
+    _lib.check(gpu_lib.omchat_peer_allreduce(peers[0], _lib.ptr(x), 4096, _lib.F32, _lib.cur_stream()))      # rank 1 never calls
+    err = C.c_int(0)
+    _lib.check(gpu_lib.omchat_peer_error(peers[0], C.byref(err)))
+    assert err.value == 1
+    _lib.check(gpu_lib.omchat_peer_error(peers[0], C.byref(err)))
+    assert err.value == 0          # sticky until read, then cleared
+    for p in peers:
+        gpu_lib.omchat_peer_destroy(p)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# separate processes on one GPU: the IPC path (hipIpcGetMemHandle / hipIpcOpenMemHandle), bootstrap over gloo
+# ---------------------------------------------------------------------------------------------------------------------
+def _proc_selftest(rank, size, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        peer = tp.init_peer(rank, size, cap_bytes=4 << 20, max_blocks=8)
+        ok, detail = tp.peer_selftest(peer, rank, size, iters=8, sizes=(16, 3584 * 4, 300 * 1024, 3 << 20))
+        dist.barrier()
+        _lib.lib().omchat_peer_destroy(peer)
+        q.put((rank, ok, detail))
+    except BaseException as e:      # noqa
+        q.put((rank, False, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _proc_tp_engine(rank, size, port, q):
+    import torch.distributed as dist
+    from omchat_amd.engine import Engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        cfg = tiny(q_heads=7, kv_heads=1, heads_v=3)
+        peer = tp.init_peer(rank, size, cap_bytes=4 << 20, max_blocks=8)
+        e = Engine(cfg, dtype="bf16", max_seq=128, max_batch=2, max_tiles=2, tp_rank=rank, tp_size=size, comm=None)
+        e.set_peer(peer, 0, all_sizes=True)
+        e.fill_synthetic(13)                   # device-side sharding of the TP = 1 synthetic values
+        px = torch.from_numpy(synth.pixels(2, 56, 1))
+        ids = torch.tensor([[3, -200, 17, -200, 19, 20]])
+        feats = e.encode_images(px)
+        embeds, lengths, _ = e.splice(ids, None, feats)
+        logits, _ = e.prefill(embeds, lengths)
+        first = e.argmax(logits)
+        toks = [int(first[0])]
+        tok = first
+        for _ in range(6):
+            tok, _ = e.decode_step(tok)
+            toks.append(int(tok[0]))
+        torch.cuda.synchronize()
+        err = C.c_int(0)
+        _lib.check(_lib.lib().omchat_peer_error(peer, C.byref(err)))
+        st = e.comm_stats()
+        dist.barrier()
+        q.put((rank, feats.float().cpu().numpy(), logits.float().cpu().numpy(), toks, err.value, st))
+        e.close()
+        _lib.lib().omchat_peer_destroy(peer)
+    except BaseException as e:      # noqa
+        import traceback
+        q.put((rank, None, traceback.format_exc(), None, 1, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, size, timeout=240):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=timeout))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    return sorted(res, key=lambda x: x[0])
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_peer_allreduce_across_processes_ipc(gpu_lib, size):
+    res = _spawn(_proc_selftest, size)
+    assert len(res) == size
+    for rank, ok, detail in res:
+        assert ok, (rank, detail)
+
+
+def test_tp2_engine_processes_over_peer_allreduce_equal_tp1(gpu_lib):
+    """two rank PROCESSES, every tensor-parallel sum on the peer kernels, weights = device-side shards of the synthetic TP = 1
+    values: features / logits agree with the TP = 1 engine within the multi-layer tolerance, both ranks bit-identical"""
+    from gpu_util import rel, TOL_DEEP
+    from omchat_amd.engine import Engine
+    res = _spawn(_proc_tp_engine, 2)
+    for r in res:
+        assert r[1] is not None, r[2]
+        assert r[4] == 0
+        assert r[5]["peer_allreduces"] > 0 and r[5]["rccl_allreduces"] == 0
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][3] == res[1][3]
+    cfg = tiny(q_heads=7, kv_heads=1, heads_v=3)
+    e = Engine(cfg, dtype="bf16", max_seq=128, max_batch=2, max_tiles=2)
+    e.fill_synthetic(13)
+    px = torch.from_numpy(synth.pixels(2, 56, 1))
+    ids = torch.tensor([[3, -200, 17, -200, 19, 20]])
+    feats = e.encode_images(px)
+    embeds, lengths, _ = e.splice(ids, None, feats)
+    logits, _ = e.prefill(embeds, lengths)
+    torch.cuda.synchronize()
+    assert rel(torch.from_numpy(res[0][1]), feats) < TOL_DEEP["bf16"]
+    full = np.concatenate([res[0][2], res[1][2]], axis=-1)
+    assert rel(torch.from_numpy(full), logits) < TOL_DEEP["bf16"]
+    e.close()
