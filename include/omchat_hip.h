@@ -91,9 +91,11 @@ int omchat_encode_images(omchat_ctx* ctx, const void* pixels, int n_tiles, int s
 /* Host-side plan (integers only).  ids int64 [b,T] with -200 sentinels; mask uint8 [b,T] or NULL; n_tok rows per
  * tile; padding_side 0 = right, 1 = left; max_length <= 0 = none.  Writes src_index int32 [b * S_out] (>= 0: token
  * id, <= -1: feature row -1-k, OMCHAT_PAD_ROW: zero row), lengths int32 [b]; returns S_out via *S_out.
- * Call with src_index == NULL to size the output.  n_tiles_avail is checked like the reference's running index. */
+ * Call with src_index == NULL to size the output.  n_tiles_avail is checked like the reference's running index.
+ * vocab > 0: an unmasked id outside [0, vocab) other than the -200 sentinel returns 4 (the reference raises IndexError from
+ * embed_tokens, omchat_arch.py:139); vocab <= 0 skips the check. */
 int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b, int T, int n_tok, int n_tiles_avail,
-                       int padding_side, int max_length, int32_t* src_index, int32_t* lengths, int* S_out);
+                       int padding_side, int max_length, int32_t* src_index, int32_t* lengths, int* S_out, int vocab);
 /* Device gather: embeds[r] = embed_tokens[idx] | feats[row] | 0.  src_index device int32 [rows]. */
 int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, const void* feats, void* embeds, int rows, void* stream);
 
@@ -103,6 +105,12 @@ int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, const void* 
  * hidden_out: optional [b, S, t_hidden] post-final-norm hidden states (test hook).  */
 int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last,
                    void* hidden_out, void* stream);
+/* Prefill of a LEFT-padded batch (config.tokenizer_padding_side == "left", omchat_arch.py:176-184): row i holds its lengths[i] tokens at
+ * [S - lengths[i], S).  As in the reference, position_ids are dropped (:206-207) so RoPE runs on arange(S) for every row, the padded
+ * keys are masked, and logits_last is the position S - 1 of every row (what generate reads).  Decode steps after it are refused
+ * (the reference positions them with sum(mask) - 1, :61-70, which contradicts the prefill: DESIGN.md section 7). */
+int omchat_prefill_left(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last,
+                        void* hidden_out, void* stream);
 /* Decode step >= 1 (omchat_qwen2.py:92-111, omchat_arch.py:61-70): one token per sequence, appended at kv_len.
  * tokens device int32 [b]; logits device fp32 [b, t_vocab] or NULL; next_tokens device int32 [b] (greedy argmax,
  * first index wins) or NULL. */

@@ -41,9 +41,10 @@ _SIGS = {
     "omchat_vit_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "omchat_projector_forward": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_encode_images": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
-    "omchat_splice_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "omchat_splice_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i), _i]),
     "omchat_splice_gather": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "omchat_prefill": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "omchat_prefill_left": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "omchat_decode_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "omchat_lm_head": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_greedy": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -122,6 +123,8 @@ def check(rc):
         msg = lib().omchat_last_error().decode()
         if rc == 1:
             raise ValueError(msg)      # argument / shape errors: the reference raises ValueError at these seams
+        if rc == 4:
+            raise IndexError(msg)      # token id outside the embedding table (torch's embed_tokens raises IndexError)
         raise OmchatError(msg)
 
 

@@ -26,6 +26,7 @@ struct AttnP {
   const void* Q; const void* K; const void* V; void* O;
   int64_t q_sb, q_sh, q_sr, k_sb, k_sh, k_sr, v_sb, v_sh, v_sr, o_sb, o_sh, o_sr;
   const int* kv_len;
+  const int* kv_start;
   int q_heads, kv_heads, Sq, Skv, causal, q_pos0, nsplit;
   float c;      // scale * log2(e)
   float* ws;
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   int kmax = kv_len;
   if (p.causal) { const int lim = q0 + NW * NQ * 16 + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
   const int t_end = (kmax + KV_TILE - 1) / KV_TILE;
+  const int kv_start = p.kv_start ? p.kv_start[b] : 0;      // left-padded batch: the first kv_start keys are padding
+  const int t_begin = kv_start / KV_TILE;
 
   const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
@@ -202,8 +205,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   const bool wave_active = q0 + wave * NQ * 16 < p.Sq;        // wave-uniform
   // tile t lives in buffer t & 1.  Iteration t: wait for own DMA of tile t, barrier (tile t visible to everyone, buffer
   // (t+1)&1 no longer read by anyone), issue tile t+1, then S^T, softmax and PV from buffer t & 1.
-  if (t_end > 0) issue_tile(0, 0);
-  for (int t = 0; t < t_end; ++t) {
+  if (t_end > t_begin) issue_tile(t_begin, t_begin & 1);
+  for (int t = t_begin; t < t_end; ++t) {
     const int cur = t & 1;
     const char* const Ks = smem + cur * BUF;
     const char* const Vs = Ks + KV_TILE * RB;
@@ -232,18 +235,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
     // ---- mask + online softmax (per lane = per query column).  exp2((s - m) * c) = exp2(s * c - m * c).
     const int key0 = t * KV_TILE + 4 * fg;
     // masking is needed only on the last kv tile (ragged tail) and on tiles that reach the causal diagonal of this block
-    const bool need_mask = (t + 1) * KV_TILE > kv_len || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1);
+    const bool need_mask = (t + 1) * KV_TILE > kv_len || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1) || t * KV_TILE < kv_start;
     frag_t pf[NQ][2];
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) {
       if (need_mask) {
         int lim = kv_len;                                   // keys < lim are visible
         if (p.causal) { const int cl = qrow[qt] + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
-        const int rel = lim - key0;                         // register r of key tile kt is key key0 + 16*kt + r
+        const int rel = lim - key0, rel_lo = kv_start - key0;     // register r of key tile kt is key key0 + 16*kt + r
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[qt][kt][r] = kt * 16 + r < rel ? s[qt][kt][r] : NEG_BIG;
+          for (int r = 0; r < 4; ++r) s[qt][kt][r] = (kt * 16 + r < rel && kt * 16 + r >= rel_lo) ? s[qt][kt][r] : NEG_BIG;
       }
       // VALU is the bound of this kernel (MFMA and VALU issue do not overlap on a SIMD: tools/tune_pipes.hip), so the
       // softmax is written for instruction count: v_max3 chain, v_pk_fma / v_pk_add on register pairs
@@ -538,7 +541,7 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.Sq > 0 && a.Skv > 0 && a.batch > 0, "empty attention");
   OM_CHECK(a.q_sr % 8 == 0 && a.k_sr % 8 == 0 && a.v_sr % 8 == 0 && a.o_sr % 4 == 0, "row strides must keep 16-B alignment");
   AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
-          a.kv_len, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
+          a.kv_len, a.kv_start, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
           nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
@@ -567,7 +570,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   const int nsplit = cdiv(a.L, KV_TILE);
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
-          a.kv_len, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
+          a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
           a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max};
   OM_CHECK(!a.rope || (a.pos && a.k_new && a.v_new && a.kv_len), "fused RoPE decode needs pos, k_new, v_new and kv_len");
   dim3 grid(nsplit, a.kv_heads, a.batch);

@@ -77,7 +77,8 @@ struct AttnArgs {
   int batch, q_heads, kv_heads;
   int Sq, Skv;              // common lengths; per-batch overrides below
   const int* kv_len;        // optional device [batch] (valid keys per sequence), null -> Skv
-  int causal;               // key j visible to query i iff j < kv_len and (!causal or j <= i + q_pos0)
+  const int* kv_start;      // optional device [batch]: keys < kv_start[b] are masked (left-padded batches), null -> 0
+  int causal;               // key j visible to query i iff kv_start <= j < kv_len and (!causal or j <= i + q_pos0)
   int q_pos0;               // absolute position of query row 0 (0 for a fresh prefill)
   float scale;              // applied to scores in fp32
   int head_dim;             // 128 (0 = 128) or 64 (InternViT-300M)

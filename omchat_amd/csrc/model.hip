@@ -90,7 +90,7 @@ struct omchat_ctx {
   struct DecLayer8 { void *wqkv, *wo, *wgu, *wd; float *sqkv, *so, *sgu, *sd; };
   std::vector<DecLayer8> dl8;
   void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
-  bool fp8_decode = false;
+  bool fp8_decode = false, fp8_stale = false;
   // decode step as a hipGraph (omchat_enable_decode_graph): ~230 launches per token replayed as one graph launch.  Captured on a
   // context-owned stream (the caller's may be the legacy null stream, which cannot capture) with context-owned token / logits
   // buffers so that every kernel argument is replay-invariant; the split-KV attention grid is captured for `cap_len` keys
@@ -121,7 +121,8 @@ struct omchat_ctx {
   float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
   float* tw_attn_ws = nullptr;
   size_t tw_attn_ws_bytes = 0;
-  int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr;
+  int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_start = nullptr;
+  bool left_padded = false;
   void *kcache = nullptr, *vcache = nullptr;   // [layers][max_batch][kv_heads][max_seq][128]
   std::vector<int> h_len;
   // optional per-kernel-class HIP-event timing (bench.py roofline): category -> event pairs recorded on the launch stream
@@ -331,6 +332,7 @@ int build(omchat_ctx* ctx) {
     TRY(ctx->alloc((void**)&ctx->d_pos, (size_t)c.max_batch * 4));
     TRY(ctx->alloc((void**)&ctx->d_len, (size_t)c.max_batch * 4));
     TRY(ctx->alloc((void**)&ctx->d_idx, (size_t)c.max_batch * 4));
+    TRY(ctx->alloc((void**)&ctx->d_start, (size_t)c.max_batch * 4));
     const size_t cache = (size_t)c.t_layers * ctx->cache_layer_stride() * 2;
     TRY(ctx->alloc(&ctx->kcache, cache));
     TRY(ctx->alloc(&ctx->vcache, cache));
@@ -434,6 +436,13 @@ extern "C" int omchat_load_tensor(omchat_ctx* ctx, const char* name, const void*
   for (int i = 0; i < ndim; ++i) n *= shape[i];
   OM_CHECK(n == r.rows * r.cols, std::string("shape mismatch for ") + name + ": expected " + std::to_string(r.rows * r.cols) +
                                      " elements, got " + std::to_string(n));
+  {   // the leading dims must multiply to the routed row count (catches a transposed [cols, rows] tensor of the right size)
+    bool split_ok = r.rows == 1 || ndim == 1;
+    int64_t lead = 1;
+    for (int i = 0; i < ndim && !split_ok; ++i) { lead *= shape[i]; split_ok = lead == r.rows; }
+    OM_CHECK(split_ok, std::string("shape mismatch for ") + name + ": expected [" + std::to_string(r.rows) + ", " + std::to_string(r.cols) + "]");
+  }
+  if (!ctx->dl8.empty()) ctx->fp8_stale = true;      // the e4m3 replica no longer matches the 16-bit weights
   if (src_dtype == ctx->dt) return place(ctx, r, data);
   OM_CHECK(src_dtype == OMCHAT_F32, "source dtype must be the context dtype or OMCHAT_F32");
   TRY(ensure_stage(ctx, (size_t)n * 4, (size_t)n * 2));
@@ -652,8 +661,17 @@ extern "C" int omchat_encode_images(omchat_ctx* ctx, const void* pixels, int n_t
 // splice
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int omchat_splice_plan(const int64_t* ids, const uint8_t* mask, int b, int T, int n_tok, int n_tiles_avail, int padding_side,
-                                  int max_length, int32_t* src_index, int32_t* lengths, int* S_out) {
+                                  int max_length, int32_t* src_index, int32_t* lengths, int* S_out, int vocab) {
   OM_CHECK(ids && S_out && b > 0 && T > 0 && n_tok >= 0, "bad argument");
+  // embed_tokens raises IndexError for an id outside [0, vocab) (omchat_arch.py:139); the device gather would read out of bounds
+  if (vocab > 0)
+    for (size_t i = 0; i < (size_t)b * T; ++i) {
+      if (mask && !mask[i]) continue;
+      if (ids[i] != -200 && (ids[i] < 0 || ids[i] >= vocab)) {
+        omchat_set_error("omchat_splice_plan: token id " + std::to_string(ids[i]) + " out of range [0, " + std::to_string(vocab) + ") (index out of range in embed_tokens)");
+        return 4;
+      }
+    }
   // pass 1: lengths (omchat_arch.py:115-164); a row without sentinels still consumes one tile slot (:122-129)
   std::vector<int> len(b);
   int cur = 0, S = 0, total_img = 0;
@@ -722,13 +740,15 @@ extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
   const omchat_config& c = ctx->c;
   OM_CHECK(c.t_layers > 0, "context has no decoder");
   if (!on) { ctx->fp8_decode = false; return 0; }
-  if (ctx->dl8.empty()) {
+  if (ctx->dl8.empty() || ctx->fp8_stale) {
     OM_CHECK(omchat_weights_missing(ctx) == 0, "load the weights before quantising them");
     const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
     ctx->dl8.resize(c.t_layers);
     auto quant = [&](const void* W, int N, int K, void** w8, float** sc) -> int {
-      TRY(ctx->alloc(w8, (size_t)N * K));
-      TRY(ctx->alloc((void**)sc, (size_t)N * 4));
+      if (!*w8) {      // first build allocates; a rebuild after omchat_load_tensor re-quantises in place
+        TRY(ctx->alloc(w8, (size_t)N * K));
+        TRY(ctx->alloc((void**)sc, (size_t)N * 4));
+      }
       return launch_quant_fp8_rows(ctx->dt, W, K, N, K, *w8, K, *sc, nullptr);
     };
     for (int i = 0; i < c.t_layers; ++i) {
@@ -738,8 +758,9 @@ extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
       TRY(quant(L.wgu, 2 * It, H, &Q.wgu, &Q.sgu));
       TRY(quant(L.wd, H, It, &Q.wd, &Q.sd));
     }
-    TRY(quant(ctx->t_lm, c.t_vocab, H, &ctx->t_lm8, &ctx->t_lm8_s));
+    TRY(quant(ctx->t_lm, c.t_vocab, H, &ctx->t_lm8, (float**)&ctx->t_lm8_s));
     OM_HIP(hipDeviceSynchronize());
+    ctx->fp8_stale = false;
   }
   ctx->fp8_decode = true;
   return 0;
@@ -769,8 +790,8 @@ extern "C" int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float*
   return lm_head_rows(ctx, hidden, n, logits, (hipStream_t)stream);
 }
 
-extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last, void* hidden_out,
-                              void* stream) {
+static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last, void* hidden_out,
+                        void* stream, bool left) {
   OM_CHECK(ctx && embeds && lengths, "null argument");
   const omchat_config& c = ctx->c;
   OM_CHECK(c.t_layers > 0, "context has no decoder");
@@ -783,10 +804,18 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
   const int H = c.t_hidden, It = c.t_mlp, rows = b * S, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   const bool lead = ctx->tp_rank == 0;
 
-  std::vector<int> pos(b), len1(b);
-  for (int i = 0; i < b; ++i) { ctx->h_len[i] = lengths[i]; pos[i] = lengths[i]; len1[i] = lengths[i] + 1; }
-  // d_len holds the valid lengths during prefill; switched to (len + 1, pos = len) for the decode steps at the end
-  OM_HIP(hipMemcpyAsync(ctx->d_len, lengths, (size_t)b * 4, hipMemcpyHostToDevice, s));
+  std::vector<int> pos(b), len1(b), klen(b), kstart(b);
+  // left-padded batch (omchat_arch.py:176-184): row i holds its n_i tokens at [S - n_i, S); the reference drops position_ids
+  // (:206-207), so RoPE runs on arange(S) for every row, the padded keys are masked, and every row's last token sits at S - 1
+  for (int i = 0; i < b; ++i) {
+    ctx->h_len[i] = left ? 0 : lengths[i];            // 0 = no decode after a left-padded prefill (see omchat_decode_step)
+    pos[i] = lengths[i]; len1[i] = lengths[i] + 1;
+    klen[i] = left ? S : lengths[i]; kstart[i] = left ? S - lengths[i] : 0;
+  }
+  ctx->left_padded = left;
+  // d_len holds the valid key range end during prefill; switched to (len + 1, pos = len) for the decode steps at the end
+  OM_HIP(hipMemcpyAsync(ctx->d_len, klen.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  if (left) OM_HIP(hipMemcpyAsync(ctx->d_start, kstart.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
 
   void* x = ctx->tw_x;
   void* y = ctx->tw_x2;
@@ -806,6 +835,7 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
     a.V = vc; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
     a.O = ctx->tw_ao; a.o_sb = (int64_t)S * qd; a.o_sh = 128; a.o_sr = qd;
     a.batch = b; a.q_heads = c.t_heads; a.kv_heads = c.t_kv_heads; a.Sq = S; a.Skv = S; a.kv_len = ctx->d_len; a.causal = 1; a.q_pos0 = 0;
+    a.kv_start = left ? ctx->d_start : nullptr;
     a.scale = 0.08838834764831845f;
     TRY(launch_attn_prefill(ctx->dt, a, s));
     if (ctx->tp_size == 1) {
@@ -837,6 +867,16 @@ extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S,
   OM_HIP(hipMemcpyAsync(ctx->d_len, len1.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
   OM_HIP(hipStreamSynchronize(s));     // pos/len1 are stack vectors
   return 0;
+}
+
+extern "C" int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last, void* hidden_out,
+                              void* stream) {
+  return prefill_impl(ctx, embeds, b, S, lengths, logits_last, hidden_out, stream, false);
+}
+
+extern "C" int omchat_prefill_left(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last,
+                                   void* hidden_out, void* stream) {
+  return prefill_impl(ctx, embeds, b, S, lengths, logits_last, hidden_out, stream, true);
 }
 
 // One decode step on stream s.  Lmax = upper bound of the key count (sizes the split-KV grid; the kernels read the true
@@ -972,6 +1012,8 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   OM_CHECK(c.t_layers > 0, "context has no decoder");
   OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
   int Lmax = 0;
+  OM_CHECK(!ctx->left_padded, "decode after a left-padded prefill is refused: the reference positions such a batch inconsistently "
+                              "between prefill (arange(S)) and decode (sum(mask) - 1); pad on the right (DESIGN.md section 7)");
   for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
   OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
   hipStream_t s = (hipStream_t)stream;

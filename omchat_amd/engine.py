@@ -196,9 +196,9 @@ class Engine:
         ml = -1 if max_length is None else int(max_length)
         S = C.c_int(0)
         lens = torch.zeros(b, dtype=torch.int32)
-        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, None, ptr(lens), C.byref(S)))
+        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, None, ptr(lens), C.byref(S), self.c.t_vocab_total))
         idx = torch.empty(b, S.value, dtype=torch.int32)
-        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, ptr(idx), ptr(lens), C.byref(S)))
+        check(self.lib.omchat_splice_plan(ptr(ids), ptr(m), b, T, ntok, n_tiles, side, ml, ptr(idx), ptr(lens), C.byref(S), 0))
         idx_d = idx.to(self.device)
         f = None if feats is None else feats.to(device=self.device, dtype=self.torch_dtype).contiguous()
         out = torch.empty(b, S.value, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device)
@@ -206,14 +206,17 @@ class Engine:
         return out, [int(x) for x in lens], idx.ne(_lib.PAD_ROW)
 
     # ------------------------------------------------------------------ decoder
-    def prefill(self, embeds, lengths=None, want_hidden=False, want_logits=True):
+    def prefill(self, embeds, lengths=None, want_hidden=False, want_logits=True, padding_side="right"):
+        """padding_side='left': rows hold their tokens at the END (omchat_arch.py:176-184); logits are those of position S - 1 and
+        decode steps are refused afterwards (see include/omchat_hip.h: omchat_prefill_left)."""
         torch = _torch()
         e = embeds.to(device=self.device, dtype=self.torch_dtype).contiguous()
         b, S, _ = e.shape
         lens = torch.tensor(lengths if lengths is not None else [S] * b, dtype=torch.int32)
         logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
         hidden = torch.empty(b, S, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device) if want_hidden else None
-        check(self.lib.omchat_prefill(self.h, ptr(e), b, S, ptr(lens), ptr(logits), ptr(hidden), cur_stream()))
+        fn = self.lib.omchat_prefill_left if padding_side == "left" else self.lib.omchat_prefill
+        check(fn(self.h, ptr(e), b, S, ptr(lens), ptr(logits), ptr(hidden), cur_stream()))
         return logits, hidden
 
     def decode_step(self, tokens, want_logits=False):
@@ -232,6 +235,21 @@ class Engine:
         out = torch.empty(*h.shape[:-1], self.c.t_vocab, dtype=torch.float32, device=self.device)
         check(self.lib.omchat_lm_head(self.h, ptr(h), n, ptr(out), cur_stream()))
         return out
+
+    def full_logits(self, logits):
+        """[b, V / tp] rank-local vocabulary shard -> [b, V] on every rank (HF-style consumers of `out.logits` must not see a
+        shard).  Uses the initialised torch.distributed group (the bootstrap channel of tp.init_comm); identity at TP = 1."""
+        if self.tp_size == 1 or logits is None:
+            return logits
+        torch = _torch()
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise _lib.OmchatError("tensor-parallel logits are vocabulary shards: initialise torch.distributed to gather them, or use Engine.argmax")
+        cpu = dist.get_backend() == "gloo"
+        mine = logits.float().cpu().contiguous() if cpu else logits.float().contiguous()
+        parts = [torch.empty_like(mine) for _ in range(self.tp_size)]
+        dist.all_gather(parts, mine)
+        return torch.cat(parts, dim=-1).to(self.device)
 
     def kv_lengths(self, b):
         torch = _torch()

@@ -34,6 +34,7 @@ def config_from_json(path):
     mm.setdefault("image_grid_pinpoints", DEFAULT_PINPOINTS)
     cfg = OmChatConfig(vision, text, mm)
     cfg.max_sequence_length = j.get("max_sequence_length", tj.get("max_sequence_length", 2048))
+    cfg.max_position_embeddings = tj.get("max_position_embeddings", j.get("max_position_embeddings"))
     cfg.eos_token_id = j.get("eos_token_id", tj.get("eos_token_id"))
     return cfg
 
@@ -49,11 +50,28 @@ def iter_safetensors(path):
                 yield k, f.get_tensor(k)
 
 
-def load_omchat_model(model_path, torch_dtype=torch.float16, max_seq=None, max_batch=1, max_tiles=16, tp_rank=0, tp_size=1, comm=None):
+def default_capacity(cfg):
+    """(max_seq, max_tiles) when the caller does not size the context.  The reference's DynamicCache has no limit; here the KV
+    cache and the prefill workspaces are allocated once, so the default must hold the largest anyres picture the pinpoints allow
+    (DEFAULT_PINPOINTS: 3 x 3 tiles + thumbnail = 10 x 1024 image tokens) plus the prompt and single_inference.py's
+    max_new_tokens = 1024: the decoder's max_position_embeddings when the checkpoint states it (Qwen2-7B: 32768 -> 1.9 GB of KV per
+    sequence), never less than tiles x tokens + 4096."""
+    tile = cfg.vision["image_size"]
+    pins = cfg.mm.get("image_grid_pinpoints") or DEFAULT_PINPOINTS
+    tiles = max((int(w) // tile) * (int(h) // tile) for w, h in pins) + 1
+    need = tiles * cfg.num_image_tokens + 4096
+    mpe = getattr(cfg, "max_position_embeddings", None)
+    max_seq = max(need, min(int(mpe), 32768) if mpe else 16384, int(getattr(cfg, "max_sequence_length", 2048) or 2048))
+    return max_seq, max(16, tiles)
+
+
+def load_omchat_model(model_path, torch_dtype=torch.float16, max_seq=None, max_batch=1, max_tiles=None, tp_rank=0, tp_size=1, comm=None):
     from ..tp import shard_tensor
     from ..weights import prepare_state_dict
     cfg = config_from_json(model_path)
-    max_seq = max_seq or max(int(getattr(cfg, "max_sequence_length", 2048)), 4096)
+    d_seq, d_tiles = default_capacity(cfg)
+    max_seq = max_seq or d_seq
+    max_tiles = max_tiles or d_tiles
     eng = Engine(cfg, dtype=torch_dtype, max_seq=max_seq, max_batch=max_batch, max_tiles=max_tiles, max_prefill_rows=max_seq * max_batch,
                  tp_rank=tp_rank, tp_size=tp_size, comm=comm)
     for k, v in iter_safetensors(model_path):           # streamed tensor by tensor: host memory stays small

@@ -131,12 +131,20 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         if inputs_embeds is not None:
             b, S, _ = inputs_embeds.shape
             lengths = self._last_lengths if self._last_lengths is not None and len(self._last_lengths) == b else [S] * b
+            side = "right"
             if attention_mask is not None and attention_mask.shape[1] == S:
                 lengths = [int(x) for x in attention_mask.ne(0).sum(dim=1)]
-                if any(int(attention_mask[i, :n].ne(0).sum()) != n for i, n in enumerate(lengths)):
-                    raise NotImplementedError("left-padded batches: pad on the right (tokenizer_padding_side='right')")
+                right = all(int(attention_mask[i, :n].ne(0).sum()) == n for i, n in enumerate(lengths))
+                left = all(int(attention_mask[i, S - n:].ne(0).sum()) == n for i, n in enumerate(lengths))
+                if not right and not left:
+                    raise NotImplementedError("attention masks with holes: pad on one side")
+                # a left-padded batch (tokenizer_padding_side='left', omchat_arch.py:176-184) is prefilled exactly as the reference
+                # does it (RoPE on arange(S), padded keys masked, logits of position S - 1); its decode steps are refused by the
+                # engine because the reference positions them inconsistently
+                side = "right" if right else "left"
             self._last_lengths = None
-            logits_last, hidden = self.engine.prefill(inputs_embeds, lengths, want_hidden=bool(output_hidden_states))
+            logits_last, hidden = self.engine.prefill(inputs_embeds, lengths, want_hidden=bool(output_hidden_states), padding_side=side)
+            logits_last = self.engine.full_logits(logits_last)        # vocab-parallel lm_head: gather the rank-local shards
             out = CausalLMOutputWithPast(logits_last.unsqueeze(1), KVHandle(self.engine, b))
             if output_hidden_states:
                 out["hidden_states"] = (hidden,); out.hidden_states = (hidden,)
@@ -144,7 +152,7 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         if input_ids.shape[1] != 1:
             raise ValueError("decode steps take exactly one token per sequence")
         nxt, logits = self.engine.decode_step(input_ids[:, 0], want_logits=True)
-        out = CausalLMOutputWithPast(logits.unsqueeze(1), past_key_values)
+        out = CausalLMOutputWithPast(self.engine.full_logits(logits).unsqueeze(1), past_key_values)
         out.next_tokens = nxt
         return out
 
@@ -178,7 +186,14 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         if streamer is not None:
             streamer.put(input_ids.cpu())
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True)
-        tok = self.engine.argmax(out.logits[:, 0])
+        tok = self.engine.argmax(out.logits[:, 0]) if self.engine.tp_size == 1 else torch.argmax(out.logits[:, 0], dim=-1).to(torch.int32)
+        # The KV cache is context-owned with a fixed capacity (the reference's DynamicCache grows without bound): generate as
+        # many tokens as fit and stop cleanly, returning what was produced, instead of failing mid-stream with 'KV cache full'.
+        room = self.engine.c.max_seq - max(self.engine.kv_lengths(b)) + 1
+        if max_new_tokens > room:
+            import warnings
+            warnings.warn(f"max_new_tokens={max_new_tokens} clamped to {room}: KV cache capacity max_seq={self.engine.c.max_seq}")
+            max_new_tokens = max(room, 1)
         new = []
         done = torch.zeros(b, dtype=torch.bool)
         for step in range(max_new_tokens):

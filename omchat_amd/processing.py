@@ -34,21 +34,53 @@ class OmChatImageProcessor(HipImageProcessor):
     preprocess = __call__
 
 
+def _batch_feature(data):
+    """BatchFeature like the reference returns (hf/processing_omchat.py:253-257): attribute access (`inputs.input_ids`,
+    hf_example.py:17), `.to("cuda")` (:12), `**inputs` into generate (:15)."""
+    from transformers import BatchFeature
+    return BatchFeature(data=data)
+
+
 class OmChatProcessor:
-    """OmChatProcessor.__call__ (hf/processing_omchat.py:171-253): one sample; `images` = one picture or a list; returns
-    {"input_ids": int64 [1, T] with one -200 per tile, "images": [sum(tiles), 3, H, W]}.  Text-only prompts return
-    {"input_ids"} (the reference builds a bare tensor there and then fails in BatchFeature(**tensor); a dict is the evident intent)."""
+    """OmChatProcessor.__call__ (hf/processing_omchat.py:171-253): one sample; `images` = one picture or a list; returns a
+    BatchFeature {"input_ids": int64 [1, T] with one -200 per tile, "images": [sum(tiles), 3, H, W]}.  Text-only prompts return
+    {"input_ids"} (the reference builds a bare tensor there and then fails in BatchFeature(**tensor); a mapping is the evident intent)."""
 
     def __init__(self, image_processor=None, tokenizer=None, **kw):
         self.image_processor = image_processor
         self.tokenizer = tokenizer
+
+    @classmethod
+    def from_pretrained(cls, path, trust_remote_code=None, **kw):
+        """AutoProcessor.from_pretrained(path, trust_remote_code=True) (hf_example.py:8): tokenizer from the checkpoint directory,
+        image geometry from its preprocessor_config.json / config.json when present, the reference's defaults otherwise."""
+        import json, os
+        from transformers import AutoTokenizer
+        try:
+            tok = AutoTokenizer.from_pretrained(path, use_fast=False)
+        except Exception:
+            tok = AutoTokenizer.from_pretrained(path)
+        crop, pins = 448, None
+        for fn in ("preprocessor_config.json", "config.json"):
+            f = os.path.join(path, fn)
+            if os.path.exists(f):
+                j = json.load(open(f))
+                pins = pins or j.get("image_grid_pinpoints")
+                cs = j.get("crop_size")
+                if isinstance(cs, dict):
+                    crop = int(cs.get("height", crop))
+                elif isinstance(cs, int):
+                    crop = cs
+                elif fn == "config.json" and isinstance(j.get("vision_config"), dict):
+                    crop = int(j["vision_config"].get("image_size", crop))
+        return cls(OmChatImageProcessor(crop_size=crop, image_grid_pinpoints=pins), tok)
 
     def __call__(self, text, images=None, padding=False, truncation=None, max_length=None, return_tensors="pt"):
         import torch
         system = "You are a helpful assistant."
         if images is None:
             _, ids = make_context(self.tokenizer, text.replace("<image>", "").strip(), None, system)
-            return {"input_ids": torch.tensor([ids])}
+            return _batch_feature({"input_ids": torch.tensor([ids])})
         out = self.image_processor(images, return_tensors=return_tensors)
         n_per = out["num_patches"].tolist()
         tiles = [out["pixel_values"][i, :n] for i, n in enumerate(n_per)]           # split_tensor (:133-141)
@@ -64,7 +96,7 @@ class OmChatProcessor:
                     query += parts[i + 1]
             query = query.strip()
         _, ids = make_context(self.tokenizer, query, None, system)
-        return {"input_ids": torch.tensor([ids]), "images": torch.cat(tiles, dim=0)}
+        return _batch_feature({"input_ids": torch.tensor([ids]), "images": torch.cat(tiles, dim=0)})
 
     def batch_decode(self, *a, **k):
         return self.tokenizer.batch_decode(*a, **k)

@@ -132,6 +132,49 @@ def test_hf_facade_same_tokens_as_native(ckpt):
     assert torch.equal(a, b)
 
 
+def test_hf_example_flow_with_only_the_import_changed(tmp_path, gpu_lib):
+    """hf_example.py:7-17 line by line on a synthetic HF-layout checkpoint: AutoModel / AutoProcessor (registered classes),
+    BatchFeature with .to('cuda') and attribute access, generate(**inputs, ...), decode of the new ids."""
+    from PIL import Image
+    from omchat_amd.model.hf import AutoModel, AutoProcessor
+    import transformers
+    cfg = tiny()
+    cfg.mm["image_grid_pinpoints"] = [[56, 112], [112, 56], [112, 112]]
+    path = save_synthetic_checkpoint(str(tmp_path / "hf"), cfg, 9, "hf")
+    model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.float16, max_seq=512, max_tiles=8).cuda().eval()
+    processor = AutoProcessor.from_pretrained(path, trust_remote_code=True)
+    image = Image.fromarray(np.random.default_rng(0).integers(0, 256, (50, 100, 3), dtype=np.uint8))
+    prompt = "w3 w4 w5"
+    inputs = processor(text=prompt, images=image, return_tensors="pt").to("cuda")
+    assert isinstance(inputs, transformers.BatchFeature) and inputs.input_ids.is_cuda and inputs["images"].shape[0] == 3
+    with torch.inference_mode():
+        output_ids = model.generate(**inputs, max_new_tokens=5, do_sample=False, eos_token_id=model.generation_config.eos_token_id,
+                                    pad_token_id=processor.tokenizer.pad_token_id)
+    assert output_ids.shape[1] == inputs.input_ids.shape[1] + 5
+    assert isinstance(processor.tokenizer.decode(output_ids[0, inputs.input_ids.shape[1]:]), str)
+    # transformers' own Auto classes resolve the registered config / model / processor classes as well (no auto_map in this checkpoint)
+    m2 = transformers.AutoModel.from_pretrained(path, torch_dtype=torch.float16, max_seq=512, max_tiles=8)
+    assert type(m2).__name__ == "OmChatForConditionalGeneration"
+    out2 = m2.generate(**inputs, max_new_tokens=5, do_sample=False)
+    assert torch.equal(out2, output_ids)
+
+
+def test_generate_clamps_to_kv_capacity_instead_of_failing(ckpt):
+    """a long max_new_tokens must not abort mid-stream with 'KV cache full'; what fits is produced and returned"""
+    cfg, native, _ = ckpt
+    _, model, _, _ = load_pretrained_model(native, "native", max_seq=48, max_tiles=2)
+    px = T32(synth.pixels(1, 56, 5)).half().cuda()
+    ids = torch.tensor([[3, I, 17, 18]])                      # 3 + 16 = 19 prompt positions -> room for 30 new tokens
+    with pytest.warns(UserWarning, match="clamped"):
+        out = model.generate(ids, images=px, max_new_tokens=1024, eos_token_id=None)
+    assert out.shape[1] == ids.shape[1] + 30
+    from omchat_amd.model.builder import default_capacity
+    from omchat_amd.config import omchat13b
+    big = omchat13b(); big.max_position_embeddings = 32768
+    seq, tiles = default_capacity(big)
+    assert seq >= 10 * 1024 + 512 + 1024 and tiles >= 10       # the largest anyres picture + prompt + single_inference's 1024 new tokens
+
+
 def test_text_only_and_bf16(ckpt):
     cfg, native, _ = ckpt
     _, model, _, _ = load_pretrained_model(native, "native", max_seq=128, max_tiles=1, torch_dtype=torch.bfloat16)

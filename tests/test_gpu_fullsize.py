@@ -92,6 +92,91 @@ def test_full_size_greedy_run_is_reproducible(eng13b):
     assert eng13b.kv_lengths(1) == [4 + 1024 + 12]
 
 
+def test_full_size_configs1_shape_3_tiles_S3584(gpu_lib):
+    """the BENCHMARKED shape of BASELINE configs[1] (3 anyres tiles + 512 text ids -> S = 3584, 45 + 28 layers): tower batch
+    independence at 3 tiles, splice = pure copy, prefill(S) + decode(t) == last position of prefill(S + 1), reproducible greedy run"""
+    cfg = omchat13b()
+    S = 3 * 1024 + 512
+    e = Engine(cfg, dtype="bf16", max_seq=S + 40, max_batch=1, max_tiles=3, max_prefill_rows=S + 8)
+    e.fill_synthetic(0)
+    px = torch.from_numpy(synth.pixels(3, 448, 0))
+    feats = e.encode_images(px); sync()
+    assert feats.shape == (3, 1024, 3584) and torch.isfinite(feats.float()).all()
+    assert rel(e.encode_images(px[2:3])[0], feats[2]) < 1e-6
+    text = synth.token_ids(512, 151643, 1).tolist()
+    ids = torch.tensor([[-200, text[0], -200, text[1], -200] + text[2:]])
+    embeds, lengths, valid = e.splice(ids, None, feats); sync()
+    assert lengths == [S] and bool(valid.all())
+    assert torch.equal(embeds[0, :1024], feats[0]) and torch.equal(embeds[0, 1025:2049], feats[1]) and torch.equal(embeds[0, 2050:3074], feats[2])
+    logits_a, _ = e.prefill(embeds, [S]); sync()
+    tok = int(torch.argmax(logits_a[0]))
+    nxt, step_logits = e.decode_step(torch.tensor([tok]), want_logits=True); sync()
+    seq = [tok, int(nxt[0])]
+    t2 = nxt
+    for _ in range(6):
+        t2, _ = e.decode_step(t2)
+        seq.append(int(t2[0]))
+    ids2 = torch.cat([ids, torch.tensor([[tok]])], dim=1)
+    embeds2, lengths2, _ = e.splice(ids2, None, feats)
+    logits_b, _ = e.prefill(embeds2, [S + 1]); sync()
+    r = rel(step_logits[0], logits_b[0])
+    print("configs1 shape prefill/decode consistency", r)
+    assert torch.isfinite(logits_b).all() and r < CONSIST_TOL["bf16"], r
+    # the same greedy run again: bit-identical ids (no race anywhere in ~75 k kernel launches)
+    logits_c, _ = e.prefill(embeds, [S])
+    assert torch.equal(logits_c, logits_a)
+    t3 = e.argmax(logits_c)
+    seq2 = [int(t3[0])]
+    for _ in range(7):
+        t3, _ = e.decode_step(t3)
+        seq2.append(int(t3[0]))
+    assert seq2 == seq
+    e.close()
+
+
+def test_full_size_batch32_rows_equal_single_sequence_runs(gpu_lib):
+    """BASELINE configs[2] batch (32 sequences, full OmChat-13B width, ragged lengths, right-padded): every row of the batched prefill
+    and of the batched decode steps must equal the run of that sequence alone.  Prefill rows are the SAME arithmetic (the GEMM tiles
+    over rows with one K order, attention per (sequence, head)): logits agree to fp32 rounding of the lm_head kernels; decode uses
+    the two-tile MFMA GEMV at b = 32 and the whole-row form at b = 1 (different K split): 16-bit rounding tolerance"""
+    cfg = omchat13b()
+    b = 32
+    lens = [1024 + 40 + 13 * i for i in range(b)]                       # 1 tile + 40 .. 443 text ids
+    S = max(lens)
+    e = Engine(cfg, dtype="bf16", max_seq=S + 16, max_batch=b, max_tiles=8, max_prefill_rows=b * S)
+    e.fill_synthetic(0)
+    feats = e.encode_images(torch.from_numpy(synth.pixels(4, 448, 2)))     # 4 distinct tiles shared round-robin by the 32 samples
+    rows, mask = [], []
+    for i, n in enumerate(lens):
+        text = synth.token_ids(n - 1024, 151643, 10 + i).tolist()
+        r = [text[0], -200] + text[1:]
+        rows.append(r + [0] * (S - 1024 + 1 - len(r))); mask.append([1] * len(r) + [0] * (S - 1024 + 1 - len(r)))
+    ids, am = torch.tensor(rows), torch.tensor(mask)
+    tile_of = [i % 4 for i in range(b)]
+    embeds, lengths, valid = e.splice(ids, am, feats[tile_of]); sync()
+    assert lengths == lens and embeds.shape == (b, S, 3584)
+    logits, _ = e.prefill(embeds, lengths); sync()
+    toks = e.argmax(logits)
+    steps = []
+    t = toks
+    for _ in range(3):
+        t, lg = e.decode_step(t, want_logits=True)
+        steps.append((t.clone(), lg.clone()))
+    sync()
+    assert e.kv_lengths(b) == [n + 3 for n in lens]
+    for i in (0, 7, 19, 31):
+        l1, _ = e.prefill(embeds[i:i + 1, :lens[i]].contiguous(), [lens[i]]); sync()
+        assert rel(l1[0], logits[i]) < 1e-4, (i, rel(l1[0], logits[i]))
+        assert int(torch.argmax(l1[0])) == int(toks[i])
+        t1 = toks[i:i + 1]
+        for s_, (tb, lb) in enumerate(steps):
+            t1n, lg1 = e.decode_step(t1, want_logits=True); sync()
+            r = rel(lg1[0], lb[i])
+            assert r < 3e-2, (i, s_, r)
+            t1 = tb[i:i + 1]                                            # follow the batched run's ids (teacher forcing)
+    e.close()
+
+
 def test_long_context_decode_16k_one_full_width_layer(gpu_lib):
     """BASELINE configs[4] shape on one Qwen2-7B-width layer: 16 k tokens of context in the KV cache (prefill in one pass), then
     decode steps with the 16-bit weights against the oracle (257 split-KV partials per head merged).  The oracle's eager

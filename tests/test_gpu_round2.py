@@ -1,0 +1,169 @@
+"""GPU parity cases added in round 2 (VERDICT r01 'close the parity holes'):
+  * the InternViT-6B tower wrapper goldens (select_layer -1 / -2, patch / cls_patch) and the full-width 25-head attention golden,
+    consumed through the C ABI (they were CPU-only fixtures before)
+  * left-padded batch PREFILL against logits captured from the reference (omchat_arch.py:176-184, :206-207), decode refused
+  * a free-running (not teacher-forced) fp16 greedy sequence that must reproduce every reference id
+  * id range checks of the splice, shape check of the loader, fp8 replica refreshed after a weight reload"""
+import types
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from conftest import golden
+from gpu_util import DT, CODE, TOL, TOL_DEEP, dev, rnd, rel, sync, ptr
+from omchat_amd import synth, _lib
+from omchat_amd.config import tiny
+from omchat_amd.engine import Engine
+import oracle
+
+T32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+DTS = ["bf16", "f16"]
+
+
+@pytest.fixture(scope="module")
+def tiny_engines(gpu_lib):
+    out = {}
+    for dt in DTS:
+        e = Engine(tiny(), dtype=dt, max_seq=256, max_batch=2, max_tiles=3)
+        e.load_state_dict(synth.state_dict(tiny(), 0))
+        out[dt] = e
+    yield out
+    for e in out.values():
+        e.close()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("sel,feat", [(-1, "patch"), (-2, "patch"), (-1, "cls_patch")])
+def test_tower6b_wrapper_vs_reference_fp16_run(tiny_engines, dt, sel, feat):
+    """InternVITVisionTower(...)(images) against the reference wrapper's own fp16 run (internVIT_encoder.py:35-56)"""
+    from omchat_amd.model.vision_tower import build_vision_tower
+    g = golden(f"tower_wrapper_L{sel}_{feat}")
+    args = types.SimpleNamespace(mm_vision_tower="internvit-6b-448px", mm_vision_select_layer=sel, mm_vision_select_feature=feat)
+    tw = build_vision_tower(args, engine=tiny_engines[dt])
+    assert tw.select_layer == sel and tw.select_feature == feat and tw.is_loaded
+    feats = tw(T32(g["pixels"]).half().cuda()); sync()
+    assert feats.dtype == torch.float16 and tuple(feats.shape) == g["feats_half"].shape      # .to(images.dtype), :54
+    assert rel(feats, T32(g["feats_half"])) < TOL_DEEP[dt], rel(feats, T32(g["feats_half"]))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_vit_attention_full_width_vs_reference_golden(gpu_lib, dt):
+    """InternAttention at the production width (3200 channels, 25 heads x 128, joint q/k RMSNorm over all heads) on 33 tokens:
+    qkv GEMM -> vit_qknorm -> flash MHA -> proj GEMM through the op-level C ABI, against the module's output captured from the
+    reference (modeling_intern_vit.py:138-155)"""
+    g = golden("vit_attn_full")
+    P = "g.attnfull."
+    C_, H = 3200, 25
+    w = {k: rnd(synth.uniform(P + k, s, 0, 0.05 if "norm" in k else 0.02, 1.0 if "norm" in k else 0.0), dt)
+         for k, s in {"qkv.weight": (9600, 3200), "q_norm.weight": (3200,), "k_norm.weight": (3200,), "proj.weight": (3200, 3200),
+                      "proj.bias": (3200,)}.items()}
+    x = rnd(T32(g["x"]), dt)[0]                                        # [33, 3200]
+    N = x.shape[0]
+    code = CODE[dt]
+    dx, dwq, dwp, dbp = dev(x, dt), dev(w["qkv.weight"], dt), dev(w["proj.weight"], dt), dev(w["proj.bias"], dt)
+    dqn, dkn = dev(w["q_norm.weight"], dt), dev(w["k_norm.weight"], dt)
+    qkv = torch.empty(N, 3 * C_, dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemm(code, ptr(dx), C_, ptr(dwq), C_, ptr(qkv), 3 * C_, N, 3 * C_, C_, None, None, None, 0, _lib.EPI_NONE, 0, None))
+    _lib.check(gpu_lib.omchat_op_vit_qknorm(code, ptr(qkv), 3 * C_, ptr(dqn), ptr(dkn), N, C_, C_, 1e-6, 128 ** -0.5, None))
+    ao = torch.empty(1, N, H, 128, dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_mha_fwd(ptr(qkv), 1, N, H, 1.0, 0, ptr(ao), code, None))       # q already carries head_dim^-0.5 (N5)
+    out = torch.empty(N, C_, dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemm(code, ptr(ao), C_, ptr(dwp), C_, ptr(out), C_, N, C_, C_, ptr(dbp), None, None, 0, _lib.EPI_NONE, 0, None))
+    sync()
+    ref = T32(g["y"])[0]
+    assert rel(out, ref) < 2 * TOL[dt], rel(out, ref)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_left_padded_batch_prefill_vs_reference_logits(gpu_lib, dt):
+    """tokenizer_padding_side='left': splice (bit-exact golden elsewhere) + prefill with RoPE on arange(S) and the padded keys masked;
+    logits of position S - 1 of both rows against the reference's forward on the same batch; the right-padded run of the same
+    batch against its own golden; decode after the left-padded prefill is refused"""
+    g = golden("leftpad_prefill")
+    cfg = tiny()
+    e = Engine(cfg, dtype=dt, max_seq=128, max_batch=2, max_tiles=3)
+    e.load_state_dict(synth.state_dict(cfg, int(g["seed"])))
+    ids, mask = torch.from_numpy(g["ids"]).long(), torch.from_numpy(g["mask"]).long()
+    feats = rnd(T32(g["feats"]), dt)
+    lens_want = [int(x) for x in g["lengths"]]
+    for side, key in (("left", "logits_left_last"), ("right", "logits_right_last")):
+        embeds, lengths, valid = e.splice(ids, mask, feats.cuda(), padding_side=side)
+        assert lengths == lens_want and embeds.shape[1] == int(g["S"])
+        logits, _ = e.prefill(embeds, lengths, padding_side=side); sync()
+        ref = T32(g[key])
+        for i in range(2):
+            assert rel(logits[i], ref[i]) < TOL_DEEP[dt], (side, i, rel(logits[i], ref[i]))
+        if side == "left":
+            with pytest.raises(ValueError, match="left-padded"):
+                e.decode_step(torch.tensor([1, 2]))
+        else:
+            e.decode_step(torch.tensor([1, 2]))              # right-padded batches decode as before
+    # the reference-shaped forward() picks the side from the attention mask
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+    m = OmChatQwen2ForCausalLM(cfg.clone(), e)
+    m.config.mm["tokenizer_padding_side"] = "left"
+    m.encode_images = lambda images: feats.to(DT[dt]).cuda()
+    out = m(input_ids=ids, attention_mask=mask, images=torch.zeros(3, 3, 56, 56))
+    sync()
+    assert rel(out.logits[:, 0], T32(g["logits_left_last"])) < TOL_DEEP[dt]
+    e.close()
+
+
+def test_free_running_fp16_sequence_equals_every_reference_id(gpu_lib):
+    """no teacher forcing: the fp16 HIP path generates 16 tokens on its own and every id must equal the reference's fp16 run
+    (margins >= 0.013, an order of magnitude above the fp16 noise of this model)"""
+    g = golden("e2e_free_f16")
+    cfg = tiny()
+    e = Engine(cfg, dtype="f16", max_seq=128, max_batch=1, max_tiles=2)
+    e.load_state_dict(synth.state_dict(cfg, int(g["seed"])))
+    px = T32(synth.pixels(int(g["n_tiles"]), 56, int(g["pixel_seed"])))
+    embeds, lengths, _ = e.splice(torch.from_numpy(g["ids"]).long(), None, e.encode_images(px))
+    logits, _ = e.prefill(embeds, lengths)
+    tok = e.argmax(logits)
+    got = [int(tok[0])]
+    ref = [int(t) for t in g["tokens"]]
+    for _ in range(len(ref) - 1):
+        tok, _ = e.decode_step(tok)
+        got.append(int(tok[0]))
+    assert float(g["margins"].min()) > 0.01 and len(set(ref)) >= 3
+    assert got == ref, (got, ref)
+    e.close()
+
+
+def test_splice_and_loader_reject_bad_inputs(tiny_engines):
+    e = tiny_engines["bf16"]
+    feats = torch.zeros(1, 16, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(IndexError):
+        e.splice(torch.tensor([[3, -200, 320]]), None, feats)          # id == vocab
+    with pytest.raises(IndexError):
+        e.splice(torch.tensor([[3, -200, -100]]), None, feats)         # IGNORE_INDEX-like stray negative id
+    e.splice(torch.tensor([[3, -200, -100]]), torch.tensor([[1, 1, 0]]), feats)      # masked out: dropped before the lookup
+    w = torch.zeros(512, 256)                                           # fc1 is [512, 256]; a transposed [256, 512] must not load
+    with pytest.raises(ValueError, match="shape mismatch"):
+        e.load_tensor(synth.TOWER + "encoder.layers.0.mlp.fc1.weight", w.t().contiguous())
+
+
+def test_fp8_replica_follows_a_weight_reload(gpu_lib):
+    """after omchat_load_tensor the e4m3 replica is stale; enabling fp8 decode again must re-quantise it"""
+    cfg = tiny()
+    sd = synth.state_dict(cfg, 5)
+    e = Engine(cfg, dtype="bf16", max_seq=64, max_batch=1, max_tiles=1, vision=False)
+    e.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
+    x = torch.randn(1, 9, 256, generator=torch.Generator().manual_seed(0)) * 0.5
+
+    def fp8_step():
+        e.enable_fp8_decode(True)
+        e.prefill(x)
+        _, lg = e.decode_step(torch.tensor([7]), want_logits=True); sync()
+        e.enable_fp8_decode(False)
+        return lg.clone()
+    a = fp8_step()
+    name = "model.layers.1.mlp.down_proj.weight"
+    e.load_tensor(name, torch.from_numpy(sd[name]) * 3.0)
+    b = fp8_step()
+    assert not torch.equal(a, b)                                       # a stale replica would reproduce `a` bit for bit
+    e.prefill(x)
+    _, ref = e.decode_step(torch.tensor([7]), want_logits=True); sync()
+    assert rel(b, ref) < 0.12                                          # e4m3 weights vs the 16-bit weights of the SAME (new) values
+    e.close()

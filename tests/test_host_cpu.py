@@ -44,11 +44,29 @@ def _plan(ids, mask, ntok, ntiles, side, maxlen):
     S = C.c_int(0)
     lens = np.zeros(b, np.int32)
     pm = None if m is None else m.ctypes.data_as(C.c_void_p)
-    _lib.check(lib.omchat_splice_plan(ids.ctypes.data_as(C.c_void_p), pm, b, T, ntok, ntiles, side, maxlen, None, lens.ctypes.data_as(C.c_void_p), C.byref(S)))
+    _lib.check(lib.omchat_splice_plan(ids.ctypes.data_as(C.c_void_p), pm, b, T, ntok, ntiles, side, maxlen, None, lens.ctypes.data_as(C.c_void_p), C.byref(S), 0))
     idx = np.zeros((b, S.value), np.int32)
     _lib.check(lib.omchat_splice_plan(ids.ctypes.data_as(C.c_void_p), pm, b, T, ntok, ntiles, side, maxlen, idx.ctypes.data_as(C.c_void_p),
-                                      lens.ctypes.data_as(C.c_void_p), C.byref(S)))
+                                      lens.ctypes.data_as(C.c_void_p), C.byref(S), 0))
     return idx, lens
+
+
+def test_splice_plan_rejects_ids_outside_the_embedding_table():
+    """the reference's embed_tokens raises IndexError for an id >= vocab or a stray negative id (omchat_arch.py:139); the plan
+    must refuse them before the device gather reads out of bounds.  Masked-out positions and -200 sentinels are fine."""
+    lib = _lib.lib()
+    S = C.c_int(0)
+    lens = np.zeros(1, np.int32)
+    call = lambda ids, mask, vocab: lib.omchat_splice_plan(np.ascontiguousarray(ids, np.int64).ctypes.data_as(C.c_void_p),
+                                                           None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data_as(C.c_void_p),
+                                                           1, len(ids[0]), 4, 1, 0, -1, None, lens.ctypes.data_as(C.c_void_p), C.byref(S), vocab)
+    assert call([[1, -200, 319]], None, 320) == 0
+    assert call([[1, -200, 320]], None, 320) == 4 and b"out of range" in lib.omchat_last_error()
+    assert call([[1, -200, -100]], None, 320) == 4
+    assert call([[1, -200, -100]], [[1, 1, 0]], 320) == 0          # padded positions are dropped first (:115)
+    assert call([[1, -200, 10 ** 9]], None, 0) == 0                # vocab <= 0: unchecked
+    with pytest.raises(IndexError):
+        _lib.check(4)
 
 
 @pytest.mark.parametrize("name", ["1x3", "2_uneven_right", "2_uneven_left", "noimage_row", "truncate"])
@@ -280,3 +298,63 @@ def test_public_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o", str(tmp_path / "hdr.o")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_hf_auto_classes_dispatch_to_the_hip_library(tmp_path):
+    """omchat_qwen2.py:113-114 / hf_example.py:7-8: the OmChat config / model / processor classes are registered with transformers'
+    Auto classes; on a box without a GPU the dispatch still reaches this library, which fails loudly (no CPU fallback)."""
+    import transformers
+    from omchat_amd.model import hf as H
+    from omchat_amd.model.builder import save_synthetic_checkpoint
+    from omchat_amd.config import tiny
+    assert type(transformers.AutoConfig.for_model("omchat")) is H.OmChatHFConfig
+    assert type(transformers.AutoConfig.for_model("omchat_qwen2")) is H.OmChatQwen2HFConfig
+    assert transformers.AutoModel._model_mapping[H.OmChatHFConfig] is H.OmChatForConditionalGeneration
+    assert transformers.AutoModelForCausalLM._model_mapping[H.OmChatQwen2HFConfig] is H.OmChatQwen2ForCausalLMHF
+    cfg = tiny(layers_v=1, layers_t=1)
+    path = save_synthetic_checkpoint(str(tmp_path / "hf"), cfg, 1, "hf")
+    assert type(transformers.AutoConfig.from_pretrained(path)) is H.OmChatHFConfig
+    import torch
+    if not torch.cuda.is_available():
+        for auto in (transformers.AutoModel, H.AutoModel):
+            with pytest.raises(_lib.OmchatError, match="HIP device"):
+                auto.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.float16)
+    proc = H.AutoProcessor.from_pretrained(path, trust_remote_code=True)
+    assert type(proc).__name__ == "OmChatProcessor" and proc.tokenizer is not None and proc.image_processor.crop_size["height"] == 56
+    out = proc(text="w1 w2")                                  # text-only: no device work
+    assert isinstance(out, transformers.BatchFeature) and out.input_ids.shape[0] == 1
+
+
+def test_make_context_and_get_context_vs_ids_captured_from_the_reference():
+    """omchat/make_context.py:14-43,66-148 run in the build container with a stub one-id-per-character tokenizer
+    (tools/make_golden_r2.py): system prompt, image sentinels, the newest-first history window and the raw format must give the
+    same raw_text and context_tokens here"""
+    import json, os, types
+    import torch
+    from conftest import GOLDEN
+    from omchat_amd.make_context import make_context, get_context
+    import omchat_amd.make_context as mc
+
+    class Tok:
+        bos_token_id = None
+        def encode(self, s): return [1000 + ord(ch) for ch in s]
+        def __call__(self, s): return types.SimpleNamespace(input_ids=self.encode(s))
+
+    cases = json.load(open(os.path.join(GOLDEN, "make_context.json")))
+    assert len(cases) >= 10
+    for c in cases:
+        if c["name"].startswith("get_context"):
+            n = c["n_tiles"]
+            orig = mc.process_anyres_image
+            mc.process_anyres_image = lambda image, ip, pins, flag, return_best_res=False, n=n: ([torch.zeros(3, 4, 4)] * n, (448, 896))
+            try:
+                inp, ids, image_tensor = get_context(c["text"], Tok(), image=object(), image_processor=None, image_grid_pinpoints=None, device="cpu")
+            finally:
+                mc.process_anyres_image = orig
+            assert list(image_tensor.shape) == c["image_tensor_shape"] and str(image_tensor.dtype) == c["image_tensor_dtype"]
+        else:
+            hist = [tuple(h) for h in c["history"]] if c["history"] else None
+            inp, ids = make_context(Tok(), c["query"], hist, c["system"], c["max_window_size"], c.get("chat_format", "chatml"))
+        assert inp == c["raw_text"], c["name"]
+        assert ids == c["context_tokens"], c["name"]
+        assert ids.count(-200) == c["raw_text"].count("<image>") or c.get("chat_format") == "raw"

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the tensor-parallel sharding plan (omchat_amd/tp.py) executed with the same dataflow as
+"""CPU, world_size 2 / 4 / 8 over gloo: the tensor-parallel sharding plan (omchat_amd/tp.py) executed with the same dataflow as
 the C++ loops (model.hip: rank 0 carries bias + residual, one all-reduce per sub-block, joint q/k-norm sum of squares
 all-reduced with the divisor kept at the full channel count) must reproduce the unsharded oracle."""
 import os
@@ -83,15 +83,18 @@ def _worker(rank, size, port, case, q):
     dist.init_process_group("gloo", rank=rank, world_size=size)
     torch.manual_seed(0)
     try:
-        if case == "vit":
-            cfg = tiny(heads_v=3, layers_v=1)                       # 3 heads over 2 ranks: [0,1] and [2,pad]
+        if case.startswith("vit"):
+            hv = 3 if case == "vit" else 5                          # 3 heads over 2 ranks: [0,1] and [2,pad]; 5 heads over 4 / 8 ranks:
+            cfg = tiny(heads_v=hv, layers_v=1)                      # the 25-head pattern (one rank with an extra real head, the rest padded)
             sd = synth.state_dict(cfg, 3, synth.TOWER)
-            x = torch.randn(2, 17, 384)
+            x = torch.randn(2, 17, 128 * hv)
             out = _vit_layer_tp(x, sd, cfg, rank, size)
-            ref = oracle.vit_layer(x, _sub({k: T(v) for k, v in sd.items()}, TOWER_PFX), 0, 3)
+            ref = oracle.vit_layer(x, _sub({k: T(v) for k, v in sd.items()}, TOWER_PFX), 0, hv)
             err = float((out - ref).norm() / ref.norm())
         else:
-            qh, kvh = (4, 2) if case == "dec_split" else (7, 1)     # kv heads split / kv head replicated with 4+3(+pad) q heads
+            # kv heads split / kv head replicated with 4+3(+pad) q heads / the Qwen2-7B head pattern (28 q, 4 kv): TP = 4 splits the kv
+            # heads (7 q each), TP = 8 replicates every kv head on two ranks that take 4 and 3 (+1 zero) of its query heads
+            qh, kvh = {"dec_split": (4, 2), "dec_replicated_kv": (7, 1), "dec28_4": (28, 4)}[case]
             cfg = tiny(q_heads=qh, kv_heads=kvh, layers_t=1)
             sd = {k: v for k, v in synth.state_dict(cfg, 4).items() if k.startswith(("model.layers.0.", "lm_head"))}
             x = torch.randn(1, 9, 256)
@@ -105,15 +108,16 @@ def _worker(rank, size, port, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["vit", "dec_split", "dec_replicated_kv"])
-def test_tp2_equals_unsharded(case):
+@pytest.mark.parametrize("case,size", [("vit", 2), ("dec_split", 2), ("dec_replicated_kv", 2),
+                                       ("vit5", 4), ("vit5", 8), ("dec28_4", 4), ("dec28_4", 8)])
+def test_tp_equals_unsharded(case, size):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, size, port, case, q)) for r in range(size)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
