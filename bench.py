@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-tp1-check", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny geometry (NOT the benchmark config)")
+    ap.add_argument("--tuning", default="", help="debug: comma-separated key=value pairs for omchat_op_set_tuning (include/omchat_hip.h)")
     return ap.parse_args()
 
 
@@ -203,6 +204,9 @@ def main():
     from omchat_amd.engine import Engine
     from omchat_amd import tp
 
+    for kv in filter(None, a.tuning.split(",")):
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().omchat_op_set_tuning(int(k), int(v)))
     cfg = tiny() if a.tiny else omchat13b()
     n_tiles = 3
     ntok = cfg.num_image_tokens

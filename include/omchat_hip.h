@@ -166,7 +166,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
 /* experiment knobs (key 0: start skew of the 256x256 GEMM workgroups, in units of ~1024 cycles; key 1: 1 = skinny GEMM
  * always takes the MFMA form, 0 = batch 1 takes the whole-row streaming form; key 4: row count from which a tensor-parallel
  * row-parallel projection is pipelined against its all-reduce in 2 chunks (3x: 4 chunks), default 1024; key 5: 0 = GEMM tile
- * shapes from the cost model instead of the first-use measurement) */
+ * shapes from the cost model instead of the first-use measurement; key 6: 0 = batched decode steps (2 <= b <= 32) read the
+ * row-major weights instead of building the packed replica (+ one more copy of the decoder weights)) */
 int omchat_op_set_tuning(int key, int value);
 size_t omchat_op_gemm_sk_ws(void);
 int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -174,6 +175,12 @@ int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw,
                       size_t ws_bytes, int stream_k, void* stream);
 int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
                    const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream);
+/* batched decode GEMV with packed operands (MFMA fragment order, csrc/common.h): packs X [b <= 32, K] (and W [N, K] when
+ * w_packed) into scratch, then Y = epi(X W^T); epi EPI_NONE (T or fp32 out) | EPI_SWIGLU (y_packed: output in the packed x layout
+ * of the consumer) | EPI_PARTIAL (fp32 [ksplit][b][ldy]).  omchat_op_pack_x: row-major -> packed x with NB = b > 16 ? 2 : 1. */
+int omchat_op_gemv_packed(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
+                          const void* bias, int epi, int out_f32, int ksplit, int w_packed, int y_packed, void* stream);
+int omchat_op_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, void* stream);
 /* fp8 pieces: W [N][K] (dtype) -> W8 [N][K] e4m3 bytes + scale [N]; y[N] = (W8 . x) * scale (+ epilogue), batch 1;
  * epi EPI_PARTIAL writes fp32 slices [ksplit][N] */
 int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float* scale, void* stream);

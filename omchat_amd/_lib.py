@@ -59,6 +59,8 @@ _SIGS = {
     "omchat_op_gemm_sk_ws": (_sz, []),
     "omchat_op_gemm_sk": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
     "omchat_op_gemv": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "omchat_op_gemv_packed": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "omchat_op_pack_x": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     "omchat_enable_fp8_decode": (_i, [_vp, _i]),
     "omchat_enable_decode_graph": (_i, [_vp, _i]),
     "omchat_decode_graph_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),

@@ -54,7 +54,10 @@ __device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type 
 
 constexpr int KV_TILE = 64;
 constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
-constexpr float NEG_BIG = -1e30f;
+constexpr float NEG_BIG = -1e30f;      // a masked score
+constexpr float M_FLOOR = -1e20f;      // initial running-max reference: far below any real score, far above NEG_BIG, so that a row whose
+                                       // keys are ALL masked (padded query rows of a left-padded batch) gets p = exp2(-huge) = 0, l = 0 and an
+                                       // output of exactly 0 -- never inf - inf.  Its V rows feed later layers as masked keys: 0 * finite.
 constexpr float RESCALE_LOG2 = 8.f;   // prefill: running-max reference moves only on a > 2^8 overshoot
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   float m_run[NQ], l_run[NQ];
 #pragma unroll
   for (int qt = 0; qt < NQ; ++qt) {
-    m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
+    m_run[qt] = M_FLOOR; l_run[qt] = 0.f;
 #pragma unroll
     for (int dn = 0; dn < DN; ++dn) o[qt][dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
   for (int qt = 0; qt < NQ; ++qt) {
     const float l = sum_xor32(sum_xor16(l_run[qt]));
     if (qrow[qt] < p.Sq) {
-      const float inv = 1.f / l;
+      const float inv = l > 0.f ? 1.f / l : 0.f;
       T* op = (T*)p.O + b * p.o_sb + hq0 * p.o_sh + qrow[qt] * p.o_sr + fg * 4;
 #pragma unroll
       for (int dn = 0; dn < DN; ++dn) {
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
 // phase 2: thread d sums its column over the splits with independent (unrolled) loads.
 template <typename T>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
-                                                         T* O, int64_t o_sb, int64_t o_sh) {
+                                                         T* O, int64_t o_sb, int64_t o_sh, int pack_nb) {
   __shared__ float fw[1024];
   __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -531,7 +534,8 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
     for (; s < n; ++s) acc += fw[s] * wd[(size_t)s * WS_STRIDE];
     __syncthreads();
   }
-  O[b * o_sb + h * o_sh + d] = fromf<T>(acc / ltot);
+  // pack_nb: the consumer is the batched o_proj GEMV, which reads its x operand in MFMA fragment order (common.h)
+  O[pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d)] = fromf<T>(acc / ltot);
 }
 
 }  // namespace
@@ -573,14 +577,15 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
           a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max};
   OM_CHECK(!a.rope || (a.pos && a.k_new && a.v_new && a.kv_len), "fused RoPE decode needs pos, k_new, v_new and kv_len");
+  OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
     hipLaunchKernelGGL(attn_decode_kernel<f16>, grid, dim3(64), 0, s, p);
-    hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh);
+    hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
   } else if (dtype == OMCHAT_BF16) {
     hipLaunchKernelGGL(attn_decode_kernel<bf16>, grid, dim3(64), 0, s, p);
-    hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh);
+    hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

@@ -17,6 +17,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 1) { gemv_set_force_mfma(value); return 0; }
   if (key == 5) { gemm_set_autotune(value); return 0; }
   if (key == 4) { model_set_ar_min_rows(value); return 0; }
+  if (key == 6) { model_set_pack_replica(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }
@@ -35,6 +36,29 @@ extern "C" int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, 
   GemvArgs g{X, ldx, W, ldw, Y, ldy, b, N, K, bias, resid, ldr, epi, out_f32};
   return launch_gemv(dtype, g, S(stream));
 }
+
+// packed-operand batched GEMV (gemv.hip: gemv_pk_kernel): X row-major [b, K] and W row-major [N, K] are packed into scratch here
+// (launch_pack_x / launch_pack_w), then Y = epi(X W^T); y_packed != 0 returns the SwiGLU output in the packed x layout
+extern "C" int omchat_op_gemv_packed(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
+                                     const void* bias, int epi, int out_f32, int ksplit, int w_packed, int y_packed, void* stream) {
+  OM_CHECK(b >= 1 && b <= 32 && K % 64 == 0, "1 <= b <= 32, K % 64 == 0");
+  const int NB = b > 16 ? 2 : 1;
+  void *xp = nullptr, *wp = nullptr;
+  OM_HIP(hipMalloc(&xp, (size_t)NB * 16 * K * 2));
+  int rc = launch_pack_x(dtype, X, ldx, b, K, xp, S(stream));
+  if (rc == 0 && w_packed) {
+    if (hipMalloc(&wp, (size_t)N * K * 2) != hipSuccess) { hipFree(xp); omchat_set_error("hipMalloc failed"); return 2; }
+    rc = launch_pack_w(dtype, W, ldw, N, K, wp, S(stream));
+  }
+  if (rc == 0) {
+    GemvArgs g{xp, K, w_packed ? wp : W, ldw, Y, ldy, b, N, K, bias, nullptr, 0, epi, out_f32, ksplit, 0, nullptr, 1, w_packed, y_packed};
+    rc = launch_gemv(dtype, g, S(stream));
+  }
+  hipStreamSynchronize(S(stream));
+  hipFree(xp); if (wp) hipFree(wp);
+  return rc;
+}
+extern "C" int omchat_op_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, void* stream) { return launch_pack_x(dtype, X, ldx, b, K, out, S(stream)); }
 
 extern "C" int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream) {
   return launch_rmsnorm(dtype, x, H, w, y, H, rows, H, eps, S(stream));

@@ -147,7 +147,14 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_twoshot_kernel(PeerK k, voi
   const u32x4_t* src = reinterpret_cast<const u32x4_t*>(buf);
   u32x4_t* dst = reinterpret_cast<u32x4_t*>(buf);
   const int stride = gridDim.x * PEER_THREADS, t0 = blockIdx.x * PEER_THREADS + threadIdx.x;
-  for (int i = t0; i < n16; i += stride) __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, i << 4, 0, AUX_SYS);
+  // Every stage walks a segment as  first piece + t0 + m * stride : piece i of segment r is then touched by the SAME block index on
+  // every rank in all three stages (copy-in here, reduction by rank r, gather by the others), which is what the per-block barrier
+  // orders.  (A flat copy-in loop over the whole message breaks that whenever a segment is not a whole number of strides: the reducer
+  // would read pieces that a DIFFERENT block of the peer has not written yet.)
+  for (int r = 0; r < k.size; ++r) {
+    const int l1 = r * seg16, h1 = l1 + seg16 < n16 ? l1 + seg16 : n16;
+    for (int i = l1 + t0; i < h1; i += stride) __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, i << 4, 0, AUX_SYS);
+  }
   peer_barrier(k);
   // reduce my segment into my result area (and into the output)
   const int lo = k.rank * seg16, hi = lo + seg16 < n16 ? lo + seg16 : n16;

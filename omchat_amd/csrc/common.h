@@ -81,6 +81,19 @@ template <typename T> __device__ __forceinline__ void st8(T* p, typename V8<T>::
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Packed ("MFMA fragment order") operand layouts of the batched decode GEMV (gemv.hip): every wave load is 1 KiB contiguous.
+//   x  [K/64 chunks][2 halves][NB][64 lanes][8]   lane l of (chunk, half, nb) holds batch row 16*nb + (l & 15), k = 64*chunk + 32*half + 8*(l >> 4) + j
+//   W  [N/16 tiles][K/64 chunks][2 halves][64 lanes][8]   lane l holds weight row 16*tile + (l & 15), the same k
+// NB = 1 for up to 16 batch rows, 2 for up to 32.  Element index of x[row][k]:
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ size_t packed_x_index(int row, int k, int NB) {
+  return ((((size_t)(k >> 6) * 2 + ((k >> 5) & 1)) * NB + (row >> 4)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}
+__host__ __device__ __forceinline__ size_t packed_w_index(int row, int k, int K) {
+  return ((((size_t)(row >> 4) * (K >> 6) + (k >> 6)) * 2 + ((k >> 5) & 1)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 void omchat_set_error(const std::string& s);

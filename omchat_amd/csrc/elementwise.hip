@@ -25,7 +25,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // fp32 statistics, y = T( w * T(x * rsqrt(mean(x^2) + eps)) )   (two roundings, N2)
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int ldx, const T* w, T* y, int ldy, int H, float eps) {
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int ldx, const T* w, T* y, int ldy, int H, float eps, int pack_nb) {
   typedef typename V8<T>::type v8;
   __shared__ float red[NORM_THREADS / 64];
   const int row = blockIdx.x;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
       v8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(tof(xv[i][j]) * inv));
-      st8<T>(yr + c * 8, o);
+      st8<T>(pack_nb ? y + packed_x_index(row, c * 8, pack_nb) : yr + c * 8, o);
     }
   }
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(const T* x, int
 // (T(linear) then T(residual + .), modeling_qwen2.py:283-296), then the NEXT RMSNorm of the same row, in one pass.
 template <typename T, int KS>
 __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int ldx, const float* part, int rows, const T* w, T* xn,
-                                                                     int ldn, int H, float eps) {
+                                                                     int ldn, int H, float eps, int pack_nb) {
   typedef typename V8<T>::type v8;
   __shared__ float red[NORM_THREADS / 64];
   const int row = blockIdx.x;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int l
       v8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(xv[i][j] * inv));
-      st8<T>(nr + c * 8, o);
+      st8<T>(pack_nb ? xn + packed_x_index(row, c * 8, pack_nb) : nr + c * 8, o);
     }
   }
 }
@@ -424,10 +424,11 @@ int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const voi
   return 0;
 }
 
-int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s) {
+int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s, int pack_nb) {
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");
+  OM_CHECK(pack_nb == 0 || (rows <= 16 * pack_nb && H % 64 == 0 && x != y), "packed output: rows <= 16 * NB, H % 64 == 0, not in place");
   if (rows == 0) return 0;
-  DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, H, eps));
+  DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, H, eps, pack_nb));
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -511,11 +512,12 @@ int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scr
 }
 
 int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
-                         hipStream_t s) {
+                         hipStream_t s, int pack_nb) {
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldn % 8 == 0 && ks >= 1, "H % 8, H <= 16384, ld % 8");
+  OM_CHECK(pack_nb == 0 || (rows <= 16 * pack_nb && H % 64 == 0), "packed output: rows <= 16 * NB, H % 64 == 0");
   if (rows == 0) return 0;
   OM_CHECK(ks <= 8, "at most 8 K slices");
-#define RR(KS_) case KS_: DISPATCH(dtype, hipLaunchKernelGGL((resid_rmsnorm_kernel<T, KS_>), dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, part, rows, (const T*)w, (T*)xn, ldn, H, eps)); break;
+#define RR(KS_) case KS_: DISPATCH(dtype, hipLaunchKernelGGL((resid_rmsnorm_kernel<T, KS_>), dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, part, rows, (const T*)w, (T*)xn, ldn, H, eps, pack_nb)); break;
   switch (ks) { RR(1) RR(2) RR(3) RR(4) RR(5) RR(6) RR(7) RR(8) }
 #undef RR
   OM_LAUNCH_CHECK();

@@ -17,6 +17,7 @@ struct GemvP {
   const void* X; const void* W; void* Y; const void* bias; const void* resid;
   int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
   const float* w_scale;
+  int y_packed;
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
@@ -174,6 +175,156 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
         }
       }
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched decode (2 <= b <= 32) with PACKED operands (common.h: packed_x_index / packed_w_index).  The kernel above loads
+// fragment-shaped operands (16 rows x 64 B per wave instruction) for W AND for x; at b = 32 the x loads (L2 hits, as many bytes
+// as the weights) make it address-path bound: 3.2 TB/s on gate|up.  Here x arrives packed from its producer (RMSNorm, attention
+// merge, SwiGLU epilogue) and W optionally from the packed replica, so every wave load is 1 KiB contiguous; NTILE row tiles share
+// each x fragment.  Measured (tools/tune_gemv32.hip, MI355X, b = 32): gate|up 84 -> 66 us with packed x, -> 53 us with packed W
+// too (5.1 TB/s); down_proj 50 -> 28 us; qkv 17.7 -> 12.2; o_proj 13.8 -> 9.0; lm_head 318 -> 207.
+// Wave w of a workgroup walks K chunks (64 wide) c_lo + UNROLL * (w + WAVES * i) + u; partial tiles are summed through LDS in a
+// fixed order by all waves, which also apply the epilogue.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int NTILE, int EPI, int WAVES, int UNROLL, int NB, bool WPACK>
+__global__ __launch_bounds__(WAVES * 64) void gemv_pk_kernel(GemvP p) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ float red[WAVES][NTILE * NB][256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tile0 = blockIdx.x * NTILE;
+  const int n_tiles = (p.N + 15) >> 4;
+  const int nchunk_all = p.K >> 6;
+  const int c_lo = (int)(((long)nchunk_all * blockIdx.y) / p.ksplit), c_hi = (int)(((long)nchunk_all * (blockIdx.y + 1)) / p.ksplit);
+
+  const T* W = (const T*)p.W;
+  const T* wbase[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int tl = tile0 + t < n_tiles ? tile0 + t : n_tiles - 1;
+    if constexpr (WPACK) wbase[t] = W + (size_t)tl * nchunk_all * 1024 + lane * 8;
+    else { int r = tl * 16 + fr; r = r < p.N ? r : p.N - 1; wbase[t] = W + (size_t)r * p.ldw + fg * 8; }
+  }
+  const T* xbase = (const T*)p.X + lane * 8;
+
+  f32x4 acc[NTILE][NB];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = c_lo + wave * UNROLL; c0 < c_hi; c0 += WAVES * UNROLL) {
+    frag_t wf[UNROLL][NTILE][2], xf[UNROLL][NB][2];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int c = c0 + u < c_hi ? c0 + u : c_hi - 1;          // ragged last group: re-load the last chunk, skip its MFMAs below
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const T* q = WPACK ? wbase[t] + (size_t)c * 1024 + h * 512 : wbase[t] + c * 64 + h * 32;
+          wf[u][t][h] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(q));
+        }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xf[u][nb][h] = ld8<T>(xbase + ((size_t)(c * 2 + h) * NB + nb) * 512);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (c0 + u < c_hi) {                                      // wave-uniform
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) {
+            acc[t][nb] = mfma16(wf[u][t][0], xf[u][nb][0], acc[t][nb]);
+            acc[t][nb] = mfma16(wf[u][t][1], xf[u][nb][1], acc[t][nb]);
+          }
+      }
+    }
+  }
+  // acc[t][nb][r] = Y^T[n = (tile0 + t)*16 + 4*fg + r][batch = 16*nb + fr]
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t * NB + nb][(fg * 4 + r) * 16 + fr] = acc[t][nb][r];
+  __syncthreads();
+
+  const T* bias = (const T*)p.bias;
+  for (int i = threadIdx.x; i < NB * 256; i += WAVES * 64) {
+    const int nb = i >> 8, e = i & 255, nl = e >> 4, bi = nb * 16 + (e & 15);
+    float v[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) s += red[w][t * NB + nb][e];      // fixed order: deterministic
+      v[t] = s;
+    }
+    if (bi >= p.b) continue;
+    if constexpr (EPI == EPI_PARTIAL) {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = (tile0 + t) * 16 + nl;
+        if (n < p.N) ((float*)p.Y)[((size_t)blockIdx.y * p.b + bi) * p.ldy + n] = v[t];
+      }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+      // tiles (2q, 2q + 1) = 16 gate rows and the matching 16 up rows of the fused, interleaved weight
+#pragma unroll
+      for (int t = 0; t < NTILE; t += 2) {
+        const int row = (tile0 + t) * 16 + nl;                  // gate row in the fused layout
+        if (row + 16 < p.N) {
+          const int n = ((tile0 + t) >> 1) * 16 + nl;
+          const float g = rnd<T>(v[t]), u = rnd<T>(v[t + 1]);
+          const T y = fromf<T>(rnd<T>(silu(g)) * u);
+          if (p.y_packed) ((T*)p.Y)[packed_x_index(bi, n, NB)] = y;
+          else ((T*)p.Y)[(size_t)bi * p.ldy + n] = y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = (tile0 + t) * 16 + nl;
+        if (n >= p.N) continue;
+        const float y = v[t] + (bias ? tof(bias[n]) : 0.f);
+        if (p.out_f32) ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
+        else ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
+      }
+    }
+  }
+}
+
+// row-major -> packed (model load time / tests)
+template <typename T>
+__global__ void pack_x_kernel(const T* X, int ldx, int b, int K, T* out, int NB) {
+  const int n8 = NB * 16 * (K >> 3);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+    const int row = i / (K >> 3), k = (i % (K >> 3)) * 8;
+    typename V8<T>::type v;
+    if (row < b) v = ld8<T>(X + (size_t)row * ldx + k);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (T)0.f;
+    }
+    st8<T>(out + packed_x_index(row, k, NB), v);
+  }
+}
+template <typename T>
+__global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
+  const long n8 = (long)N * (K >> 3);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    // destination-linear: consecutive threads write consecutive 16-byte pieces of the packed image
+    const long piece = i;
+    const int lane = (int)(piece & 63), half = (int)((piece >> 6) & 1);
+    const long tc = piece >> 7;
+    const int chunk = (int)(tc % (K >> 6)), tile = (int)(tc / (K >> 6));
+    const int row = tile * 16 + (lane & 15), k = chunk * 64 + half * 32 + (lane >> 4) * 8;
+    st8<T>(out + piece * 8, ld8<T>(W + (size_t)row * ldw + k));
   }
 }
 
@@ -383,7 +534,25 @@ void launch_rows(const GemvP& p, hipStream_t s) {
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale};
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed};
+  if (a.x_packed) {
+    // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
+#define OM_PK(NT_, EPI_, WV_, UN_)                                                                                                  \
+  do {                                                                                                                              \
+    const dim3 grid(cdiv(cdiv(a.N, 16), NT_), ks);                                                                                  \
+    if (a.b > 16) { if (a.w_packed) hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 2, true>), grid, dim3(WV_ * 64), 0, s, p);   \
+                    else hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 2, false>), grid, dim3(WV_ * 64), 0, s, p); }            \
+    else { if (a.w_packed) hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, true>), grid, dim3(WV_ * 64), 0, s, p);            \
+           else hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, false>), grid, dim3(WV_ * 64), 0, s, p); }                     \
+  } while (0)
+    if (a.epi == EPI_SWIGLU) OM_PK(2, EPI_SWIGLU, 8, 4);
+    else if (a.epi == EPI_PARTIAL) { if (a.K / ks >= 1536) OM_PK(4, EPI_PARTIAL, 4, 2); else OM_PK(2, EPI_PARTIAL, 8, 4); }
+    else if (a.N >= 32768) OM_PK(4, EPI_NONE, 4, 4);
+    else OM_PK(2, EPI_NONE, 8, 4);
+#undef OM_PK
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
   const bool rows_ok = a.b == 1 && cdiv(cdiv(a.K, 512), ks) <= RW_MAXC;
   if (a.w_scale && !rows_ok) { omchat_set_error("launch_gemv: fp8 weights need b == 1 and <= 8 chunks of 512 per K slice"); return 1; }
   if (rows_ok && (a.w_scale || (!a.force_mfma && !g_gemv_force_mfma))) {       // whole-row streaming form
@@ -471,8 +640,33 @@ int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void*
   return 0;
 }
 
+int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s) {
+  OM_CHECK(b >= 1 && b <= 32 && K % 64 == 0 && ldx % 8 == 0, "pack_x: 1 <= b <= 32, K % 64, ldx % 8");
+  const int NB = b > 16 ? 2 : 1;
+  const int grid = cdiv(NB * 16 * (K / 8), 256);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(pack_x_kernel<f16>, dim3(grid), dim3(256), 0, s, (const f16*)X, ldx, b, K, (f16*)out, NB);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(pack_x_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)X, ldx, b, K, (bf16*)out, NB);
+  else { omchat_set_error("launch_pack_x: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pack_w(int dtype, const void* W, int ldw, int N, int K, void* out, hipStream_t s) {
+  OM_CHECK(N % 16 == 0 && K % 64 == 0 && ldw % 8 == 0, "pack_w: N % 16, K % 64, ldw % 8");
+  const long n8 = (long)N * (K / 8);
+  const int grid = (int)(cdiv64(n8, 256) > 8192 ? 8192 : cdiv64(n8, 256));
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(pack_w_kernel<f16>, dim3(grid), dim3(256), 0, s, (const f16*)W, ldw, N, K, (f16*)out);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(pack_w_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)W, ldw, N, K, (bf16*)out);
+  else { omchat_set_error("launch_pack_w: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 32, "batch must be 1..32 per call");
+  OM_CHECK(!a.x_packed || (!a.w_scale && a.epi != EPI_RESID), "packed x: 16-bit weights, epilogue NONE / SWIGLU / PARTIAL");
+  OM_CHECK(!a.w_packed || (a.x_packed && a.N % 16 == 0), "packed W needs packed x and N % 16 == 0");
+  OM_CHECK(!a.y_packed || (a.x_packed && a.epi == EPI_SWIGLU), "packed y: SwiGLU epilogue of the packed kernel only");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
   OM_CHECK(!a.w_scale || a.b == 1, "fp8 weights: batch 1 only");
   OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU || a.epi == EPI_PARTIAL, "bad epilogue");

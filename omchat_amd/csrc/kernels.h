@@ -45,7 +45,15 @@ struct GemvArgs {
   int ksplit;               // K slices across workgroups (EPI_PARTIAL), <= 1 = none
   int force_mfma;           // 1 = always the MFMA form (tests / A-B); default: b == 1 uses the whole-row streaming form
   const float* w_scale;     // non-null: W is OCP e4m3 bytes [N][ldw] with one fp32 scale per row (weight-only fp8, b == 1 only)
+  // batched decode (b <= 32) with operands in MFMA fragment order (common.h: packed_x_index / packed_w_index): every wave load is 1 KiB
+  // contiguous instead of 16 rows x 64 B (measured, tools/tune_gemv32.hip: gate|up at b = 32 84 -> 53 us, down 50 -> 28 us)
+  int x_packed;             // X is packed with NB = b > 16 ? 2 : 1 (ldx ignored)
+  int w_packed;             // W is the packed replica (ldw ignored); needs x_packed
+  int y_packed;             // EPI_SWIGLU only: write Y in the packed x layout of the consumer (same NB; ldy ignored)
 };
+// row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
+int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
+int launch_pack_w(int dtype, const void* W, int ldw, int N, int K, void* out, hipStream_t s);
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
 // per-row (output channel) symmetric quantisation of W [N][ldw] (T) to OCP e4m3: scale[n] = absmax_n / 448 (1 if the row is 0),
 // W8[n][k] = e4m3_rne(W[n][k] / scale[n])
@@ -53,14 +61,16 @@ int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void*
 void gemv_set_force_mfma(int v);
 void gemm_set_autotune(int v);
 void model_set_ar_min_rows(int v);
+void model_set_pack_replica(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)
 int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps, hipStream_t stream);
-int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s);
+// pack_nb != 0: y is written in the packed x layout (common.h) with NB = pack_nb instead of row-major (rows <= 16 * pack_nb)
+int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s, int pack_nb = 0);
 // decode: x = T(x + T(sum_s part[s])) in place, then xn = rmsnorm(x) * w (w == null: skip the norm).  part fp32 [ks][rows][H]
 int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
-                         hipStream_t s);
+                         hipStream_t s, int pack_nb = 0);
 // ViT joint-head q/k RMSNorm in place on the fused qkv buffer [rows, 3C] (q = cols [0,C), k = [C,2C)); q is also
 // multiplied by q_scale with the reference's rounding (modeling_intern_vit.py:143-148).
 // sumsq_in: optional [rows,2] fp32 externally reduced sum of squares (tensor parallel); C_total = divisor.
@@ -101,6 +111,7 @@ struct AttnDecodeArgs {
   const float* rope; int rope_max;              // cos/sin table [max_pos][64][2] or null (= q, K, V already rotated/appended)
   const int* pos;                               // device [batch]; kv_len[b] must be pos[b] + 1
   const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v of the new token: [b][kv_heads*128] views, batch stride
+  int o_pack_nb;                                // != 0: O is written as packed x ([b][q_heads*128] rows, common.h) for the o_proj GEMV
 };
 size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len);
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s);

@@ -89,6 +89,12 @@ struct omchat_ctx {
   // scale per output row; batch-1 decode steps stream these instead of the 16-bit weights, prefill keeps the 16-bit ones
   struct DecLayer8 { void *wqkv, *wo, *wgu, *wd; float *sqkv, *so, *sgu, *sd; };
   std::vector<DecLayer8> dl8;
+  // packed replica of the same weights for BATCHED decode steps (2 <= b <= 32): MFMA fragment order, every wave load 1 KiB contiguous
+  // (gemv.hip: gemv_pk_kernel; +14 GB at OmChat-13B, built on the first batched step; omchat_op_set_tuning key 6 = 0 disables it)
+  struct DecLayerP { void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr; };
+  std::vector<DecLayerP> dlp;
+  void* t_lmP = nullptr;
+  bool pk_ready = false;
   void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
   bool fp8_decode = false, fp8_stale = false;
   // decode step as a hipGraph (omchat_enable_decode_graph): ~230 launches per token replayed as one graph launch.  Captured on a
@@ -315,7 +321,7 @@ int build(omchat_ctx* ctx) {
     TRY(ctx->alloc((void**)&ctx->vw_sumsq, M * 2 * 4 + 64));
   }
   if (c.t_layers > 0) {
-    const size_t R = (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch);
+    const size_t R = std::max<size_t>(32, (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch));      // >= 32: packed decode operands
     TRY(ctx->alloc(&ctx->tw_x, R * H * 2));
     TRY(ctx->alloc(&ctx->tw_x2, R * H * 2));
     TRY(ctx->alloc(&ctx->tw_xn, R * H * 2));
@@ -443,6 +449,7 @@ extern "C" int omchat_load_tensor(omchat_ctx* ctx, const char* name, const void*
     OM_CHECK(split_ok, std::string("shape mismatch for ") + name + ": expected [" + std::to_string(r.rows) + ", " + std::to_string(r.cols) + "]");
   }
   if (!ctx->dl8.empty()) ctx->fp8_stale = true;      // the e4m3 replica no longer matches the 16-bit weights
+  ctx->pk_ready = false;                              // nor does the packed replica
   if (src_dtype == ctx->dt) return place(ctx, r, data);
   OM_CHECK(src_dtype == OMCHAT_F32, "source dtype must be the context dtype or OMCHAT_F32");
   TRY(ensure_stage(ctx, (size_t)n * 4, (size_t)n * 2));
@@ -496,6 +503,8 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
+int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
+void model_set_pack_replica(int v) { g_pack_replica = v; }
 int g_ar_min_rows = 1024;      // rows from which a projection is pipelined in 2 (x3: 4) chunks; tests lower it (omchat_op_set_tuning key 4)
 void model_set_ar_min_rows(int v) { g_ar_min_rows = v > 8 ? v : 8; }
 
@@ -724,12 +733,16 @@ extern "C" int omchat_splice_gather(omchat_ctx* ctx, const int32_t* src_index, c
 // ---------------------------------------------------------------------------------------------------------
 // decoder
 // ---------------------------------------------------------------------------------------------------------
-static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s, bool fp8 = false) {
+static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logits, hipStream_t s, bool fp8 = false, bool packed = false) {
   const int H = ctx->c.t_hidden, V = ctx->c.t_vocab;
   for (int r0 = 0; r0 < n; r0 += 32) {
     const int R = std::min(32, n - r0);
     GemvArgs g{(const char*)hidden + (size_t)r0 * H * 2, H, ctx->t_lm, H, logits + (size_t)r0 * V, V, R, V, H, nullptr, nullptr, 0, EPI_NONE, 1};
     if (fp8 && n == 1) { g.W = ctx->t_lm8; g.w_scale = ctx->t_lm8_s; }
+    if (packed) {          // hidden is in the packed x layout (n <= 32)
+      g.x_packed = 1;
+      if (ctx->pk_ready) { g.W = ctx->t_lmP; g.w_packed = 1; }
+    }
     TRY(launch_gemv(ctx->dt, g, s));
   }
   return 0;
@@ -879,6 +892,33 @@ extern "C" int omchat_prefill_left(omchat_ctx* ctx, const void* embeds, int b, i
   return prefill_impl(ctx, embeds, b, S, lengths, logits_last, hidden_out, stream, true);
 }
 
+// (re)build the packed weight replica of the decode-streamed decoder weights; synchronous, never inside a graph capture
+static int ensure_packed(omchat_ctx* ctx) {
+  if (!g_pack_replica || ctx->pk_ready) return 0;
+  const omchat_config& c = ctx->c;
+  const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
+  if (qkvd % 16 || H % 16 || c.t_vocab % 16) return 0;          // odd geometry: stay on the row-major weights
+  if (ctx->dlp.empty()) {
+    ctx->dlp.resize(c.t_layers);
+    for (auto& P : ctx->dlp) {
+      TRY(ctx->alloc(&P.wqkv, (size_t)qkvd * H * 2)); TRY(ctx->alloc(&P.wo, (size_t)H * qd * 2));
+      TRY(ctx->alloc(&P.wgu, (size_t)2 * It * H * 2)); TRY(ctx->alloc(&P.wd, (size_t)H * It * 2));
+    }
+    TRY(ctx->alloc(&ctx->t_lmP, (size_t)c.t_vocab * H * 2));
+  }
+  for (int i = 0; i < c.t_layers; ++i) {
+    auto& L = ctx->dl[i]; auto& P = ctx->dlp[i];
+    TRY(launch_pack_w(ctx->dt, L.wqkv, H, qkvd, H, P.wqkv, nullptr));
+    TRY(launch_pack_w(ctx->dt, L.wo, qd, H, qd, P.wo, nullptr));
+    TRY(launch_pack_w(ctx->dt, L.wgu, H, 2 * It, H, P.wgu, nullptr));
+    TRY(launch_pack_w(ctx->dt, L.wd, It, H, It, P.wd, nullptr));
+  }
+  TRY(launch_pack_w(ctx->dt, ctx->t_lm, H, c.t_vocab, H, ctx->t_lmP, nullptr));
+  OM_HIP(hipDeviceSynchronize());
+  ctx->pk_ready = true;
+  return 0;
+}
+
 // One decode step on stream s.  Lmax = upper bound of the key count (sizes the split-KV grid; the kernels read the true
 // lengths from d_len).  Every argument is a context pointer or a step-invariant scalar when called for graph capture.
 static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, float* logits, int32_t* next_tokens, hipStream_t s, bool allow_prof) {
@@ -890,22 +930,30 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   TRY(launch_gather_rows(ctx->dt, tokens, ctx->t_embed, nullptr, x, b, H, s));      // embed_tokens
   // weight-only fp8 replica (omchat_enable_fp8_decode): batch-1 steps stream e4m3 bytes + per-row scales
   const bool f8 = ctx->fp8_decode && b == 1 && ctx->tp_size == 1;
+  // batched steps (2 <= b <= 32): the activations that feed a GEMV (tw_xn, tw_ao, tw_act) are produced in the packed x layout
+  // (common.h) by their producers, and the weights come from the packed replica when it exists (ensure_packed)
+  const int pk = (b > 1 && b <= 32 && H % 64 == 0 && qd % 64 == 0 && It % 64 == 0) ? (b > 16 ? 2 : 1) : 0;
+  const bool wpk = pk && ctx->pk_ready;
+  static const omchat_ctx::DecLayerP noneP{};
   auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi,
-                  const void* W8 = nullptr, const float* sc = nullptr) -> int {
+                  const void* W8 = nullptr, const float* sc = nullptr, const void* WP = nullptr, bool ypk = false) -> int {
     for (int r0 = 0; r0 < b; r0 += 32) {
       const int R = std::min(32, b - r0);
       GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
                  resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
       if (f8 && W8) { g.W = W8; g.w_scale = sc; }
+      if (pk) { g.x_packed = 1; g.y_packed = ypk; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
       TRY(launch_gemv(ctx->dt, g, s));
     }
     return 0;
   };
   // split-K over workgroups: fp32 slices [ks][b][H], summed by the fused residual + RMSNorm kernel
-  auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks, const void* W8 = nullptr, const float* sc = nullptr) -> int {
+  auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks, const void* W8 = nullptr, const float* sc = nullptr,
+                          const void* WP = nullptr) -> int {
     OM_CHECK(b <= 32, "split-K decode path handles b <= 32");
     GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
     if (f8 && W8) { g.W = W8; g.w_scale = sc; }
+    if (pk) { g.x_packed = 1; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
     TRY(launch_gemv(ctx->dt, g, s));
     // tensor parallelism: the slices hold this rank's partial sums; they are all-reduced in fp32 (<= 3 x 3584 floats at batch 1,
     // latency-bound like any small message) and the same fused residual + RMSNorm kernel then runs identically on every rank
@@ -919,15 +967,16 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return nch >= 16 ? std::min(DEC_KS_MAX, nch) : std::max(1, std::min(3, nch)); };
   const int ks_o = b == 1 ? ks_rows(qd) : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));
   const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
-  if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
+  if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     static const omchat_ctx::DecLayer8 none8{};
     const omchat_ctx::DecLayer8& Q = f8 ? ctx->dl8[i] : none8;
+    const omchat_ctx::DecLayerP& P = wpk ? ctx->dlp[i] : noneP;
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
-    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv));
+    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
     // RoPE + KV append are fused into the attention kernel (q rotated in registers, the split that owns the new
     // position rotates k and appends k / v)
     AttnDecodeArgs a{};
@@ -939,10 +988,11 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
     a.rope = ctx->rope; a.rope_max = c.max_seq; a.pos = ctx->d_pos;
     a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
+    a.o_pack_nb = fused ? pk : 0;
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
-      TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so));
-      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s));
+      TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -955,12 +1005,12 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     // per token would themselves slow the measured decode by a few per cent
     const bool mark = allow_prof && i == c.t_layers / 2;
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu));
+    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (fused) {
-      TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd));
+      TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd, P.wd));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
-      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s));
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -971,7 +1021,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   }
   if (!fused)   TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
   float* lg = logits ? logits : ctx->tw_logits;
-  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8));
+  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
   if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
@@ -1017,6 +1067,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
   OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
   hipStream_t s = (hipStream_t)stream;
+  if (b > 1 && b <= 32) TRY(ensure_packed(ctx));      // first batched step (or after a weight reload): build the packed replica
   ctx->graph_steps++;
   // graph replay needs replay-invariant arguments: single-GPU fused path only; with profiling on, every 8th step runs eagerly
   // so that the HIP-event brackets of the dominant kernel are still recorded inside the timed region

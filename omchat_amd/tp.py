@@ -194,7 +194,7 @@ def init_peer(rank, size, cap_bytes=64 << 20, fast=False, oneshot_max=0, max_blo
     return peer
 
 
-def peer_selftest(peer, rank, size, iters=64, sizes=(16, 3584 * 4, 3 * 3584 * 4, 1 << 20, 5 << 20)):
+def peer_selftest(peer, rank, size, iters=48, sizes=(16, 3584 * 4, 3 * 3584 * 4, 300 * 1024 + 16, 1 << 20, 1024 * 3200 * 2, 3584 * 3584 * 2 + 32)):
     """Run the peer all-reduce on data whose sum every rank can compute by itself (small integers: exact in fp32, bf16 and f16)
     and compare on the device.  Returns (ok, detail).  Catches stale reads / lost flags on the hardware it runs on."""
     import ctypes as C

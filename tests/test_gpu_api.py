@@ -138,7 +138,7 @@ def test_hf_example_flow_with_only_the_import_changed(tmp_path, gpu_lib):
     from PIL import Image
     from omchat_amd.model.hf import AutoModel, AutoProcessor
     import transformers
-    cfg = tiny()
+    cfg = tiny(vocab=151680)                                  # the ChatML specials 151644 / 151645 (make_context.py:79-80) must be inside the table
     cfg.mm["image_grid_pinpoints"] = [[56, 112], [112, 56], [112, 112]]
     path = save_synthetic_checkpoint(str(tmp_path / "hf"), cfg, 9, "hf")
     model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.float16, max_seq=512, max_tiles=8).cuda().eval()

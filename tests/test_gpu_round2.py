@@ -167,3 +167,77 @@ def test_fp8_replica_follows_a_weight_reload(gpu_lib):
     _, ref = e.decode_step(torch.tensor([7]), want_logits=True); sync()
     assert rel(b, ref) < 0.12                                          # e4m3 weights vs the 16-bit weights of the SAME (new) values
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched decode GEMV with packed operands (gemv.hip: gemv_pk_kernel)
+# ---------------------------------------------------------------------------------------------------------------------
+def _unpack_x(packed, b, K, NB):
+    """inverse of common.h packed_x_index on the host"""
+    p = packed.cpu().view(K // 64, 2, NB, 4, 16, 8)           # [chunk][half][nb][g][row%16][j]
+    x = p.permute(2, 4, 0, 1, 3, 5).reshape(NB * 16, K)       # row = nb*16 + r ; k = chunk*64 + half*32 + g*8 + j
+    return x[:b]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("wp", [0, 1])
+@pytest.mark.parametrize("b,N,K,ks", [(2, 320, 512, 1), (16, 4608, 3584, 1), (17, 320, 576, 2), (32, 3584, 18944, 8), (32, 37888, 3584, 1),
+                                      (24, 160, 64, 1), (5, 3584, 3584, 3), (32, 32768 + 64, 256, 1)])
+def test_gemv_packed_operands(gpu_lib, dt, wp, b, N, K, ks):
+    from test_gpu_ops import _gemm_ref
+    from gpu_util import randn
+    X = rnd(randn((b, K), 1), dt); W = rnd(randn((N, K), 2, 0.03), dt); bias = rnd(randn((N,), 3, 0.1), dt)
+    dX, dW, db = dev(X, dt), dev(W, dt), dev(bias, dt)
+    y = X @ W.t()
+    code = CODE[dt]
+    NB = 2 if b > 16 else 1
+    out = torch.full((b, N), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(out), N, b, N, K, ptr(db), _lib.EPI_NONE, 0, 1, wp, 0, None))
+    sync(); assert rel(out, rnd(y + bias, dt)) < TOL[dt]
+    outf = torch.full((b, N), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(outf), N, b, N, K, None, _lib.EPI_NONE, 1, 1, wp, 0, None))
+    sync(); assert rel(outf, y) < 1e-4
+    part = torch.full((ks, b, N), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(part), N, b, N, K, None, 5, 0, ks, wp, 0, None))
+    sync(); assert torch.isfinite(part).all() and rel(part.sum(0), y) < 1e-4
+    if N % 32 == 0 and (N // 2) % 64 == 0:
+        ref = _gemm_ref(X, W, None, None, None, _lib.EPI_SWIGLU, dt)
+        o3 = torch.full((b, N // 2), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(o3), N // 2, b, N, K, None, _lib.EPI_SWIGLU, 0, 1, wp, 0, None))
+        sync(); assert rel(o3, ref) < TOL[dt]
+        o4 = torch.zeros(NB * 16 * (N // 2), dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(o4), 0, b, N, K, None, _lib.EPI_SWIGLU, 0, 1, wp, 1, None))
+        sync(); assert torch.equal(_unpack_x(o4, b, N // 2, NB), o3.cpu())           # same values, packed for the next GEMV
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("replica", [1, 0])
+def test_batched_decode_packed_path_vs_oracle(gpu_lib, dt, replica):
+    """batched decode steps (b = 3 and b = 20) run on the packed path (packed activations; packed weight replica or the row-major
+    weights): logits against single-sequence steps of the same model (b = 1: whole-row kernels on row-major activations, themselves
+    checked against the oracle in test_gpu_model.py)"""
+    cfg = tiny(q_heads=4, kv_heads=2)
+    sd = synth.state_dict(cfg, 3)
+    gpu_lib.omchat_op_set_tuning(6, replica)
+    try:
+        for b in (3, 20):
+            e = Engine(cfg, dtype=dt, max_seq=64, max_batch=b, max_tiles=1, vision=False)
+            e.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
+            S = 9
+            x = torch.randn(b, S, 256, generator=torch.Generator().manual_seed(b)) * 0.5
+            lens = [S - (i % 4) for i in range(b)]
+            e.prefill(x, lens)
+            toks = torch.arange(b) % 300 + 5
+            nxt, lg = e.decode_step(toks, want_logits=True)
+            nxt2, lg2 = e.decode_step(nxt, want_logits=True); sync()
+            # against single-sequence decode on the same engine (b = 1: whole-row kernels, row-major activations)
+            e1 = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=1, vision=False)
+            e1.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
+            for i in (0, 1, b - 1):
+                e1.prefill(x[i:i + 1, :lens[i]].contiguous(), [lens[i]])
+                _, l1 = e1.decode_step(toks[i:i + 1], want_logits=True)
+                _, l2 = e1.decode_step(nxt[i:i + 1], want_logits=True); sync()
+                assert rel(lg[i], l1[0]) < TOL_DEEP[dt] and rel(lg2[i], l2[0]) < TOL_DEEP[dt], (b, i, rel(lg[i], l1[0]), rel(lg2[i], l2[0]))
+            e.close(); e1.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(6, 1)
