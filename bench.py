@@ -318,7 +318,10 @@ def main():
             guard = max(MARGIN_GUARD[a.dtype], 6.0 * rms)      # a gap difference has sd sqrt(2) x rms: ~4 sd
             want = [int(x) for x in tp1]
             guarded = [i for i in range(len(want)) if float(margin[i]) > guard]
-            tol = 3e-2 if a.dtype == "bf16" else 6e-3          # tests/gpu_util.py TOL_DEEP: several layers, 16-bit rounding
+            # two 16-bit evaluation orders of the full 45 + 28 layer model: measured 4.2e-2 (bf16) for TP = 2 and TP = 4 alike, next to
+            # 3.7e-2 between the prefill and the decode kernels of ONE context (tests/test_gpu_fullsize.py CONSIST_TOL); a sharding
+            # or transport error shows as >= 1e-1 (the two-shot segment bug of round 2 read 2.3e-1).  The tiny geometry keeps TOL_DEEP.
+            tol = ((8e-2 if a.dtype == "bf16" else 1.5e-2) if not a.tiny else (3e-2 if a.dtype == "bf16" else 6e-3))
             tp1_check = {"mode": "teacher-forced on the TP=1 ids", "compared": len(want), "equal": sum(int(g == w) for g, w in zip(got, want)),
                          "guarded": len(guarded), "guarded_equal": sum(int(got[i] == want[i]) for i in guarded), "margin_guard": guard,
                          "logit_rel_err": rel_err, "logit_rms_diff": rms, "logit_tolerance": tol, "min_margin": float(margin.min()),

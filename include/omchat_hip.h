@@ -167,8 +167,7 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * always takes the MFMA form, 0 = batch 1 takes the whole-row streaming form; key 4: row count from which a tensor-parallel
  * row-parallel projection is pipelined against its all-reduce in 2 chunks (3x: 4 chunks), default 1024; key 5: 0 = GEMM tile
  * shapes from the cost model instead of the first-use measurement; key 6: 0 = batched decode steps (2 <= b <= 32) read the
- * row-major weights instead of building the packed replica (+ one more copy of the decoder weights); key 7: 0 = batch-1 decode
- * steps launch the residual add + RMSNorm as its own kernel instead of running it as the prologue of the consuming GEMV) */
+ * row-major weights instead of building the packed replica (+ one more copy of the decoder weights)) */
 int omchat_op_set_tuning(int key, int value);
 size_t omchat_op_gemm_sk_ws(void);
 int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,

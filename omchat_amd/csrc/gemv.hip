@@ -18,7 +18,6 @@ struct GemvP {
   int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
   const float* w_scale;
   int y_packed;
-  const float* pro_part; int pro_ks; const void* pro_x; void* pro_xout; const void* pro_w; float pro_eps;
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
@@ -337,7 +336,6 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 // epilogue.  Split-K slices are chunk ranges of 512 elements, <= RW_MAXC chunks each.
 // ---------------------------------------------------------------------------------------------------------
 int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
-static inline int g_gemv_force_mfma_peek() { return g_gemv_force_mfma; }
 constexpr int RW_MAXC = 8;
 typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -451,7 +449,7 @@ __device__ __forceinline__ void rw_dispatch(int nch, const T* W, int ldw, const 
   }
 }
 
-template <typename T, int EPI, int RR = 4, int WAVES = 4, bool F8 = false, bool PRO = false>
+template <typename T, int EPI, int RR = 4, int WAVES = 4, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   constexpr int R = EPI == EPI_SWIGLU ? 2 * RR : RR;      // SwiGLU: RR (gate, up) row pairs per group
   constexpr int OUT = RR;                                 // outputs per group
@@ -462,60 +460,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   const int c_lo = (int)(((long)nch_all * blockIdx.y) / p.ksplit), c_hi = (int)(((long)nch_all * (blockIdx.y + 1)) / p.ksplit);
   const int nch = c_hi - c_lo, k0 = c_lo * 512;
   rw_u32x4 xr[RW_MAXC];
-  if constexpr (PRO) {
-    // Residual add + RMSNorm of the (single) activation row, recomputed by every workgroup: the separate resid_rmsnorm launch was ONE
-    // workgroup and ~4.8 us of pure latency per call, 56 calls per token.  Same element -> thread assignment, the same per-thread,
-    // wave and workgroup summation orders as resid_rmsnorm_kernel (elementwise.hip): bit-identical x_new, sum of squares and x.
-    typedef typename V8<T>::type v8;
-    __shared__ float xs[RW_MAXC * 512];
-    __shared__ float red[WAVES];
-    const T* xin = (const T*)p.pro_x;
-    float ss = 0.f;
-    for (int k = threadIdx.x * 8; k < p.K; k += WAVES * 64 * 8) {
-      const v8 xi = ld8<T>(xin + k);
-      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int sl = 0; sl < p.pro_ks; ++sl) {
-        const float* pp = p.pro_part + (size_t)sl * p.K + k;
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] += p0[j]; a[4 + j] += p1[j]; }
-      }
-      v8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = p.pro_ks ? rnd<T>(tof(xi[j]) + rnd<T>(a[j])) : tof(xi[j]);
-        xs[k + j] = v; o[j] = fromf<T>(v); ss += v * v;
-      }
-      if (p.pro_xout && blockIdx.x == 0) st8<T>((T*)p.pro_xout + k, o);
-    }
-    ss = wave_sum(ss);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) tot += red[w];
-    const float inv = rsqrtf(tot / (float)p.K + p.pro_eps);
-    const T* nw = (const T*)p.pro_w;
-#pragma unroll
-    for (int c = 0; c < RW_MAXC; ++c) {
-      const int k = c * 512 + lane * 8;
-      rw_u32x4 z = {0u, 0u, 0u, 0u};
-      if (c < nch && k < p.K) {
-        const v8 wv = ld8<T>(nw + k);
-        v8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(xs[k + j] * inv));
-        z = __builtin_bit_cast(rw_u32x4, o);
-      }
-      xr[c] = z;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < RW_MAXC; ++c) {
-      const int k = k0 + c * 512 + lane * 8;
-      rw_u32x4 z = {0u, 0u, 0u, 0u};
-      xr[c] = (c < nch && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
-    }
+  for (int c = 0; c < RW_MAXC; ++c) {
+    const int k = k0 + c * 512 + lane * 8;
+    rw_u32x4 z = {0u, 0u, 0u, 0u};
+    xr[c] = (c < nch && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
   }
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   const int ngroups = (n_out + OUT - 1) / OUT;
@@ -563,20 +512,13 @@ void launch_rows_r(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   int grid = cdiv(cdiv(n_out, RR), 4);
   grid = grid > 2048 ? 2048 : grid;
-  if (p.pro_x) hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8, true>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8, false>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
 }
 // rows per wave-group from tools/tune_rows.hip (MI355X, r01): short outputs (fused qkv) are latency-bound and want the most
 // waves (R = 1: 7.8 vs 8.8 us), everything else is flat in R; 4 waves per workgroup beat 8.  fp8 rows are half as many
 // bytes: the wide lm_head takes 8 rows per group, the split-K shapes measured flat (o_proj slightly worse) and keep 4.
 template <typename T, int EPI>
 void launch_rows(const GemvP& p, hipStream_t s) {
-  // with the prologue every workgroup re-reads the activation row and its fp32 slices from L2 (up to 122 KB): the short fused-qkv
-  // output then takes 4 rows per wave (288 workgroups) instead of 1 (1152)
-  if (p.pro_x && EPI == EPI_NONE && p.N < 32768) {
-    if (p.w_scale) launch_rows_r<T, EPI, 4, true>(p, s); else launch_rows_r<T, EPI, 4, false>(p, s);
-    return;
-  }
   if (p.w_scale) {
     if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1, true>(p, s);
     else if (EPI == EPI_NONE) launch_rows_r<T, EPI, 8, true>(p, s);      // lm_head: 80.7 vs 82.3 us
@@ -592,8 +534,7 @@ void launch_rows(const GemvP& p, hipStream_t s) {
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed,
-          a.pro ? a.pro_part : nullptr, a.pro ? a.pro_ks : 0, a.pro ? a.pro_x : nullptr, a.pro ? a.pro_xout : nullptr, a.pro ? a.pro_w : nullptr, a.pro_eps};
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed};
   if (a.x_packed) {
     // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
 #define OM_PK(NT_, EPI_, WV_, UN_)                                                                                                  \
@@ -726,9 +667,6 @@ int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(!a.x_packed || (!a.w_scale && a.epi != EPI_RESID), "packed x: 16-bit weights, epilogue NONE / SWIGLU / PARTIAL");
   OM_CHECK(!a.w_packed || (a.x_packed && a.N % 16 == 0), "packed W needs packed x and N % 16 == 0");
   OM_CHECK(!a.y_packed || (a.x_packed && a.epi == EPI_SWIGLU), "packed y: SwiGLU epilogue of the packed kernel only");
-  OM_CHECK(!a.pro || (a.b == 1 && a.ksplit <= 1 && a.K <= RW_MAXC * 512 && a.K % 8 == 0 && a.pro_x && a.pro_w && a.pro_x != a.pro_xout &&
-                      a.pro_ks >= 0 && a.pro_ks <= 8 && (a.pro_ks == 0 || a.pro_part) && !a.x_packed && !a.force_mfma && !g_gemv_force_mfma_peek()),
-           "fused residual + RMSNorm prologue: b == 1 whole-row form, ksplit <= 1, K <= 4096, K % 8, distinct in / out buffers");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");
   OM_CHECK(!a.w_scale || a.b == 1, "fp8 weights: batch 1 only");
   OM_CHECK(a.epi == EPI_NONE || a.epi == EPI_RESID || a.epi == EPI_SWIGLU || a.epi == EPI_PARTIAL, "bad epilogue");

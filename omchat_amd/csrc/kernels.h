@@ -50,14 +50,6 @@ struct GemvArgs {
   int x_packed;             // X is packed with NB = b > 16 ? 2 : 1 (ldx ignored)
   int w_packed;             // W is the packed replica (ldw ignored); needs x_packed
   int y_packed;             // EPI_SWIGLU only: write Y in the packed x layout of the consumer (same NB; ldy ignored)
-  // b == 1 whole-row form only: residual add + RMSNorm as the PROLOGUE of the GEMV that consumes them (instead of the separate
-  // single-workgroup resid_rmsnorm launch): x_new = T(pro_x + T(sum_s pro_part[s])) (fixed order), optionally stored to pro_xout
-  // by workgroup 0, and the GEMV's x = T(pro_w * T(x_new * rsqrt(mean(x_new^2) + eps))).  Every workgroup recomputes the row
-  // (K <= 4096, ksplit <= 1); bit-identical to launch_resid_rmsnorm + launch_gemv.  X is ignored.
-  int pro;
-  const float* pro_part; int pro_ks;      // fp32 slices [pro_ks][K] (pro_ks may be 0)
-  const void* pro_x; void* pro_xout;      // residual stream in / out (different buffers; pro_xout may be null)
-  const void* pro_w; float pro_eps;       // RMSNorm weight, eps
 };
 // row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
@@ -70,7 +62,6 @@ void gemv_set_force_mfma(int v);
 void gemm_set_autotune(int v);
 void model_set_ar_min_rows(int v);
 void model_set_pack_replica(int v);
-void model_set_decode_prologue(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)

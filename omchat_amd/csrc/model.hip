@@ -503,8 +503,6 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
-int g_decode_prologue = 1;    // omchat_op_set_tuning key 7: 0 = separate resid_rmsnorm launches at batch 1 (A/B, bit-equality test)
-void model_set_decode_prologue(int v) { g_decode_prologue = v; }
 int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
 void model_set_pack_replica(int v) { g_pack_replica = v; }
 int g_ar_min_rows = 1024;      // rows from which a projection is pipelined in 2 (x3: 4) chunks; tests lower it (omchat_op_set_tuning key 4)
@@ -937,23 +935,15 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   const int pk = (b > 1 && b <= 32 && H % 64 == 0 && qd % 64 == 0 && It % 64 == 0) ? (b > 16 ? 2 : 1) : 0;
   const bool wpk = pk && ctx->pk_ready;
   static const omchat_ctx::DecLayerP noneP{};
-  // batch 1: the residual add + RMSNorm that precedes a GEMV runs as that GEMV's prologue (gemv.hip, GemvArgs::pro): 6 launches per
-  // layer instead of 8, the residual stream ping-pongs between x and y
-  const bool pro = g_decode_prologue && b == 1 && H <= 4096 && H % 8 == 0;
-  struct Pro { int ks; const void* w; bool last; };
   auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi,
-                  const void* W8 = nullptr, const float* sc = nullptr, const void* WP = nullptr, bool ypk = false, const Pro* pr = nullptr) -> int {
+                  const void* W8 = nullptr, const float* sc = nullptr, const void* WP = nullptr, bool ypk = false) -> int {
     for (int r0 = 0; r0 < b; r0 += 32) {
       const int R = std::min(32, b - r0);
       GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
                  resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
       if (f8 && W8) { g.W = W8; g.w_scale = sc; }
       if (pk) { g.x_packed = 1; g.y_packed = ypk; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
-      if (pr) {
-        g.pro = 1; g.pro_part = ctx->tw_part; g.pro_ks = pr->ks; g.pro_x = x; g.pro_xout = pr->last ? nullptr : y; g.pro_w = pr->w; g.pro_eps = c.t_eps;
-      }
       TRY(launch_gemv(ctx->dt, g, s));
-      if (pr && !pr->last) std::swap(x, y);
     }
     return 0;
   };
@@ -977,7 +967,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return nch >= 16 ? std::min(DEC_KS_MAX, nch) : std::max(1, std::min(3, nch)); };
   const int ks_o = b == 1 ? ks_rows(qd) : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));
   const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
-  if (fused && !pro) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+  if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     static const omchat_ctx::DecLayer8 none8{};
@@ -986,12 +976,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
-    if (pro) {      // input norm of this layer (+ the previous layer's down_proj slices and residual) inside the qkv GEMV
-      const Pro pr{i == 0 ? 0 : ks_d, L.ln1, false};
-      TRY(gemv(nullptr, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, nullptr, false, &pr));
-    } else {
-      TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
-    }
+    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
     // RoPE + KV append are fused into the attention kernel (q rotated in registers, the split that owns the new
     // position rotates k and appends k / v)
     AttnDecodeArgs a{};
@@ -1007,7 +992,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
-      if (!pro) TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -1020,17 +1005,12 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     // per token would themselves slow the measured decode by a few per cent
     const bool mark = allow_prof && i == c.t_layers / 2;
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    if (pro) {      // o_proj slices + residual + post-attention norm inside the gate|up GEMV
-      const Pro pr{ks_o, L.ln2, false};
-      TRY(gemv(nullptr, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, nullptr, false, &pr));
-    } else {
-      TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
-    }
+    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (fused) {
       TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd, P.wd));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
-      if (!pro) TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -1041,14 +1021,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   }
   if (!fused)   TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
   float* lg = logits ? logits : ctx->tw_logits;
-  if (pro) {        // last down_proj slices + residual + final norm inside the lm_head GEMV
-    GemvArgs g{nullptr, H, f8 ? ctx->t_lm8 : ctx->t_lm, H, lg, c.t_vocab, 1, c.t_vocab, H, nullptr, nullptr, 0, EPI_NONE, 1};
-    if (f8) g.w_scale = ctx->t_lm8_s;
-    g.pro = 1; g.pro_part = ctx->tw_part; g.pro_ks = ks_d; g.pro_x = x; g.pro_xout = nullptr; g.pro_w = ctx->t_norm; g.pro_eps = c.t_eps;
-    TRY(launch_gemv(ctx->dt, g, s));
-  } else {
-    TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
-  }
+  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
   if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();

@@ -241,34 +241,3 @@ def test_batched_decode_packed_path_vs_oracle(gpu_lib, dt, replica):
             e.close(); e1.close()
     finally:
         gpu_lib.omchat_op_set_tuning(6, 1)
-
-
-@pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("fp8", [False, True])
-def test_batch1_decode_prologue_fusion_is_bit_identical(gpu_lib, dt, fp8):
-    """residual add + RMSNorm as the prologue of the consuming GEMV (6 launches per layer) vs the separate resid_rmsnorm launches
-    (8 per layer): same element/thread assignment and summation orders, so logits and ids are identical bit for bit"""
-    cfg = tiny(q_heads=4, kv_heads=2, layers_t=3)
-    sd = {k: v for k, v in synth.state_dict(cfg, 17).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
-    x = torch.randn(1, 21, 256, generator=torch.Generator().manual_seed(2)) * 0.5
-    runs = []
-    try:
-        for mode in (1, 0):
-            gpu_lib.omchat_op_set_tuning(7, mode)
-            e = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=1, vision=False)
-            e.load_state_dict(sd)
-            if fp8:
-                e.enable_fp8_decode(True)
-            lg0, _ = e.prefill(x)
-            tok = e.argmax(lg0)
-            out = []
-            for _ in range(5):
-                tok, lg = e.decode_step(tok, want_logits=True)
-                out.append((int(tok[0]), lg.clone()))
-            sync()
-            runs.append(out)
-            e.close()
-    finally:
-        gpu_lib.omchat_op_set_tuning(7, 1)
-    for (ta, la), (tb, lb) in zip(*runs):
-        assert ta == tb and torch.equal(la, lb)
