@@ -142,6 +142,16 @@ int omchat_decode_graph_stats(omchat_ctx* ctx, long* steps, long* replays, long*
  * path): parity is against the oracle run on the de-quantised weights. */
 int omchat_enable_fp8_decode(omchat_ctx* ctx, int on);
 
+/* ---- fp8 KV cache and fp8 x fp8 prefill GEMMs (BASELINE configs[4]: long video context, "fp8 MFMA weights") ------ */
+/* omchat_enable_fp8_kv: after the next prefill the decode steps read keys and values as OCP e4m3 bytes (57 344 -> 28 672 bytes per
+ * cached token, + 2 x 4 kv heads x 28 layers fp32 scales) with one scale per (layer, sequence, kv head, position) = absmax / 448; the
+ * token being decoded is rotated, appended and quantised before its attention.  The 16-bit cache stays (prefill attention reads it).
+ * omchat_enable_fp8_prefill: the qkv and gate|up GEMMs of the prefill run as fp8 x fp8 MFMA: activations quantised per token by the
+ * RMSNorm kernel, weights from the e4m3 replica (per output row); o_proj / down_proj keep 16-bit operands.
+ * Neither is part of the reference: parity is stated against the oracle on de-quantised operands (tests/test_gpu_fp8.py). */
+int omchat_enable_fp8_kv(omchat_ctx* ctx, int on);
+int omchat_enable_fp8_prefill(omchat_ctx* ctx, int on);
+
 /* ---- measurement: HIP-event timing of the dominant kernel classes, recorded on the launch stream ------------------ */
 #define OMCHAT_PROF_DECODE_GATEUP 0   /* decode gate|up weight-streaming GEMV (+SwiGLU), one launch per layer per token */
 #define OMCHAT_PROF_PREFILL_GATEUP 1  /* decoder prefill gate|up MFMA GEMM (+SwiGLU), one launch per layer */
@@ -169,6 +179,11 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * shapes from the cost model instead of the first-use measurement; key 6: 0 = batched decode steps (2 <= b <= 32) read the
  * row-major weights instead of building the packed replica (+ one more copy of the decoder weights)) */
 int omchat_op_set_tuning(int key, int value);
+/* GEMM tile choices are measured on first use of a (dtype, epilogue, ceil(M/256), N, K) class; load / dump persist them as text
+ * (returns the number of entries, -1 when the file cannot be opened); omchat_gemm_tune_runs = measurements done by this process */
+int omchat_gemm_tune_load(const char* path);
+int omchat_gemm_tune_dump(const char* path);
+long omchat_gemm_tune_runs(void);
 size_t omchat_op_gemm_sk_ws(void);
 int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                       const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* ws,
@@ -181,6 +196,12 @@ int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, vo
 int omchat_op_gemv_packed(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
                           const void* bias, int epi, int out_f32, int ksplit, int w_packed, int y_packed, void* stream);
 int omchat_op_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, void* stream);
+/* fp8 x fp8 MFMA GEMM (BASELINE configs[4] "fp8 MFMA weights"): A8 [M, K] and W8 [N, K] are OCP e4m3 bytes with one fp32 scale per row;
+ * C (dtype) = epi(a_scale[m] * w_scale[n] * A8 W8^T), epilogues as omchat_op_gemm (ls unused).  K % 128 == 0.
+ * omchat_op_quant_rows_fp8: per-row (per token) quantisation of activations, optionally behind an RMSNorm (norm_w != NULL). */
+int omchat_op_gemm_fp8(int dtype, const void* A8, const float* a_scale, const void* W8, const float* w_scale, void* C, int ldc, int M, int N,
+                       int K, const void* bias, const void* resid, int ldr, int epi, void* stream);
+int omchat_op_quant_rows_fp8(int dtype, const void* x, const void* norm_w, float eps, void* y8, float* scale, int rows, int H, void* stream);
 /* fp8 pieces: W [N][K] (dtype) -> W8 [N][K] e4m3 bytes + scale [N]; y[N] = (W8 . x) * scale (+ epilogue), batch 1;
  * epi EPI_PARTIAL writes fp32 slices [ksplit][N] */
 int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float* scale, void* stream);

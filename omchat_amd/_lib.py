@@ -56,12 +56,19 @@ _SIGS = {
     "omchat_mha_fwd_varlen": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _i, _vp]),
     "omchat_op_gemm": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_set_tuning": (_i, [_i, _i]),
+    "omchat_gemm_tune_load": (_i, [C.c_char_p]),
+    "omchat_gemm_tune_dump": (_i, [C.c_char_p]),
+    "omchat_gemm_tune_runs": (C.c_long, []),
     "omchat_op_gemm_sk_ws": (_sz, []),
     "omchat_op_gemm_sk": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
     "omchat_op_gemv": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_gemv_packed": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "omchat_op_pack_x": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "omchat_op_gemm_fp8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "omchat_op_quant_rows_fp8": (_i, [_i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
     "omchat_enable_fp8_decode": (_i, [_vp, _i]),
+    "omchat_enable_fp8_kv": (_i, [_vp, _i]),
+    "omchat_enable_fp8_prefill": (_i, [_vp, _i]),
     "omchat_enable_decode_graph": (_i, [_vp, _i]),
     "omchat_decode_graph_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "omchat_op_quant_fp8": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
@@ -116,6 +123,10 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        # measured GEMM tile choices for the OmChat-13B shapes (TP 1 / 2 / 4 / 8) on MI355X: no first-use tuning on known shapes
+        tune = os.environ.get("OMCHAT_GEMM_TUNE_FILE") or os.path.join(HERE, "gemm_tune_gfx950.txt")
+        if os.path.exists(tune):
+            l.omchat_gemm_tune_load(tune.encode())
         _lib = l
     return _lib
 

@@ -36,7 +36,23 @@ struct AttnP {
   const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v rows, batch stride (elements); head stride 128
   void* k_cache_w; void* v_cache_w;                          // writable views of K / V (same strides as K / V)
   int rope_max;
+  const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;      // fp8 KV cache (decode only)
 };
+
+// 8 e4m3 bytes -> 8 T (exact widening)
+template <typename T> __device__ __forceinline__ typename V8<T>::type widen8(u32x2 w);
+template <> __device__ __forceinline__ bf16x8 widen8<bf16>(u32x2 w) {
+  typedef bf16 v2 __attribute__((ext_vector_type(2)));
+  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, true);
+  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, true);
+  return (bf16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+template <> __device__ __forceinline__ f16x8 widen8<f16>(u32x2 w) {
+  typedef f16 v2 __attribute__((ext_vector_type(2)));
+  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, true);
+  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, true);
+  return (f16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
 
 // RoPE of one 8-element chunk (rotate-half, modeling_qwen2.py:105-135) with the reference's rounding (N11):
 // x = own chunk, o = partner chunk 64 elements away, first half gets -partner*sin, second half +partner*sin
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 // rotates q in registers and, in the split that owns the new position, rotates k and appends k / v to the cache
 // (replaces the separate RoPE + KV-append launch for S = 1).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool KV8 = false>
 __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   __shared__ __attribute__((aligned(256))) char Vs[KV_TILE * 256];
@@ -369,17 +385,41 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
   for (int kt = 0; kt < 4; ++kt) {
     const int key = key0 + kt * 16 + fc;
     kfresh[kt] = fuse && key >= pp;           // not in the cache yet (or clamped onto it)
-    const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+    if constexpr (KV8) {                      // e4m3 cache bytes, widened exactly; the per-key scale multiplies the score below
+      const unsigned char* src = (const unsigned char*)p.K + b * p.k_sb + kvh * p.k_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = widen8<T>(*reinterpret_cast<const u32x2*>(src + ds * 32 + fg * 8));
+    } else {
+      const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
+    }
   }
   frag_t vreg[16];                            // V^T image source: chunk idx = i*64 + lane -> row = 4*i + fg, ch = fc
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int key = key0 + i * 4 + fg;
     const bool fresh = fuse && key >= pp;
-    const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
-    vreg[i] = ld8<T>(src + fc * 8);
+    if constexpr (KV8) {
+      const unsigned char* src = (const unsigned char*)p.V + b * p.v_sb + kvh * p.v_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+      vreg[i] = widen8<T>(*reinterpret_cast<const u32x2*>(src + fc * 8));
+    } else {
+      const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+      vreg[i] = ld8<T>(src + fc * 8);
+    }
+  }
+  // fp8 cache: scales of the keys this lane's score registers hold (key0 + 16 kt + 4 fg + r), clamped like the rows
+  f32x4 ksc[4], vsc[4];
+  if constexpr (KV8) {
+    const float* ksp = p.k_scale + b * p.scale_sb + kvh * p.scale_sh;
+    const float* vsp = p.v_scale + b * p.scale_sb + kvh * p.scale_sh;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + 4 * fg + r, kc = key < kv_len ? key : kv_len - 1;
+        ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
+      }
   }
   frag_t qf[4];
   {
@@ -428,7 +468,9 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? s[kt][r] : NEG_BIG;
+      float sv = s[kt][r];
+      if constexpr (KV8) sv *= ksc[kt][r];
+      const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? sv : NEG_BIG;
       s[kt][r] = v;
       mx = fmaxf(mx, v);
     }
@@ -444,6 +486,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
     for (int j = 0; j < 8; ++j) {
       e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
       psum += e[j];
+      if constexpr (KV8) e[j] *= vsc[2 * ks + (j >> 2)][j & 3];      // V = scale * e4m3: fold the per-key scale into P
     }
     pf[ks] = __builtin_convertvector(e, frag_t);
   }
@@ -538,7 +581,46 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
   O[pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d)] = fromf<T>(acc / ltot);
 }
 
+// fp8 KV cache: one wave per cache row (128 elements): s = absmax / 448 (1 for a zero row), bytes = e4m3_rne(x / s)
+template <typename T>
+__global__ __launch_bounds__(256) void kv_quant_kernel(const T* kc, const T* vc, unsigned char* k8, unsigned char* v8, float* ks, float* vs, int kv_heads,
+                                                       int64_t c_sb, int64_t c_sh, int64_t s_sb, int64_t s_sh, const int* pos_lo, int pos0, const int* len,
+                                                       int max_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;                        // row index inside [pos_lo, ...) of this (sequence, head)
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lo = pos_lo ? pos_lo[b] : pos0;
+  const int pos = lo + r;
+  if (r >= max_rows || (len && pos >= len[b])) return;        // wave-uniform
+  const int64_t off = b * c_sb + h * c_sh + (int64_t)pos * 128 + lane * 2;
+  const int64_t soff = b * s_sb + h * s_sh + pos;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const T* src = (which ? vc : kc) + off;
+    const float x0 = tof(src[0]), x1 = tof(src[1]);
+    float m = fmaxf(fabsf(x0), fabsf(x1));
+    m = wave_max(m);
+    const float sc = m > 0.f ? m / 448.0f : 1.0f;
+    const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x0 / sc, x1 / sc, 0, false);
+    *reinterpret_cast<unsigned short*>((which ? v8 : k8) + off) = (unsigned short)(pk & 0xFFFF);
+    if (lane == 0) (which ? vs : ks)[soff] = sc;
+  }
+}
+
 }  // namespace
+
+int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v8, float* ks, float* vs, int b, int kv_heads, int64_t c_sb, int64_t c_sh,
+                    int64_t s_sb, int64_t s_sh, const int* pos_lo, int pos0, const int* len, int max_rows, hipStream_t s) {
+  if (b <= 0 || max_rows <= 0) return 0;
+  dim3 grid(cdiv(max_rows, 4), kv_heads, b);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(kv_quant_kernel<f16>, grid, dim3(256), 0, s, (const f16*)kc, (const f16*)vc, (unsigned char*)k8, (unsigned char*)v8,
+                                              ks, vs, kv_heads, c_sb, c_sh, s_sb, s_sh, pos_lo, pos0, len, max_rows);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(kv_quant_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)kc, (const bf16*)vc, (unsigned char*)k8,
+                                                    (unsigned char*)v8, ks, vs, kv_heads, c_sb, c_sh, s_sb, s_sh, pos_lo, pos0, len, max_rows);
+  else { omchat_set_error("launch_kv_quant: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.q_heads % a.kv_heads == 0, "q_heads must be a multiple of kv_heads");
@@ -546,7 +628,7 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.q_sr % 8 == 0 && a.k_sr % 8 == 0 && a.v_sr % 8 == 0 && a.o_sr % 4 == 0, "row strides must keep 16-B alignment");
   AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
           a.kv_len, a.kv_start, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
-          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
+          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
@@ -575,16 +657,20 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
-          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max};
+          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh};
+  const bool kv8 = a.k_scale != nullptr;
+  OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
   OM_CHECK(!a.rope || (a.pos && a.k_new && a.v_new && a.kv_len), "fused RoPE decode needs pos, k_new, v_new and kv_len");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
-    hipLaunchKernelGGL(attn_decode_kernel<f16>, grid, dim3(64), 0, s, p);
+    if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
   } else if (dtype == OMCHAT_BF16) {
-    hipLaunchKernelGGL(attn_decode_kernel<bf16>, grid, dim3(64), 0, s, p);
+    if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();

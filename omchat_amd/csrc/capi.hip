@@ -22,6 +22,10 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   return 1;
 }
 
+extern "C" int omchat_gemm_tune_load(const char* path) { OM_CHECK(path, "null path"); return gemm_tune_load(path); }
+extern "C" int omchat_gemm_tune_dump(const char* path) { OM_CHECK(path, "null path"); return gemm_tune_dump(path); }
+extern "C" long omchat_gemm_tune_runs(void) { return gemm_tune_runs(); }
+
 extern "C" size_t omchat_op_gemm_sk_ws(void) { return gemm_sk_ws_bytes(); }
 
 extern "C" int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -59,6 +63,18 @@ extern "C" int omchat_op_gemv_packed(int dtype, const void* X, int ldx, const vo
   return rc;
 }
 extern "C" int omchat_op_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, void* stream) { return launch_pack_x(dtype, X, ldx, b, K, out, S(stream)); }
+
+// fp8 x fp8 GEMM (BASELINE configs[4]): A8 [M, K], W8 [N, K] e4m3 bytes with per-row fp32 scales -> C (dtype) = epi(sa[m] sw[n] A8 W8^T)
+extern "C" int omchat_op_gemm_fp8(int dtype, const void* A8, const float* a_scale, const void* W8, const float* w_scale, void* C, int ldc, int M,
+                                  int N, int K, const void* bias, const void* resid, int ldr, int epi, void* stream) {
+  GemmArgs g{A8, K, W8, K, C, ldc, M, N, K, bias, nullptr, resid, ldr, epi, 0, nullptr, 0, -1, 1, a_scale, w_scale};
+  return launch_gemm(dtype, g, S(stream));
+}
+// per-row e4m3 quantisation of activations [rows, H]: norm_w != NULL applies the RMSNorm first (launch_rmsnorm_q8)
+extern "C" int omchat_op_quant_rows_fp8(int dtype, const void* x, const void* norm_w, float eps, void* y8, float* scale, int rows, int H, void* stream) {
+  if (norm_w) return launch_rmsnorm_q8(dtype, x, H, norm_w, y8, H, scale, rows, H, eps, S(stream));
+  return launch_quant_rows_q8(dtype, x, H, y8, H, scale, rows, H, S(stream));
+}
 
 extern "C" int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream) {
   return launch_rmsnorm(dtype, x, H, w, y, H, rows, H, eps, S(stream));

@@ -58,6 +58,85 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fp8 x fp8 prefill (BASELINE configs[4]): the activation operand of the GEMM is e4m3 with one scale per token (row).
+//   NORM: y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (the reference's RMSNorm, same roundings), then s = absmax(y) / 448 (1 for a zero row),
+//         y8 = e4m3_rne(y / s).      !NORM: plain per-row quantisation of x.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NORM_THREADS / 64; ++w) t = fmaxf(t, red[w]);
+  __syncthreads();
+  return t;
+}
+
+template <typename T, bool NORM>
+__global__ __launch_bounds__(NORM_THREADS) void rows_q8_kernel(const T* x, int ldx, const T* w, unsigned char* y8, int ldy, float* scale, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  const T* xr = x + (size_t)row * ldx;
+  const int nchunk = H >> 3;
+  float xv[NORM_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 v = ld8<T>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xv[i][j] = tof(v[j]); ss += xv[i][j] * xv[i][j]; }
+    }
+  }
+  float amax = 0.f;
+  if constexpr (NORM) {
+    const float inv = rsqrtf(block_sum(ss, red) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+        const v8 wv = ld8<T>(w + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[i][j] = rnd<T>(tof(wv[j]) * rnd<T>(xv[i][j] * inv)); amax = fmaxf(amax, fabsf(xv[i][j])); }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(xv[i][j]));
+      }
+    }
+  }
+  amax = block_max(amax, red);
+  const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+  if (threadIdx.x == 0) scale[row] = sc;
+  unsigned char* yr = y8 + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = xv[i][j] / sc;
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      u32x2 o2 = {(unsigned)lo, (unsigned)hi};
+      *reinterpret_cast<u32x2*>(yr + c * 8) = o2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LayerNorm (InternViT-300M: NORM2FN['layer_norm'] = nn.LayerNorm, intern_vit_300m/modeling_intern_vit.py:61-64,209-210):
 // fp32 mean / biased variance over the row, y = T((x - mean) * rsqrt(var + eps) * w + b)   (one rounding, as ATen)
 // ---------------------------------------------------------------------------------------------------------
@@ -429,6 +508,22 @@ int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, in
   OM_CHECK(pack_nb == 0 || (rows <= 16 * pack_nb && H % 64 == 0 && x != y), "packed output: rows <= 16 * NB, H % 64 == 0, not in place");
   if (rows == 0) return 0;
   DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, H, eps, pack_nb));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rmsnorm_q8(int dtype, const void* x, int ldx, const void* w, void* y8, int ldy, float* scale, int rows, int H, float eps, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL((rows_q8_kernel<T, true>), dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (unsigned char*)y8, ldy, scale, H, eps));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_quant_rows_q8(int dtype, const void* x, int ldx, void* y8, int ldy, float* scale, int rows, int H, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL((rows_q8_kernel<T, false>), dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)nullptr, (unsigned char*)y8, ldy, scale, H, 0.f));
   OM_LAUNCH_CHECK();
   return 0;
 }

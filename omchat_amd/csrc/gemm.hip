@@ -23,6 +23,7 @@ namespace {
 struct GemmP {
   const void* A; const void* W; void* C; const void* bias; const void* ls; const void* resid;
   int lda, ldw, ldc, ldr, M, N, K;
+  const float* a_scale; const float* w_scale;      // fp8 x fp8 kernel: per-row scales of A and W (null otherwise)
 };
 
 // Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
@@ -65,6 +66,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
   const int rowu = __builtin_amdgcn_readfirstlane(rowu_), colu = __builtin_amdgcn_readfirstlane(colu_);      // SGPRs: scalar offsets, scalar resources
   const int rows_valid = p.M - rowu < MR * 16 ? p.M - rowu : MR * 16;
   if (rows_valid <= 0) return;                                                   // wave-uniform
+  if (p.a_scale) {          // fp8 x fp8 operands: the accumulators are sums of unscaled e4m3 products (wave-uniform branch)
+    float sw[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { const int col = colu + j * 16 + fr; sw[j] = p.w_scale[col < p.N ? col : p.N - 1]; }
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowu + i * 16 + fg * 4 + r;
+        const float sa = p.a_scale[row < p.M ? row : p.M - 1];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j][r] *= sa * sw[j];
+      }
+  }
   const T* __restrict__ bias = (const T*)p.bias;
   // byte ranges of the wave tile's rows (< 2^32: at most 128 rows of one matrix row stride each)
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((T*)p.C + (size_t)rowu * p.ldc, 0, rows_valid * p.ldc * 2, 0x00020000);
@@ -240,22 +255,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
 // ---------------------------------------------------------------------------------------------------------
 // K-tiles [kt0, kt1) of the 256x256 tile at (m0, n0), accumulated into acc (zeroed here).  All 512 threads call it
 // together; on return every wave has passed the same number of barriers and no LDS read is outstanding.
-template <typename T>
+// one 16-byte operand fragment pair -> accumulator: 8 16-bit elements (one 16x16x32 MFMA) or 16 e4m3 bytes (two 16x16x32 fp8 MFMAs: the
+// lane's bytes 0-7 and 8-15 are two K slots; A and B use the same assignment, so the K order inside a 128-byte row is immaterial)
+template <typename T, bool F8>
+__device__ __forceinline__ f32x4 mma_frag(typename V8<T>::type a, typename V8<T>::type b, f32x4 c) {
+  if constexpr (F8) {
+    typedef long l2 __attribute__((ext_vector_type(2)));
+    const l2 a2 = __builtin_bit_cast(l2, a), b2 = __builtin_bit_cast(l2, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[0], b2[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[1], b2[1], c, 0, 0, 0);
+  } else {
+    return mfma16(a, b, c);
+  }
+}
+
+template <typename T, bool F8 = false>
 __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, int kt0, int kt1, char* smem, f32x4 (&acc)[8][4]) {
   constexpr int SLOT = 128 * 128;                 // 128 rows x 128 B
   constexpr int STAGE = 4 * SLOT;                 // A_0, A_1, B_0, B_1
+  constexpr int ES = F8 ? 1 : 2;                  // bytes per operand element: a 128-byte row holds 128 / ES elements of K
   typedef typename V8<T>::type frag_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
+  const char* __restrict__ A = (const char*)p.A;
+  const char* __restrict__ W = (const char*)p.W;
 
-  // staging sources: slot piece lin = i*512 + tid -> slot row rho = lin >> 3, physical chunk pc = lin & 7
-  const T* a_src[2][2];     // [mh][round]
-  const T* b_src[2][2];     // [nh][round]
+  // staging sources (byte pointers): slot piece lin = i*512 + tid -> slot row rho = lin >> 3, physical chunk pc = lin & 7
+  const char* a_src[2][2];     // [mh][round]
+  const char* b_src[2][2];     // [nh][round]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lin = i * 512 + tid, rho = lin >> 3, pc = lin & 7;
@@ -263,17 +293,17 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int gr = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63); gr = gr < p.M ? gr : p.M - 1;
-      a_src[h][i] = A + (size_t)gr * p.lda + c * 8;
+      a_src[h][i] = A + (size_t)gr * p.lda * ES + c * 16;
       int gc = n0 + (rho >> 5) * 64 + h * 32 + (rho & 31); gc = gc < p.N ? gc : p.N - 1;
-      b_src[h][i] = W + (size_t)gc * p.ldw + c * 8;
+      b_src[h][i] = W + (size_t)gc * p.ldw * ES + c * 16;
     }
   }
   // slot order inside a stage: 0 = A_0, 1 = A_1, 2 = B_0, 3 = B_1
-  auto issue = [&](int buf, int slot, const T* const (&src)[2], int kt) {
+  auto issue = [&](int buf, int slot, const char* const (&src)[2], int kt) {
     char* base = smem + buf * STAGE + slot * SLOT;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (kt0 + kt) * 64), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (size_t)(kt0 + kt) * 128), (lptr_t)(base + (i * 512 + wave * 64) * 16), 16, 0, 0);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -329,7 +359,7 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   __builtin_amdgcn_s_setprio(1);                                                                                   \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-          acc[(MH) * 4 + i][(NH) * 2 + j] = mfma16(af[i][s], BF[j][s], acc[(MH) * 4 + i][(NH) * 2 + j]);           \
+          acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag<T, F8>(af[i][s], BF[j][s], acc[(MH) * 4 + i][(NH) * 2 + j]);  \
   __builtin_amdgcn_s_setprio(0);                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_barrier();                                                                                    \
@@ -359,7 +389,7 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
 }
 
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   int m0, n0;
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
     for (int i = 0; i < d * skew; ++i) __builtin_amdgcn_s_sleep(16);
   }
   f32x4 acc[8][4];
-  gemm8_segment<T>(p, m0, n0, 0, p.K / 64, smem, acc);
+  gemm8_segment<T, F8>(p, m0, n0, 0, p.K / (F8 ? 128 : 64), smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
   gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
@@ -488,7 +518,7 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   const int KT = a.K / 64;
   const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
@@ -512,6 +542,21 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   return 0;
 }
 
+template <typename T, int EPI>
+int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
+  constexpr int LDS = 2 * 4 * 128 * 128;
+  auto kern = gemm8_kernel<T, EPI, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale};
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), LDS, stream, p, 0);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -521,7 +566,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr};
   const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
   OM_LAUNCH_CHECK();
@@ -598,6 +643,35 @@ void gemm_set_autotune(int v) { g_autotune = v; }
 
 static std::mutex g_tune_mu;
 static std::map<std::array<int, 5>, int> g_tuned;
+static long g_tune_runs = 0;      // first-use measurements performed by this process (0 when every shape came from the cache file)
+
+// Persisted winners (first-use tuning must not run inside a timed or multi-rank region, and costs a live request
+// 5 candidates x 4 launches + 384 MB flushes): one line per problem class "dtype*8+epi  ceil(M/256)  N  K  ldc  tile".
+// omchat_amd/gemm_tune_gfx950.txt (measured on MI355X, committed) is loaded by the Python binding when the library is loaded;
+// classes it does not cover are still measured on first use and can be appended with omchat_gemm_tune_dump.
+int gemm_tune_load(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  int n = 0, a, b, c, d, e, t;
+  char line[256];
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '#') continue;
+    if (sscanf(line, "%d %d %d %d %d %d", &a, &b, &c, &d, &e, &t) == 6 && t >= 1 && t <= 9) { g_tuned[{a, b, c, d, e}] = t; ++n; }
+  }
+  fclose(f);
+  return n;
+}
+int gemm_tune_dump(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return -1;
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  fprintf(f, "# omchat_amd GEMM tile choices measured on this device: dtype*8+epi ceil(M/256) N K ldc tile\n");
+  for (auto& kv : g_tuned) fprintf(f, "%d %d %d %d %d %d\n", kv.first[0], kv.first[1], kv.first[2], kv.first[3], kv.first[4], kv.second);
+  fclose(f);
+  return (int)g_tuned.size();
+}
+long gemm_tune_runs() { return g_tune_runs; }
 
 static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   const std::array<int, 5> key{dtype * 8 + a.epi, cdiv(a.M, 256), a.N, a.K, a.ldc};
@@ -621,6 +695,7 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   if (hipMalloc(&flush, FLUSH_BYTES) != hipSuccess) { (void)hipGetLastError(); flush = nullptr; }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  ++g_tune_runs;
   int cands[5] = {2, 8, 9, 7, 3};
   int best = heuristic;
   float best_ms = 1e30f;
@@ -657,8 +732,30 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
 }
 size_t gemm_sk_ws_bytes() { return (size_t)SK_MAX_WG * SK_SLAB_BYTES + 4096; }
 
+template <typename T>
+static int launch_f8_t(const GemmArgs& a, hipStream_t stream) {
+  switch (a.epi) {
+    case EPI_NONE: return launch_cfg8_f8<T, EPI_NONE>(a, stream);
+    case EPI_GELU: return launch_cfg8_f8<T, EPI_GELU>(a, stream);
+    case EPI_LS_RESID: return launch_cfg8_f8<T, EPI_LS_RESID>(a, stream);
+    case EPI_RESID: return launch_cfg8_f8<T, EPI_RESID>(a, stream);
+    case EPI_SWIGLU: return launch_cfg8_f8<T, EPI_SWIGLU>(a, stream);
+  }
+  omchat_set_error("launch_gemm: bad epilogue");
+  return 1;
+}
+
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "empty problem");
+  if (a.f8) {
+    OM_CHECK(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && a.a_scale && a.w_scale, "fp8 GEMM: K % 128, lda / ldw % 16 bytes, both scale vectors");
+    OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.ldc % 2 == 0 && ((uintptr_t)a.C & 3) == 0, "fp8 GEMM: alignment");
+    OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
+    if (dtype == OMCHAT_F16) return launch_f8_t<f16>(a, stream);
+    if (dtype == OMCHAT_BF16) return launch_f8_t<bf16>(a, stream);
+    omchat_set_error("launch_gemm: bad dtype");
+    return 1;
+  }
   OM_CHECK(a.K % 64 == 0, "K must be a multiple of 64");
   OM_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, "lda/ldw must be multiples of 8 elements (16-byte rows)");
   OM_CHECK(a.ldc % 2 == 0 && (!a.resid || a.ldr % 2 == 0) && ((uintptr_t)a.C & 3) == 0 && ((uintptr_t)a.resid & 3) == 0,

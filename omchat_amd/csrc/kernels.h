@@ -26,6 +26,11 @@ struct GemmArgs {
   int force_tile;     // 0 auto, 1 = 128x128, 2 = 256x256 (staggered 4-phase), 3 = 256x192, 4 = 224x256, 5 = 192x256, 6 = 256x256 (one barrier)
   void* sk_ws; size_t sk_ws_bytes;   // stream-K workspace (gemm_sk_ws_bytes()), null = data-parallel only
   int stream_k;       // 0 auto (when a workspace is given), -1 never, 1 required
+  // fp8 x fp8 MFMA (BASELINE configs[4], "fp8 MFMA weights"): A [M, K] and W [N, K] are OCP e4m3 bytes (lda / ldw in bytes) with one fp32
+  // scale per row each; C = epi(a_scale[m] * w_scale[n] * sum_k A8 W8) in the 16-bit type.  K % 128 == 0.  256x256 tile, 128-deep K
+  // steps: the same LDS bytes per step as the 16-bit kernel feed twice the MFMAs.
+  int f8;
+  const float* a_scale; const float* w_scale;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 size_t gemm_sk_ws_bytes();
@@ -60,6 +65,9 @@ int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
 int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t stream);
 void gemv_set_force_mfma(int v);
 void gemm_set_autotune(int v);
+int gemm_tune_load(const char* path);
+int gemm_tune_dump(const char* path);
+long gemm_tune_runs();
 void model_set_ar_min_rows(int v);
 void model_set_pack_replica(int v);
 
@@ -68,6 +76,10 @@ void model_set_pack_replica(int v);
 int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps, hipStream_t stream);
 // pack_nb != 0: y is written in the packed x layout (common.h) with NB = pack_nb instead of row-major (rows <= 16 * pack_nb)
 int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, int ldy, int rows, int H, float eps, hipStream_t s, int pack_nb = 0);
+// RMSNorm whose output goes to an fp8 x fp8 GEMM: y8[row] = e4m3(T(w * T(x * rsqrt(..))) / s_row), s_row = absmax / 448 (per token)
+int launch_rmsnorm_q8(int dtype, const void* x, int ldx, const void* w, void* y8, int ldy, float* scale, int rows, int H, float eps, hipStream_t s);
+// per-row e4m3 quantisation of an activation matrix [rows, H] (16-bit) -> bytes + one fp32 scale per row
+int launch_quant_rows_q8(int dtype, const void* x, int ldx, void* y8, int ldy, float* scale, int rows, int H, hipStream_t s);
 // decode: x = T(x + T(sum_s part[s])) in place, then xn = rmsnorm(x) * w (w == null: skip the norm).  part fp32 [ks][rows][H]
 int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
                          hipStream_t s, int pack_nb = 0);
@@ -112,7 +124,15 @@ struct AttnDecodeArgs {
   const int* pos;                               // device [batch]; kv_len[b] must be pos[b] + 1
   const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v of the new token: [b][kv_heads*128] views, batch stride
   int o_pack_nb;                                // != 0: O is written as packed x ([b][q_heads*128] rows, common.h) for the o_proj GEMV
+  // fp8 KV cache (BASELINE configs[4]): K / V point at OCP e4m3 bytes in the SAME [b, kv_heads, L, 128] layout (strides in elements),
+  // with one fp32 scale per (sequence, kv head, key): k_scale / v_scale [b][kv_heads][scale_cap]; rope must be null (the new token is
+  // rotated, appended and quantised before the call)
+  const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;
 };
+// quantise rows [pos0, pos1) of every (sequence < b, kv head) of a 16-bit cache [b_cap, kv_heads, cap, 128] into the fp8 cache + scales
+// (pos1 = null-terminated per sequence: rows >= len[b] are skipped when len != null)
+int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v8, float* ks, float* vs, int b, int kv_heads, int64_t c_sb, int64_t c_sh,
+                    int64_t s_sb, int64_t s_sh, const int* pos_lo, int pos0, const int* len, int max_rows, hipStream_t s);
 size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len);
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s);
 

@@ -97,6 +97,13 @@ struct omchat_ctx {
   bool pk_ready = false;
   void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
   bool fp8_decode = false, fp8_stale = false;
+  // BASELINE configs[4]: fp8 KV cache for decode (e4m3 bytes in the layout of the 16-bit cache + one fp32 scale per (layer, sequence,
+  // kv head, position)) and fp8 x fp8 MFMA prefill GEMMs (qkv and gate|up: the activations come quantised per token from the RMSNorm)
+  void *k8cache = nullptr, *v8cache = nullptr;
+  float *ks8 = nullptr, *vs8 = nullptr;
+  bool fp8_kv = false, kv8_valid = false, fp8_prefill = false;
+  void* tw_q8 = nullptr; float* tw_q8s = nullptr;
+  int64_t scale_layer_stride() const { return (int64_t)c.max_batch * c.t_kv_heads * c.max_seq; }
   // decode step as a hipGraph (omchat_enable_decode_graph): ~230 launches per token replayed as one graph launch.  Captured on a
   // context-owned stream (the caller's may be the legacy null stream, which cannot capture) with context-owned token / logits
   // buffers so that every kernel argument is replay-invariant; the split-KV attention grid is captured for `cap_len` keys
@@ -748,11 +755,8 @@ static int lm_head_rows(omchat_ctx* ctx, const void* hidden, int n, float* logit
   return 0;
 }
 
-extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
-  OM_CHECK(ctx, "null context");
+static int ensure_fp8_weights(omchat_ctx* ctx) {
   const omchat_config& c = ctx->c;
-  OM_CHECK(c.t_layers > 0, "context has no decoder");
-  if (!on) { ctx->fp8_decode = false; return 0; }
   if (ctx->dl8.empty() || ctx->fp8_stale) {
     OM_CHECK(omchat_weights_missing(ctx) == 0, "load the weights before quantising them");
     const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
@@ -775,7 +779,47 @@ extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
     OM_HIP(hipDeviceSynchronize());
     ctx->fp8_stale = false;
   }
+  return 0;
+}
+
+extern "C" int omchat_enable_fp8_decode(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null context");
+  OM_CHECK(ctx->c.t_layers > 0, "context has no decoder");
+  if (!on) { ctx->fp8_decode = false; return 0; }
+  TRY(ensure_fp8_weights(ctx));
   ctx->fp8_decode = true;
+  return 0;
+}
+
+extern "C" int omchat_enable_fp8_kv(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null context");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  ctx->kv8_valid = false;            // takes effect with the next prefill
+  if (!on) { ctx->fp8_kv = false; return 0; }
+  if (!ctx->k8cache) {
+    const size_t bytes = (size_t)c.t_layers * ctx->cache_layer_stride();
+    const size_t sc = (size_t)c.t_layers * ctx->scale_layer_stride() * 4;
+    TRY(ctx->alloc(&ctx->k8cache, bytes)); TRY(ctx->alloc(&ctx->v8cache, bytes));
+    TRY(ctx->alloc((void**)&ctx->ks8, sc)); TRY(ctx->alloc((void**)&ctx->vs8, sc));
+  }
+  ctx->fp8_kv = true;
+  return 0;
+}
+
+extern "C" int omchat_enable_fp8_prefill(omchat_ctx* ctx, int on) {
+  OM_CHECK(ctx, "null context");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  if (!on) { ctx->fp8_prefill = false; return 0; }
+  OM_CHECK(c.t_hidden % 128 == 0, "fp8 x fp8 prefill GEMMs need hidden_size % 128 == 0");
+  TRY(ensure_fp8_weights(ctx));
+  if (!ctx->tw_q8) {
+    const size_t R = std::max<size_t>(32, (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch));
+    TRY(ctx->alloc(&ctx->tw_q8, R * c.t_hidden));
+    TRY(ctx->alloc((void**)&ctx->tw_q8s, R * 4));
+  }
+  ctx->fp8_prefill = true;
   return 0;
 }
 
@@ -838,8 +882,20 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     // Qwen2DecoderLayer.forward (modeling_qwen2.py:269-298)
-    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, rows, H, c.t_eps, s));
-    TRY(gemm(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, nullptr, nullptr, 0, EPI_NONE, s));
+    const bool f8p = ctx->fp8_prefill && !ctx->dl8.empty() && !ctx->fp8_stale;
+    // fp8 x fp8 MFMA for the two column-parallel GEMMs (BASELINE configs[4]): the RMSNorm writes e4m3 + one scale per token, the
+    // weights are the e4m3 replica with one scale per output row; o_proj / down_proj keep the 16-bit operands
+    auto gemm_f8 = [&](const void* W8, const float* sw, void* Cb, int ldc, int N, const void* bias, int epi) -> int {
+      GemmArgs g{ctx->tw_q8, H, W8, H, Cb, ldc, rows, N, H, bias, nullptr, nullptr, 0, epi, 0, nullptr, 0, -1, 1, ctx->tw_q8s, sw};
+      return launch_gemm(ctx->dt, g, s);
+    };
+    if (f8p) {
+      TRY(launch_rmsnorm_q8(ctx->dt, x, H, L.ln1, ctx->tw_q8, H, ctx->tw_q8s, rows, H, c.t_eps, s));
+      TRY(gemm_f8(ctx->dl8[i].wqkv, ctx->dl8[i].sqkv, ctx->tw_qkv, qkvd, qkvd, L.bqkv, EPI_NONE));
+    } else {
+      TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, rows, H, c.t_eps, s));
+      TRY(gemm(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, nullptr, nullptr, 0, EPI_NONE, s));
+    }
     RopeArgs r{ctx->tw_qkv, qkvd, rows, S, c.t_heads, c.t_kv_heads, nullptr, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
     TRY(launch_rope_kv(ctx->dt, r, s));
     AttnArgs a{};
@@ -857,9 +913,11 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
       TRY(gemm_allreduce(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, qd, nullptr, nullptr, lead ? x : nullptr, EPI_RESID, s));
       std::swap(x, y);
     }
-    TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
+    if (f8p) TRY(launch_rmsnorm_q8(ctx->dt, x, H, L.ln2, ctx->tw_q8, H, ctx->tw_q8s, rows, H, c.t_eps, s));
+    else TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
     ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
-    TRY(gemm(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, nullptr, nullptr, 0, EPI_SWIGLU, s));
+    if (f8p) TRY(gemm_f8(ctx->dl8[i].wgu, ctx->dl8[i].sgu, ctx->tw_act, It, 2 * It, nullptr, EPI_SWIGLU));
+    else TRY(gemm(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, nullptr, nullptr, 0, EPI_SWIGLU, s));
     ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
@@ -875,6 +933,16 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     TRY(launch_gather_rows(ctx->dt, ctx->d_idx, x, nullptr, ctx->tw_last, b, H, s));
     TRY(launch_rmsnorm(ctx->dt, ctx->tw_last, H, ctx->t_norm, ctx->tw_last, H, b, H, c.t_eps, s));
     TRY(lm_head_rows(ctx, ctx->tw_last, b, logits_last, s));
+  }
+  ctx->kv8_valid = false;
+  if (ctx->fp8_kv && !left) {      // fp8 KV cache for the decode steps: quantise what this prefill wrote (d_len still holds the valid lengths)
+    for (int i = 0; i < c.t_layers; ++i) {
+      const size_t off = (size_t)i * ctx->cache_layer_stride(), so = (size_t)i * ctx->scale_layer_stride();
+      TRY(launch_kv_quant(ctx->dt, (char*)ctx->kcache + off * 2, (char*)ctx->vcache + off * 2, (char*)ctx->k8cache + off, (char*)ctx->v8cache + off,
+                          ctx->ks8 + so, ctx->vs8 + so, b, c.t_kv_heads, ctx->cache_sb(), ctx->cache_sh(), (int64_t)c.t_kv_heads * c.max_seq, c.max_seq,
+                          nullptr, 0, ctx->d_len, S, s));
+    }
+    ctx->kv8_valid = true;
   }
   OM_HIP(hipMemcpyAsync(ctx->d_pos, pos.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
   OM_HIP(hipMemcpyAsync(ctx->d_len, len1.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
@@ -988,6 +1056,18 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
     a.rope = ctx->rope; a.rope_max = c.max_seq; a.pos = ctx->d_pos;
     a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
+    if (ctx->fp8_kv && ctx->kv8_valid) {
+      // fp8 KV cache: rotate q / k and append to the 16-bit cache with the prefill's kernel, quantise the new row, then attend over e4m3
+      // keys and values (two small launches more per layer than the fused 16-bit path; this mode is for long contexts)
+      RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
+      TRY(launch_rope_kv(ctx->dt, r, s));
+      const size_t off = (size_t)i * ctx->cache_layer_stride(), so = (size_t)i * ctx->scale_layer_stride();
+      TRY(launch_kv_quant(ctx->dt, kc, vc, (char*)ctx->k8cache + off, (char*)ctx->v8cache + off, ctx->ks8 + so, ctx->vs8 + so, b, c.t_kv_heads,
+                          ctx->cache_sb(), ctx->cache_sh(), (int64_t)c.t_kv_heads * c.max_seq, c.max_seq, ctx->d_pos, 0, nullptr, 1, s));
+      a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
+      a.K = (char*)ctx->k8cache + off; a.V = (char*)ctx->v8cache + off;
+      a.k_scale = ctx->ks8 + so; a.v_scale = ctx->vs8 + so; a.scale_sb = (int64_t)c.t_kv_heads * c.max_seq; a.scale_sh = c.max_seq;
+    }
     a.o_pack_nb = fused ? pk : 0;
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
@@ -1076,7 +1156,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     TRY(decode_body(ctx, tokens, b, Lmax, logits, next_tokens, s, true));
   } else {
     const bool f8 = ctx->fp8_decode && b == 1;
-    omchat_ctx::DecodeGraph& g = ctx->graphs[b * 2 + (f8 ? 1 : 0)];
+    omchat_ctx::DecodeGraph& g = ctx->graphs[b * 4 + (f8 ? 2 : 0) + ((ctx->fp8_kv && ctx->kv8_valid) ? 1 : 0)];
     hipStream_t gs = ctx->graph_stream;
     OM_HIP(hipEventRecord(ctx->graph_ev_in, s));
     OM_HIP(hipStreamWaitEvent(gs, ctx->graph_ev_in, 0));

@@ -125,6 +125,14 @@ class Engine:
         """Weight-only OCP e4m3 replica of the decode-streamed decoder weights (quantised on first call); batch-1 decode only."""
         check(self.lib.omchat_enable_fp8_decode(self.h, int(on)))
 
+    def enable_fp8_kv(self, on=True):
+        """fp8 (e4m3 + per-position scale) KV cache for the decode steps that follow the NEXT prefill (BASELINE configs[4])"""
+        check(self.lib.omchat_enable_fp8_kv(self.h, int(on)))
+
+    def enable_fp8_prefill(self, on=True):
+        """fp8 x fp8 MFMA for the qkv and gate|up GEMMs of the prefill (activations quantised per token, weights per output row)"""
+        check(self.lib.omchat_enable_fp8_prefill(self.h, int(on)))
+
     def enable_decode_graph(self, on=True):
         """Replay each decode step as one hipGraph launch (TP = 1, b <= 32); same kernels and results as the eager step."""
         check(self.lib.omchat_enable_decode_graph(self.h, int(on)))

@@ -166,3 +166,147 @@ def test_full_width_layer_fp8_decode(gpu_lib, dt):
         ref = oracle.decode_step(torch.tensor([[tok]]), sdq, cfg.text, cache)[0, 0]
         assert rel(lg[0], ref) < TOL_DEEP[dt], rel(lg[0], ref)
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2 (BASELINE configs[4]): fp8 x fp8 MFMA prefill GEMM, quantising RMSNorm, fp8 KV cache
+# ---------------------------------------------------------------------------------------------------------------------
+def dev_quant_rows(x_dev, dt, norm_w=None, eps=1e-6):
+    lib = _lib.lib()
+    rows, H = x_dev.shape
+    y8 = torch.empty(rows, H, dtype=torch.uint8, device="cuda")
+    sc = torch.empty(rows, dtype=torch.float32, device="cuda")
+    _lib.check(lib.omchat_op_quant_rows_fp8(CODE[dt], ptr(x_dev), ptr(norm_w), eps, ptr(y8), ptr(sc), rows, H, None))
+    sync()
+    return y8, sc
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_activation_quantiser_and_quantising_rmsnorm_bit_exact(gpu_lib, dt):
+    x = rnd(randn((37, 3584), 1, 2.0), dt)
+    x[5] = 0
+    y8, sc = dev_quant_rows(dev(x, dt), dt)
+    q, s = quant_ref(x)
+    assert torch.equal(sc.cpu(), s) and torch.equal(y8.cpu(), q.view(torch.uint8))
+    w = rnd(randn((3584,), 2, 0.05) + 1, dt)
+    dw = dev(w, dt)
+    y8, sc = dev_quant_rows(dev(x, dt), dt, dw)
+    xn = rnd(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6), dt)       # T(x * rsqrt), then T(w * .): the reference's two roundings (N2)
+    yn = rnd(w * xn, dt)
+    q, s = quant_ref(yn)
+    # rsqrt on the device is 1 ulp: allow a handful of e4m3 ties to land on the neighbouring code
+    assert (sc.cpu() - s).abs().max() <= 1e-6 * s.abs().max() + 1e-12
+    diff = (y8.cpu().view(torch.float8_e4m3fn).float() - q.float()).abs()
+    assert float((diff > 0).float().mean()) < 2e-3
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K,epi", [(300, 512, 256, "none"), (3584, 4608, 3584, "none"), (1025, 2048, 3584, "swiglu"), (64, 320, 128, "resid"),
+                                       (257, 288, 1024, "none")])
+def test_gemm_fp8xfp8_vs_dequantised_matmul(gpu_lib, dt, M, N, K, epi):
+    """e4m3 products are exact in fp32, so the fp8 x fp8 MFMA GEMM must equal the fp32 matmul of the DE-QUANTISED operands up to fp32
+    summation order (then the usual 16-bit rounding of the epilogue)"""
+    lib = _lib.lib()
+    a = rnd(randn((M, K), 1, 1.0), dt); w = rnd(randn((N, K), 2, 0.03), dt)
+    a8, sa = dev_quant_rows(dev(a, dt), dt)
+    w8, sw = dev_quant(dev(w, dt), dt)
+    ad, wd = dequant_ref(a).double(), dequant_ref(w).double()
+    acc = (ad @ wd.t()).float()
+    bias = rnd(randn((N,), 3, 0.1), dt); bd = dev(bias, dt)
+    if epi == "none":
+        c = torch.full((M, N), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(lib.omchat_op_gemm_fp8(CODE[dt], ptr(a8), ptr(sa), ptr(w8), ptr(sw), ptr(c), N, M, N, K, ptr(bd), None, 0, _lib.EPI_NONE, None)); sync()
+        ref = acc + bias
+        assert (c.float().cpu() - rnd(ref, dt)).abs().max() <= 2 * torch.finfo(DT[dt]).eps * ref.abs().max()      # one 16-bit rounding apart at most
+        assert rel(c, ref) < 0.6 * TOL[dt]
+    elif epi == "resid":
+        r = rnd(randn((M, N), 4, 1.0), dt); rd = dev(r, dt)
+        c = torch.full((M, N), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(lib.omchat_op_gemm_fp8(CODE[dt], ptr(a8), ptr(sa), ptr(w8), ptr(sw), ptr(c), N, M, N, K, None, ptr(rd), N, _lib.EPI_RESID, None)); sync()
+        assert rel(c, r + rnd(acc, dt)) < TOL[dt]
+    else:
+        c = torch.full((M, N // 2), float("nan"), dtype=DT[dt], device="cuda")
+        _lib.check(lib.omchat_op_gemm_fp8(CODE[dt], ptr(a8), ptr(sa), ptr(w8), ptr(sw), ptr(c), N // 2, M, N, K, None, None, 0, _lib.EPI_SWIGLU, None)); sync()
+        v = acc.view(M, N // 32, 2, 16)
+        g, u = rnd(v[:, :, 0].reshape(M, -1), dt), rnd(v[:, :, 1].reshape(M, -1), dt)
+        assert rel(c, rnd(torch.nn.functional.silu(g), dt) * u) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_fp8_kv_cache_and_fp8_prefill_on_the_tiny_decoder(gpu_lib, dt):
+    """the fp8 modes end to end on a tiny decoder: each mode changes the logits by about the e4m3 step (it IS a quantised computation)
+    and stays within the quantisation tolerance of the 16-bit run; batched decode works on the fp8 cache as well"""
+    cfg = tiny(q_heads=4, kv_heads=2, layers_t=2)
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 7).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    b, S = 3, 40
+    x = rnd(randn((b, S, 256), 5, 0.5), dt)
+    lens = [40, 33, 17]
+
+    def run(kv8, pre8):
+        e = Engine(cfg, dtype=dt, max_seq=96, max_batch=b, vision=False)
+        e.load_state_dict(sd)
+        if kv8: e.enable_fp8_kv(True)
+        if pre8: e.enable_fp8_prefill(True)
+        lg0, _ = e.prefill(x, lens)
+        out = [lg0.clone()]
+        tok = torch.tensor([3, 11, 200])
+        for _ in range(3):
+            tok, lg = e.decode_step(tok, want_logits=True)
+            out.append(lg.clone())
+        sync()
+        assert e.kv_lengths(b) == [n + 3 for n in lens]
+        e.close()
+        return out
+    base = run(False, False)
+    kv = run(True, False)
+    assert torch.equal(kv[0], base[0])                                  # the prefill itself is untouched by the fp8 KV cache
+    for i in range(1, 4):
+        d = rel(kv[i], base[i])
+        assert 1e-4 < d < 0.08, (i, d)
+    pre = run(False, True)
+    for i in range(4):
+        d = rel(pre[i], base[i])
+        assert 1e-3 < d < 0.15, (i, d)
+    both = run(True, True)
+    assert all(torch.isfinite(t).all() for t in both)
+
+
+def test_fp8_kv_decode_one_full_width_layer_16k_context(gpu_lib):
+    """BASELINE configs[4] shape on one Qwen2-7B-width layer: 16 k tokens of context, fp8 weights for the decode GEMVs AND the fp8 KV
+    cache, against the oracle run on the de-quantised weights and the de-quantised cache (per (head, position) absmax / 448 scales)"""
+    from oracle import KVCache, decode_step
+    from oracle.decoder import rope_cos_sin, apply_rope
+    from oracle.vit import rms_norm
+    import torch.nn.functional as F
+    dt = "bf16"
+    cfg = omchat13b()
+    cfg.text["num_hidden_layers"] = 1
+    cfg.text["vocab_size"] = 2048
+    S = 16400
+    e = Engine(cfg, dtype=dt, max_seq=S + 64, max_batch=1, vision=False)
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 0).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    e.load_state_dict(sd)
+    e.enable_fp8_kv(True)
+    x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(1)) * 0.5).bfloat16().float()
+    logits, _ = e.prefill(x); sync()
+    assert torch.isfinite(logits).all()
+    e.enable_fp8_decode(True)
+    P = "model.layers.0."
+    xn = rms_norm(x, sd[P + "input_layernorm.weight"], 1e-6)
+    k = F.linear(xn, sd[P + "self_attn.k_proj.weight"], sd[P + "self_attn.k_proj.bias"]).view(1, S, 4, 128).transpose(1, 2)
+    v = F.linear(xn, sd[P + "self_attn.v_proj.weight"], sd[P + "self_attn.v_proj.bias"]).view(1, S, 4, 128).transpose(1, 2)
+    cos, sin = rope_cos_sin(torch.arange(S)[None], 128, cfg.text["rope_theta"], torch.float32)
+    _, k = apply_rope(k, k, cos, sin)
+    dq = lambda t: dequant_ref(t.to(torch.bfloat16).float().reshape(-1, 128)).reshape(t.shape)      # the device quantises the bf16 cache rows
+    cache = KVCache(1)
+    cache.update(dq(k), dq(v), 0)
+    sdq = _dequant_decoder_weights(sd, dt)
+    for tok in (5, 9):
+        nxt, lg = e.decode_step(torch.tensor([tok]), want_logits=True); sync()
+        r = decode_step(torch.tensor([[tok]]), sdq, cfg.text, cache)[0, 0]
+        # the oracle appends the new token's k / v unquantised: one of 16 k keys, invisible at this tolerance
+        d = float((lg[0].float().cpu() - r).norm() / r.norm())
+        assert d < 3e-2, d
+        assert int(nxt[0]) == int(torch.argmax(lg[0]))
+    assert e.kv_lengths(1) == [S + 2]
+    e.close()
