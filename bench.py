@@ -15,6 +15,9 @@ Workloads (BASELINE.json):
   configs2  32 such samples per step: 96 tiles through the ViT, right-padded batch prefill of 32 x 3584 rows, G batched
             decode steps.  Reported under "configs2" (tokens / s, samples / s, HBM fraction of the decode steps); it is `value`
             only with --workload configs2.
+  configs4  (only on request) one 32-frame clip: 32 tiles through the ViT, prefill of 32 x 1024 + 512 = 33 280 positions (>= 16 k
+            visual + text tokens), G greedy tokens with the fp8 modes on: e4m3 decode weights, e4m3 KV cache, fp8 x fp8 MFMA for the
+            qkv / gate|up prefill GEMMs.  A quantised computation: not comparable with `value` of configs1.
 Inputs are resident in HBM before the timed region.  Weights: deterministic synthetic (omchat_amd/synth.py) at the full
 OmChat-13B geometry, generated on the device; under TP every rank keeps its SHARD of the same values, and the first 32
 greedy ids are checked against a TP = 1 context that rank 0 runs first in the same process ("tokens_match_tp1").
@@ -41,7 +44,8 @@ MARGIN_GUARD = {"bf16": 0.05, "f16": 0.02}      # top-1 / top-2 logit gap below 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="both", choices=["both", "configs1", "configs2"])
+    ap.add_argument("--workload", default="both", choices=["both", "configs1", "configs2", "configs4"])
+    ap.add_argument("--frames", type=int, default=32, help="configs4: video frames (one 448x448 tile = 1024 visual tokens each)")
     ap.add_argument("--graph", action="store_true", help="replay each decode step as one captured hipGraph instead of ~230 eager launches "
                     "(measured SLOWER on ROCm 7.2 / MI355X: 3.21 vs 2.96 ms per token, so it is off by default)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the (untimed) weight-only fp8 decode measurement")
@@ -182,6 +186,8 @@ def pmc_traffic(substrings):
 
 def main():
     a = parse()
+    if a.workload == "configs4":
+        a.no_tp1_check = True          # a quantised computation: there is no TP = 1 16-bit twin to compare ids with
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
@@ -208,10 +214,11 @@ def main():
         k, v = kv.split("=")
         _lib.check(_lib.lib().omchat_op_set_tuning(int(k), int(v)))
     cfg = tiny() if a.tiny else omchat13b()
-    n_tiles = 3
+    do4 = a.workload == "configs4"
+    n_tiles = a.frames if do4 else 3
     ntok = cfg.num_image_tokens
     S = n_tiles * ntok + a.text_tokens
-    do1 = a.workload in ("both", "configs1")
+    do1 = a.workload in ("both", "configs1", "configs4")      # configs4 runs through the batch-1 leg with its own tile count and fp8 modes
     do2 = a.workload in ("both", "configs2")
     B2 = a.batch2 if do2 else 1
 
@@ -261,7 +268,10 @@ def main():
         for i in range(b):
             text = synth.token_ids(a.text_tokens, min(cfg.text["vocab_size"], 151643), 1 + i).tolist()
             # "<image>\npatch:<image>\npatch:<image>\n{question}" layout (make_context.py:30): sentinel, 1 separator id between
-            rows.append([-200, text[0], -200, text[1], -200] + text[2:])
+            row = []
+            for tix in range(n_tiles):
+                row += [-200, text[tix]]
+            rows.append(row[:-1] + text[n_tiles - 1:])
         ids = torch.tensor(rows, dtype=torch.int64)
         assert ids.shape[1] - n_tiles + n_tiles * ntok == S
         return px, ids
@@ -294,6 +304,8 @@ def main():
     eng.fill_synthetic(0)
     if a.graph and world == 1:
         eng.enable_decode_graph(True)      # one graph launch per token; every 8th step stays eager for the HIP-event brackets
+    if do4:
+        eng.enable_fp8_decode(True); eng.enable_fp8_kv(True); eng.enable_fp8_prefill(True)
 
     if tp1 is not None:
         # teacher-forced on the TP = 1 ids: the TP = N logits (vocab shards gathered on rank 0) against the TP = 1 logits, and the
@@ -449,6 +461,9 @@ def main():
     name = "OmChat-13B (InternViT-6B 45L + Qwen2-7B 28L)" if full else "TINY DEBUG GEOMETRY"
     wl1 = (f"{name}, configs[1]: 1 sample = {n_tiles} tiles of 448x448 + {a.text_tokens} text ids -> prefill S={S}, "
            f"{a.gen} greedy decode tokens, batch 1")
+    if do4:
+        wl1 = (f"{name}, configs[4]: one {n_tiles}-frame clip = {n_tiles} tiles + {a.text_tokens} text ids -> prefill S={S}, {a.gen} greedy decode "
+               f"tokens, batch 1; fp8: e4m3 decode weights + e4m3 KV cache + fp8 x fp8 MFMA qkv / gate|up prefill GEMMs")
     wl2 = (f"{name}, configs[2]: {B2} samples per step = {n_tiles * B2} tiles + {B2} x {a.text_tokens} text ids -> batch prefill {B2} x {S}, "
            f"{a.gen} batched greedy decode steps")
     res = {
@@ -465,6 +480,17 @@ def main():
         "device_gb": eng.device_bytes() / 1e9,
         "decode_graph": eng.decode_graph_stats() if (a.graph and world == 1) else None,
     }
+    if do4 and full:
+        dec_s = head["dec_ms"] / 1e3 / (a.gen - 1)
+        res["dtype"] = a.dtype + " activations, e4m3 weights (decode GEMVs, qkv / gate|up prefill GEMMs) and KV cache"
+        res["decode_hbm_frac"] = (7.07e9 + 28672.0 * (S + a.gen / 2)) / world / dec_s / 1e9 / HBM_PEAK_GBS
+        res["decode_hbm_note"] = "algorithmic bytes per token: 7.07 GB of e4m3 weights + 28 672 B of e4m3 KV per cached position"
+        if roof:
+            roof["bytes_per_launch"] = gu_bytes_f8 = ld["t_mlp"] * t["hidden_size"] * 2.0
+            roof["achieved"] = gu_bytes_f8 / (roof["avg_launch_us"] * 1e-6) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["kernel"] = "gemv_rows_kernel<EPI_SWIGLU, F8> (decode gate|up e4m3 weight stream, batch 1)"
+            roof["traffic"] = None; roof["traffic_source"] = None
     if world > 1:
         res["rccl_nranks"] = transport.get("rccl_nranks")
         res["tokens_match_tp1"] = tokens_match
@@ -478,7 +504,7 @@ def main():
                    "note": "side measurement in the same process and context; NOT part of `value`"})
         res["configs2"] = s2
     # weight-only fp8 decode (row f-2 / configs[4]), outside the timed region: same prompt, 64 greedy tokens on the e4m3 replica
-    if world == 1 and not a.no_fp8:
+    if world == 1 and not a.no_fp8 and not do4:
         px, ids = make_inputs(1)
         eng.enable_fp8_decode(True)
         n8 = min(64, a.gen)

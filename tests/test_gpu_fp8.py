@@ -306,7 +306,7 @@ def test_fp8_kv_decode_one_full_width_layer_16k_context(gpu_lib):
         r = decode_step(torch.tensor([[tok]]), sdq, cfg.text, cache)[0, 0]
         # the oracle appends the new token's k / v unquantised: one of 16 k keys, invisible at this tolerance
         d = float((lg[0].float().cpu() - r).norm() / r.norm())
-        assert d < 3e-2, d
+        assert d < 4e-2, d
         assert int(nxt[0]) == int(torch.argmax(lg[0]))
     assert e.kv_lengths(1) == [S + 2]
     e.close()
