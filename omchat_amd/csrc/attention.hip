@@ -349,6 +349,217 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------
+// Prefill kernel, second generation (head_dim 128): 32x32x16 MFMA, one wave = 32 queries of one head.
+//
+// Why: the 16x16x32 kernel above is VALU-issue bound (a 16x16x32 MFMA blocks the SIMD's vector issue for 8 of its 16 cycles, a
+// 32x32x16 for 8 of its 32: MI355X_MICROARCH.md "vector-instruction ISSUE cost"), and every q head re-staged the K / V tiles of its
+// kv head.  Here
+//   * S^T[32 keys][32 q] = K Q^T with 32x32x16: the lane holds 16 scores of ONE query (its column), the partner lane (l ^ 32) the other
+//     16 keys of the 32-key tile: the row max / sum need one v_permlane32_swap each, and half as many MFMA issue slots per FLOP go to
+//     the softmax's VALU work;
+//   * P^T feeds the PV MFMA as its B operand straight from the score registers (cdna_hip_programming.md §3 "An accumulator tile as the
+//     next MFMA's operand": registers 8s..8s+7 are k-step s, element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)); V^T comes
+//     through ds_read_b64_tr_b16 in that same key order;
+//   * GQA (decoder prefill): the workgroup is the n_rep (7) query heads of ONE kv head x 32 queries, so a K / V tile is staged once
+//     for all of them; MHA (ViT): 4 waves = 128 queries of one head.
+// K and V tiles (64 keys x 256 B) share ONE LDS image formula, T10 image (b): off(row, ch) = 256 row + 16 (ch ^ (((row & 3) << 2) |
+// ((row >> 2) & 3))), conflict-free for the 32-row ds_read_b128 operand read AND for the transposed reads; filled by LDS-DMA with the
+// permutation on the source chunk.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int swz_b(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <typename T, int NW, bool GQA>
+__global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  constexpr int NT = NW * 64;
+  constexpr int TILE = KV_TILE * 256;                 // bytes of one K (or V) tile
+  constexpr int BUF = 2 * TILE;
+  constexpr int NPIECE = KV_TILE * 16;                // 16-byte pieces per tile
+  constexpr int ROUNDS = (NPIECE + NT - 1) / NT;
+  __shared__ __attribute__((aligned(256))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qc = lane & 31, hh = lane >> 5;           // query column of this lane, lane half
+
+  const int n_rep = p.q_heads / p.kv_heads;
+  const int nqb = gridDim.x;
+  const int qb = p.causal ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;     // heaviest causal blocks first
+  const int b = blockIdx.z;
+  constexpr int QW = GQA ? 32 : NW * 32;              // queries of the workgroup
+  const int kvh = GQA ? (int)blockIdx.y : (int)blockIdx.y / n_rep;
+  const int hq = GQA ? kvh * n_rep + wave : (int)blockIdx.y;
+  const int q0b = qb * QW;
+  const int q0 = q0b + (GQA ? 0 : wave * 32);
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  int kmax = kv_len;
+  if (p.causal) { const int lim = q0b + QW + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
+  const int t_end = (kmax + KV_TILE - 1) / KV_TILE;
+  const int kv_start = p.kv_start ? p.kv_start[b] : 0;
+  const int t_begin = kv_start / KV_TILE;
+
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const bool wave_active = (GQA ? wave < n_rep : true) && q0 < p.Sq;       // wave-uniform
+
+  // ---- Q fragments (B operand of S^T): lane holds Q[query qc][d = 16 s + 8 hh + j]
+  frag_t qf[8];
+  const int qrow = q0 + qc;
+  {
+    const int rr = qrow < p.Sq ? qrow : p.Sq - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (wave_active ? hq : 0) * p.q_sh + (int64_t)rr * p.q_sr;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = ld8<T>(qp + s * 16 + hh * 8);
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = M_FLOOR, l_run = 0.f;
+
+  // ---- staging: piece = i * NT + tid -> LDS row = piece >> 4, physical chunk = piece & 15 (lane-linear destination, permuted source)
+  auto issue_tile = [&](int t, int buf) {
+    char* const Kw = smem + buf * BUF;
+    char* const Vw = Kw + TILE;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      if ((i + 1) * NT <= NPIECE || i * NT + wave * 64 < NPIECE) {         // whole waves only (wave-uniform)
+        const int piece = i * NT + tid, row = piece >> 4, pc = piece & 15;
+        int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;    // masked keys must stay finite
+        const int ch = pc ^ swz_b(row);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)kr * p.k_sr + ch * 8), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)kr * p.v_sr + ch * 8), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // K (A operand of S^T), k-step s of key tile kt: row 32 kt + qc, chunk 2 s + hh
+  // V^T (A operand of PV), k-step s2 of key tile kt, d block db: 16-lane group g = lane >> 4 (half = g >> 1, d sub-block = g & 1);
+  //   lane 4 q + pp of the group supplies row r0 + q, chunk c0 + (pp >> 1), + 8 (pp & 1) bytes, r0 = 32 kt + 16 s2 + 4 half (+ 8), c0 = 4 db + 2 dsub
+  const int vq = (lane & 15) >> 2, vp = lane & 3, vg = lane >> 4;
+  const int v_row_lo = 4 * (vg >> 1) + vq;            // + 32 kt + 16 s2 (+ 8 for the second read)
+  const int v_ch_lo = 2 * (vg & 1) + (vp >> 1);       // + 4 db
+  const int v_byte = 8 * (vp & 1);
+
+  if (t_end > t_begin) issue_tile(t_begin, t_begin & 1);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = t & 1;
+    const char* const Ks = smem + cur * BUF;
+    const char* const Vs = Ks + TILE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);
+    if (!wave_active) continue;
+
+    // ---- S^T = K Q^T: two 32-key tiles
+    f32x16 sc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+      const int row = kt * 32 + qc;
+      const char* kb = Ks + row * 256;
+      const int sw = swz_b(row);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(kb + (((2 * s + hh) ^ sw) << 4));
+        sc[kt] = mfma32(kf, qf[s], sc[kt]);
+      }
+    }
+
+    // ---- mask + online softmax (this lane: query qc, keys 32 kt + (r & 3) + 8 (r >> 2) + 4 hh)
+    const int key0 = t * KV_TILE + 4 * hh;
+    const bool need_mask = (t + 1) * KV_TILE > kv_len || (p.causal && (t + 1) * KV_TILE > q0 + p.q_pos0 + 1) || t * KV_TILE < kv_start;
+    if (need_mask) {
+      int lim = kv_len;
+      if (p.causal) { const int cl = qrow + p.q_pos0 + 1; lim = cl < lim ? cl : lim; }
+      const int rel = lim - key0, rel_lo = kv_start - key0;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = kt * 32 + (r & 3) + 8 * (r >> 2);
+          sc[kt][r] = (kk < rel && kk >= rel_lo) ? sc[kt][r] : NEG_BIG;
+        }
+    }
+    float mx = max3(sc[0][0], sc[0][1], sc[0][2]);
+#pragma unroll
+    for (int r = 3; r + 1 < 16; r += 2) mx = max3(mx, sc[0][r], sc[0][r + 1]);
+    mx = max3(mx, sc[0][15], sc[1][0]);
+#pragma unroll
+    for (int r = 1; r + 1 < 16; r += 2) mx = max3(mx, sc[1][r], sc[1][r + 1]);
+    mx = max2(mx, sc[1][15]);
+    mx = max_xor32_raw(mx);
+    if (__any((mx - m_run) * p.c > RESCALE_LOG2)) {
+      const float m_new = max2(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] *= alpha;
+    }
+    const float nmc = -m_run * p.c;
+    frag_t pf[2][2];
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        f32x8 e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          e[j] = __builtin_amdgcn_exp2f(fmaf(sc[kt][8 * s2 + j], p.c, nmc));
+          psum += e[j];
+        }
+        pf[kt][s2] = __builtin_convertvector(e, frag_t);
+      }
+    l_run += psum;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r_lo = kt * 32 + s2 * 16 + v_row_lo, r_hi = r_lo + 8;
+        const char* rb_lo = Vs + r_lo * 256 + v_byte;
+        const char* rb_hi = Vs + r_hi * 256 + v_byte;
+        const int sw_lo = swz_b(r_lo), sw_hi = swz_b(r_hi);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const s16x4 lo = tr_read(rb_lo + (((4 * db + v_ch_lo) ^ sw_lo) << 4));
+          const s16x4 hi = tr_read(rb_hi + (((4 * db + v_ch_lo) ^ sw_hi) << 4));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = mfma32(__builtin_bit_cast(frag_t, cat), pf[kt][s2], o[db]);
+        }
+      }
+  }
+
+  // ---- finalize.  o[db][r] = O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hh][query qc]
+  const float l = sum_xor32(l_run);
+  if (wave_active && qrow < p.Sq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    T* op = (T*)p.O + b * p.o_sb + hq * p.o_sh + (int64_t)qrow * p.o_sr + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typename V8<T>::half_type h4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h4[r] = fromf<T>(o[db][4 * g + r] * inv);
+        *reinterpret_cast<typename V8<T>::half_type*>(op + db * 32 + g * 8) = h4;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Decode attention, one wave per (64-key split, kv head, sequence).  Same transposed MFMA formulation as the prefill kernel
 // with the n_rep query heads of the kv group as the 16 "queries", but latency-shaped: ALL global loads of the tile (K as
 // MFMA A fragments straight to registers, V for the LDS transpose image, Q, RoPE table row) are issued at once -- one HBM
@@ -622,6 +833,9 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
   return 0;
 }
 
+int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
+void attn_set_v2(int v) { g_attn_v2 = v; }
+
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.q_heads % a.kv_heads == 0, "q_heads must be a multiple of kv_heads");
   OM_CHECK(a.Sq > 0 && a.Skv > 0 && a.batch > 0, "empty attention");
@@ -636,6 +850,28 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
     if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, 64>), grid, dim3(256), 0, s, p);
     else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, 64>), grid, dim3(256), 0, s, p);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  const int n_rep = a.q_heads / a.kv_heads;
+  if (g_attn_v2 && n_rep == 1) {                 // MHA (ViT): 4 waves = 128 queries of one head
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false>), grid, dim3(256), 0, s, p);
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false>), grid, dim3(256), 0, s, p);
+    else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (g_attn_v2 && n_rep <= 8) {                 // GQA: the n_rep query heads of one kv head x 32 queries share every K / V tile
+    const dim3 g2(cdiv(a.Sq, 32), a.kv_heads, a.batch);
+#define OM_A2(NW_)                                                                                                       \
+  do {                                                                                                                   \
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);            \
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);     \
+    else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }                                               \
+  } while (0)
+    switch (n_rep) { case 2: OM_A2(2); break; case 3: OM_A2(3); break; case 4: OM_A2(4); break; case 5: OM_A2(5); break;
+                     case 6: OM_A2(6); break; case 7: OM_A2(7); break; default: OM_A2(8); break; }
+#undef OM_A2
     OM_LAUNCH_CHECK();
     return 0;
   }

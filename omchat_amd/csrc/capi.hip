@@ -18,6 +18,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 5) { gemm_set_autotune(value); return 0; }
   if (key == 4) { model_set_ar_min_rows(value); return 0; }
   if (key == 6) { model_set_pack_replica(value); return 0; }
+  if (key == 8) { attn_set_v2(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }

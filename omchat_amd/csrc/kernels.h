@@ -106,6 +106,7 @@ struct AttnArgs {
   int head_dim;             // 128 (0 = 128) or 64 (InternViT-300M)
 };
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s);
+void attn_set_v2(int v);
 
 // decode: one query token per sequence, q heads grouped per kv head; split-KV partials + merge.
 struct AttnDecodeArgs {

@@ -202,16 +202,30 @@ def peer_selftest(peer, rank, size, iters=48, sizes=(16, 3584 * 4, 3 * 3584 * 4,
     from . import _lib
     lib = _lib.lib()
     bad = 0
+    err = C.c_int(0)
+
+    def one(it, nbytes, dt, code):
+        n = nbytes // (4 if dt == torch.float32 else 2)
+        i = torch.arange(n, device="cuda", dtype=torch.int64)
+        val = lambda r: (((i * 7 + it * 13 + r * 5) % 31) - 15).to(torch.float32)      # |sum over 8 ranks| <= 120: exact in bf16
+        x = val(rank).to(dt).contiguous()
+        _lib.check(lib.omchat_peer_allreduce(peer, _lib.ptr(x), n, code, _lib.cur_stream()))
+        ref = sum(val(r) for r in range(size))
+        return int((x.to(torch.float32) != ref).sum())
+
+    # one small call first, checked at once: a group that cannot talk (a peer that never arrives, a mapping that does not work across
+    # these devices) shows as a barrier timeout here, and the test must cost ONE timeout, not one per call
+    bad += one(0, 3584 * 4, torch.float32, _lib.F32)
+    _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
+    if err.value or bad:
+        return False, dict(mismatched_elements=bad, timeout=bool(err.value), iters=0)
     for it in range(iters):
         for nbytes in sizes:
             for dt, code in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16)):
-                n = nbytes // (4 if dt == torch.float32 else 2)
-                i = torch.arange(n, device="cuda", dtype=torch.int64)
-                val = lambda r: (((i * 7 + it * 13 + r * 5) % 31) - 15).to(torch.float32)      # |sum over 8 ranks| <= 120: exact in bf16
-                x = val(rank).to(dt).contiguous()
-                _lib.check(lib.omchat_peer_allreduce(peer, _lib.ptr(x), n, code, _lib.cur_stream()))
-                ref = sum(val(r) for r in range(size))
-                bad += int((x.to(torch.float32) != ref).sum())
-    err = C.c_int(0)
+                bad += one(it, nbytes, dt, code)
+        if it in (0, 1, 7):                                  # early exits: never sit through hundreds of timeouts
+            _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
+            if err.value or bad:
+                return False, dict(mismatched_elements=bad, timeout=bool(err.value), iters=it + 1)
     _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
     return bad == 0 and err.value == 0, dict(mismatched_elements=bad, timeout=bool(err.value), iters=iters)

@@ -247,6 +247,35 @@ def test_attn_prefill(gpu_lib, dt, b, Sq, Skv, Hq, Hkv, causal, lens):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Sq,Skv,Hq,Hkv,causal,lens", [
+    (1, 257, 257, 28, 4, 1, None),           # the Qwen2-7B head pattern: 7 query heads per kv head in one workgroup
+    (2, 333, 333, 8, 1, 1, [333, 130]),      # group of 8 = the widest workgroup
+    (1, 96, 96, 6, 2, 0, None),              # GQA without the causal mask
+    (1, 70, 70, 2, 2, 1, None),              # MHA + causal
+    (1, 64, 64, 5, 5, 0, None),              # exactly one kv tile
+])
+def test_attn_prefill_second_generation_shapes(gpu_lib, dt, b, Sq, Skv, Hq, Hkv, causal, lens):
+    """more head groupings for the 32x32x16 kernel, and the first-generation kernel (tuning key 8 = 0) on the same inputs"""
+    q = rnd(randn((b, Sq, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, Skv, 128), 2), dt); v = rnd(randn((b, Hkv, Skv, 128), 3), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    dl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    scale = 128 ** -0.5
+    ref = _attn_ref(q, k, v, scale, causal, 0, lens or [Skv] * b)
+    try:
+        for gen in (1, 0):
+            gpu_lib.omchat_op_set_tuning(8, gen)
+            out = torch.full((b, Sq, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Sq, Skv, Hq, Hkv, ptr(dl), causal, 0, scale, None))
+            sync()
+            for i in range(b):
+                n = Sq if lens is None else lens[i]
+                assert torch.isfinite(out[i, :n].float()).all()
+                assert rel(out[i, :n], ref[i, :n]) < TOL[dt], (gen, rel(out[i, :n], ref[i, :n]))
+    finally:
+        gpu_lib.omchat_op_set_tuning(8, 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_attn_prefill_softmax_spike(gpu_lib, dt):
     """forces the running max to jump late (online-softmax rescale path, cdna guide rule 26)"""
     Sq = Skv = 256
