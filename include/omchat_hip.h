@@ -285,6 +285,9 @@ void omchat_peer_destroy(omchat_peer* p);
  * or when the context has no RCCL communicator */
 int omchat_ctx_set_peer(omchat_ctx* ctx, omchat_peer* peer, size_t max_bytes, int all_sizes);
 int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls);
+/* in-place sum of a caller buffer over the context's tensor-parallel group (same transports as the model's own all-reduces); used for
+ * the data-parallel vision tower: every rank encodes its share of the tiles into a zero-filled feature buffer and the sum gathers them */
+int omchat_ctx_allreduce(omchat_ctx* ctx, void* buf, size_t count, int dtype, void* stream);
 
 /* Test seam: replace the RCCL all-reduce of a tensor-parallel context by a caller-supplied function (sum over ranks,
  * in place, `count` elements of dtype OMCHAT_F16/BF16/F32, ordered on `stream`).  Lets the whole TP dataflow be

@@ -103,6 +103,7 @@ _SIGS = {
     "omchat_peer_error": (_i, [_vp, C.POINTER(_i)]),
     "omchat_peer_destroy": (None, [_vp]),
     "omchat_ctx_set_peer": (_i, [_vp, _vp, _sz, _i]),
+    "omchat_ctx_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
     "omchat_ctx_comm_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
 }
 EXPORTS = sorted(_SIGS)

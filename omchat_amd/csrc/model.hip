@@ -1194,6 +1194,14 @@ extern "C" int omchat_ctx_set_peer(omchat_ctx* ctx, omchat_peer* peer, size_t ma
   return 0;
 }
 
+// in-place sum over the tensor-parallel group of a caller buffer, through the context's transports (peer kernels / RCCL); the buffer
+// must be 16-byte aligned with >= 16 bytes of slack after `count` elements when the byte count is not a multiple of 16
+extern "C" int omchat_ctx_allreduce(omchat_ctx* ctx, void* buf, size_t count, int dtype, void* stream) {
+  OM_CHECK(ctx && buf, "null argument");
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == OMCHAT_F32, "bad dtype");
+  return ctx->allreduce_any(buf, count, dtype, (hipStream_t)stream);
+}
+
 extern "C" int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls) {
   OM_CHECK(ctx, "null ctx");
   if (peer_calls) *peer_calls = ctx->n_ar_peer;

@@ -116,6 +116,25 @@ class Engine:
         """attach a peer all-reduce group member (tp.init_peer) for the tensor-parallel sums of this context"""
         check(self.lib.omchat_ctx_set_peer(self.h, peer, max_bytes, int(all_sizes)))
 
+    def allreduce(self, t):
+        """in-place sum of a contiguous CUDA tensor (engine dtype or fp32, byte count a multiple of 16) over the tensor-parallel group"""
+        if self.tp_size > 1:
+            check(self.lib.omchat_ctx_allreduce(self.h, ptr(t), t.numel(), _lib.dtype_code(t.dtype), cur_stream()))
+        return t
+
+    def encode_images_dp(self, tower, pixels, select_layer=-1):
+        """Data-parallel vision tower (optional throughput mode): `tower` is a REPLICATED vision-only Engine (tp_size 1)
+        on this rank; the tiles are dealt to the ranks in contiguous shares, every rank encodes its share into a zero-filled feature
+        buffer and one all-reduce over this (tensor-parallel) engine's transports gathers them: x + 0 is exact, so every rank ends with
+        the bits a single tower would have produced.  Replaces ~90 ViT-sized all-reduces per sample by one."""
+        torch = _torch()
+        n = pixels.shape[0]
+        out = torch.zeros(n, self.ntok, self.cfg.text["hidden_size"], dtype=self.torch_dtype, device=self.device)
+        lo, hi = self.tp_rank * n // self.tp_size, (self.tp_rank + 1) * n // self.tp_size
+        if hi > lo:
+            out[lo:hi] = tower.encode_images(pixels[lo:hi], select_layer)
+        return self.allreduce(out)
+
     def comm_stats(self):
         a, b = C.c_long(0), C.c_long(0)
         check(self.lib.omchat_ctx_comm_stats(self.h, C.byref(a), C.byref(b)))

@@ -131,17 +131,23 @@ def _proc_tp_engine(rank, size, port, q):
         for _ in range(6):
             tok, _ = e.decode_step(tok)
             toks.append(int(tok[0]))
+        # data-parallel tower: replicated vision-only context, tiles dealt to the ranks, one all-reduce gathers the features
+        tower = Engine(cfg, dtype="bf16", max_seq=32, max_batch=1, max_tiles=2, text=False)
+        tower.fill_synthetic(13)
+        px3 = torch.from_numpy(synth.pixels(3, 56, 2))
+        feats_dp = e.encode_images_dp(tower, px3)
         torch.cuda.synchronize()
         err = C.c_int(0)
         _lib.check(_lib.lib().omchat_peer_error(peer, C.byref(err)))
         st = e.comm_stats()
         dist.barrier()
-        q.put((rank, feats.float().cpu().numpy(), logits.float().cpu().numpy(), toks, err.value, st))
+        q.put((rank, feats.float().cpu().numpy(), logits.float().cpu().numpy(), toks, err.value, st, feats_dp.float().cpu().numpy()))
+        tower.close()
         e.close()
         _lib.lib().omchat_peer_destroy(peer)
     except BaseException as e:      # noqa
         import traceback
-        q.put((rank, None, traceback.format_exc(), None, 1, None))
+        q.put((rank, None, traceback.format_exc(), None, 1, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -198,4 +204,7 @@ def test_tp2_engine_processes_over_peer_allreduce_equal_tp1(gpu_lib):
     assert rel(torch.from_numpy(res[0][1]), feats) < TOL_DEEP["bf16"]
     full = np.concatenate([res[0][2], res[1][2]], axis=-1)
     assert rel(torch.from_numpy(full), logits) < TOL_DEEP["bf16"]
+    # the data-parallel tower gathers exactly the bits one tower produces (x + 0 is exact), on both ranks
+    f3 = e.encode_images(torch.from_numpy(synth.pixels(3, 56, 2))); torch.cuda.synchronize()
+    assert np.array_equal(res[0][6], f3.float().cpu().numpy()) and np.array_equal(res[1][6], res[0][6])
     e.close()

@@ -2,17 +2,16 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 600 python -m pytest tests/test_gpu_peer.py -q -x > gpurun_out/l_tests1.log 2>&1; echo "peer tests rc=$?"; tail -5 gpurun_out/l_tests1.log
 show() { python - "$1" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[1], {k:d.get(k) for k in ('value','ttft_ms_p50','vit_ms_p50','prefill_ms_p50','vit_mfma_frac','prefill_mfma_frac','decode_ms_per_token_p50')})
-    if 'configs2' in d: print('  configs2', {k:d['configs2'].get(k) for k in ('tokens_per_sec','vit_ms_p50','prefill_ms_p50','decode_ms_per_step_p50','vit_mfma_frac','prefill_mfma_frac','decode_hbm_frac')})
+    print(sys.argv[1], {k:d.get(k) for k in ('n_gpus','value','tokens_match_tp1','vit_data_parallel','transport','comm_stats')}, d['config']['parallelism'])
+    print('   tp1', d.get('tp1_check'))
 except Exception as e: print('parse fail', sys.argv[1], e)
 PY
 }
-timeout 900 python bench.py --steps 3 --warmup 1 --gen 64 --no-fp8 --no-cpu-baseline > gpurun_out/k_v2.json 2> gpurun_out/k_v2.err; echo "v2 rc=$?"; show gpurun_out/k_v2.json
-timeout 900 python bench.py --steps 3 --warmup 1 --gen 64 --no-fp8 --no-cpu-baseline --tuning 8=0 > gpurun_out/k_v1.json 2> gpurun_out/k_v1.err; echo "v1 rc=$?"; show gpurun_out/k_v1.json
-timeout 900 python bench.py --steps 3 --warmup 1 --gen 64 --no-fp8 --no-cpu-baseline > gpurun_out/k_v2b.json 2> gpurun_out/k_v2b.err; echo "v2 again rc=$?"; show gpurun_out/k_v2b.json
-timeout 2400 python -m pytest tests -m gpu -q -x --durations=10 > gpurun_out/k_alltests.log 2>&1; echo "all gpu tests rc=$?"
-tail -22 gpurun_out/k_alltests.log
+OMCHAT_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus 2 --steps 1 --warmup 0 --gen 34 --workload configs1 --vit both > gpurun_out/l_both.json 2> gpurun_out/l_both.err; echo "both rc=$?"; show gpurun_out/l_both.json; tail -3 gpurun_out/l_both.err
+OMCHAT_BENCH_OVERSUBSCRIBE=1 timeout 600 python bench.py --gpus 2 --steps 1 --warmup 0 --gen 34 --workload configs1 --vit dp > gpurun_out/l_dp.json 2> gpurun_out/l_dp.err; echo "dp rc=$?"; show gpurun_out/l_dp.json; tail -3 gpurun_out/l_dp.err
+OMCHAT_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 2 --steps 1 --warmup 1 --gen 8 --batch2 8 --steps2 1 > gpurun_out/l_both2.json 2> gpurun_out/l_both2.err; echo "both workloads rc=$?"; show gpurun_out/l_both2.json; tail -3 gpurun_out/l_both2.err
