@@ -751,6 +751,28 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
   int ns = (len + KV_TILE - 1) / KV_TILE;
   ns = ns < nsplit ? ns : nsplit;
   const float* w = ws + (size_t)(b * q_heads + h) * nsplit * WS_STRIDE;
+  if (ns <= 64) {
+    // short contexts (<= 4096 keys): this launch is pure latency, so every global load is issued before anything is reduced -- one
+    // round trip instead of three (split maxima, then weights, then the partial outputs).  Same arithmetic, same summation order.
+    float v[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) v[s] = w[(size_t)(s < ns ? s : 0) * WS_STRIDE + d];
+    if (d < 64) {
+      const float m_s = d < ns ? w[(size_t)d * WS_STRIDE + 128] : NEG_BIG;
+      const float l_s = d < ns ? w[(size_t)d * WS_STRIDE + 129] : 0.f;
+      const float m = wave_max(m_s);
+      const float f = d < ns ? exp2f((m_s - m) * c) : 0.f;
+      const float lsum = wave_sum(f * l_s);
+      fw[d] = f;
+      if (d == 0) red[0] = lsum;
+    }
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) a += fw[s] * v[s];
+    O[pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d)] = fromf<T>(a / red[0]);
+    return;
+  }
   float acc = 0.f, ltot = 0.f, m_run = NEG_BIG;
   for (int s0 = 0; s0 < ns; s0 += 1024) {                 // chunks of up to 1024 splits (64k keys)
     const int n = ns - s0 < 1024 ? ns - s0 : 1024;
@@ -896,7 +918,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
           a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh};
   const bool kv8 = a.k_scale != nullptr;
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
-  OM_CHECK(!a.rope || (a.pos && a.k_new && a.v_new && a.kv_len), "fused RoPE decode needs pos, k_new, v_new and kv_len");
+  OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);

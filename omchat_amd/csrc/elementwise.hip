@@ -195,6 +195,15 @@ __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int l
   const int nchunk = H >> 3;
   float xv[NORM_MAXC][8];
   float ss = 0.f;
+  // the norm weights do not depend on the reduction: their loads join the first (and only) round trip of this latency-bound launch
+  v8 wv[NORM_MAXC];
+  if (w) {
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) wv[i] = ld8<T>(w + c * 8);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NORM_MAXC; ++i) {
     const int c = threadIdx.x + i * NORM_THREADS;
@@ -229,10 +238,9 @@ __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int l
   for (int i = 0; i < NORM_MAXC; ++i) {
     const int c = threadIdx.x + i * NORM_THREADS;
     if (c < nchunk) {
-      const v8 wv = ld8<T>(w + c * 8);
       v8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(xv[i][j] * inv));
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[i][j]) * rnd<T>(xv[i][j] * inv));
       st8<T>(pack_nb ? xn + packed_x_index(row, c * 8, pack_nb) : nr + c * 8, o);
     }
   }

@@ -116,7 +116,7 @@ struct AttnDecodeArgs {
   void* O; int64_t o_sb, o_sh;                  // [b, q_heads, 128]
   int batch, q_heads, kv_heads;
   int L;                                        // kv length used when kv_len == null
-  const int* kv_len;                            // optional device [batch]
+  const int* kv_len;                            // optional device [batch]; null = every sequence holds exactly L keys (one dependent load less)
   float scale;
   float* ws; size_t ws_bytes;                   // workspace for partials
   // optional fused RoPE + KV append of the token being decoded (replaces rope_kv for S = 1): q is rotated in registers,

@@ -989,7 +989,10 @@ static int ensure_packed(omchat_ctx* ctx) {
 
 // One decode step on stream s.  Lmax = upper bound of the key count (sizes the split-KV grid; the kernels read the true
 // lengths from d_len).  Every argument is a context pointer or a step-invariant scalar when called for graph capture.
-static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, float* logits, int32_t* next_tokens, hipStream_t s, bool allow_prof) {
+// exact_len: every sequence holds exactly Lmax keys after this step (eager launches only): the attention launches then take the length
+// as a kernel argument instead of loading d_len first -- one dependent memory round trip less in two latency-bound launches per layer.
+static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, float* logits, int32_t* next_tokens, hipStream_t s, bool allow_prof,
+                       bool exact_len = false) {
   const omchat_config& c = ctx->c;
   const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   const bool lead = ctx->tp_rank == 0;
@@ -1003,14 +1006,19 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   const int pk = (b > 1 && b <= 32 && H % 64 == 0 && qd % 64 == 0 && It % 64 == 0) ? (b > 16 ? 2 : 1) : 0;
   const bool wpk = pk && ctx->pk_ready;
   static const omchat_ctx::DecLayerP noneP{};
+  auto gemv_args = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int R, int N, const void* bias, const void* resid, int epi,
+                       int ks, const void* W8, const float* sc, const void* WP, bool ypk) {
+    GemvArgs g{X, ldx, W, K, Y, ldy, R, N, K, bias, resid, H, epi, 0, ks};
+    if (f8 && W8) { g.W = W8; g.w_scale = sc; }
+    if (pk) { g.x_packed = 1; g.y_packed = ypk && epi == EPI_SWIGLU; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
+    return g;
+  };
   auto gemv = [&](const void* X, int ldx, const void* W, int K, void* Y, int ldy, int N, const void* bias, const void* resid, int epi,
                   const void* W8 = nullptr, const float* sc = nullptr, const void* WP = nullptr, bool ypk = false) -> int {
     for (int r0 = 0; r0 < b; r0 += 32) {
       const int R = std::min(32, b - r0);
-      GemvArgs g{(const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, K, bias,
-                 resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, H, epi, 0, 0};
-      if (f8 && W8) { g.W = W8; g.w_scale = sc; }
-      if (pk) { g.x_packed = 1; g.y_packed = ypk; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
+      const GemvArgs g = gemv_args((const char*)X + (size_t)r0 * ldx * 2, ldx, W, K, (char*)Y + (size_t)r0 * ldy * 2, ldy, R, N, bias,
+                                   resid ? (const char*)resid + (size_t)r0 * H * 2 : nullptr, epi, 0, W8, sc, WP, ypk);
       TRY(launch_gemv(ctx->dt, g, s));
     }
     return 0;
@@ -1019,9 +1027,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   auto gemv_partial = [&](const void* X, int ldx, const void* W, int K, int ks, const void* W8 = nullptr, const float* sc = nullptr,
                           const void* WP = nullptr) -> int {
     OM_CHECK(b <= 32, "split-K decode path handles b <= 32");
-    GemvArgs g{X, ldx, W, K, ctx->tw_part, H, b, H, K, nullptr, nullptr, 0, EPI_PARTIAL, 0, ks};
-    if (f8 && W8) { g.W = W8; g.w_scale = sc; }
-    if (pk) { g.x_packed = 1; if (wpk && WP) { g.W = WP; g.w_packed = 1; } }
+    const GemvArgs g = gemv_args(X, ldx, W, K, ctx->tw_part, H, b, H, nullptr, nullptr, EPI_PARTIAL, ks, W8, sc, WP, false);
     TRY(launch_gemv(ctx->dt, g, s));
     // tensor parallelism: the slices hold this rank's partial sums; they are all-reduced in fp32 (<= 3 x 3584 floats at batch 1,
     // latency-bound like any small message) and the same fused residual + RMSNorm kernel then runs identically on every rank
@@ -1056,6 +1062,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     a.ws = ctx->tw_attn_ws; a.ws_bytes = ctx->tw_attn_ws_bytes;
     a.rope = ctx->rope; a.rope_max = c.max_seq; a.pos = ctx->d_pos;
     a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
+    if (exact_len) a.kv_len = nullptr;
     if (ctx->fp8_kv && ctx->kv8_valid) {
       // fp8 KV cache: rotate q / k and append to the 16-bit cache with the prefill's kernel, quantise the new row, then attend over e4m3
       // keys and values (two small launches more per layer than the fused 16-bit path; this mode is for long contexts)
@@ -1144,7 +1151,12 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   int Lmax = 0;
   OM_CHECK(!ctx->left_padded, "decode after a left-padded prefill is refused: the reference positions such a batch inconsistently "
                               "between prefill (arange(S)) and decode (sum(mask) - 1); pad on the right (DESIGN.md section 7)");
-  for (int i = 0; i < b; ++i) { OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill"); Lmax = std::max(Lmax, ctx->h_len[i] + 1); }
+  bool same_len = true;
+  for (int i = 0; i < b; ++i) {
+    OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill");
+    Lmax = std::max(Lmax, ctx->h_len[i] + 1);
+    same_len = same_len && ctx->h_len[i] == ctx->h_len[0];
+  }
   OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
   hipStream_t s = (hipStream_t)stream;
   if (b > 1 && b <= 32) TRY(ensure_packed(ctx));      // first batched step (or after a weight reload): build the packed replica
@@ -1153,7 +1165,7 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   // so that the HIP-event brackets of the dominant kernel are still recorded inside the timed region
   const bool graph = ctx->graph_on && ctx->tp_size == 1 && b <= 32 && !(ctx->prof_on && ctx->graph_steps % 8 == 0);
   if (!graph) {
-    TRY(decode_body(ctx, tokens, b, Lmax, logits, next_tokens, s, true));
+    TRY(decode_body(ctx, tokens, b, Lmax, logits, next_tokens, s, true, same_len));
   } else {
     const bool f8 = ctx->fp8_decode && b == 1;
     omchat_ctx::DecodeGraph& g = ctx->graphs[b * 4 + (f8 ? 2 : 0) + ((ctx->fp8_kv && ctx->kv8_valid) ? 1 : 0)];

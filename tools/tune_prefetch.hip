@@ -1,0 +1,75 @@
+// Tuning harness (not product): does touching the next GEMV's weights from an otherwise idle kernel (the 5 us residual+RMSNorm /
+// attention-merge launches of batch-1 decode) make the GEMV that follows faster?  Measures a streaming read of W bytes (a) cold
+// (L2 + Infinity Cache flushed by reading 1.2 GB of something else), (b) after a prefetch kernel touched the head of every block's
+// slice with the same block -> address mapping (so the same XCD's L2 holds it), (c) after a prefetch with a shifted mapping (another
+// XCD's L2: Infinity Cache only).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/tune_prefetch.hip -o /tmp/tune_prefetch && /tmp/tune_prefetch
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// block b reads the first len16 16-byte words of its slice [b * per16, (b + 1) * per16): 256 threads x 16 B per step, 4 loads in flight.
+template <bool NT>
+__global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ p, size_t per16, size_t len16, size_t total16, unsigned* out, int rot) {
+  const size_t blk = (blockIdx.x + rot) % gridDim.x;
+  const u32x4* q = p + blk * per16;
+  size_t n = len16;
+  if (blk * per16 + n > total16) n = blk * per16 < total16 ? total16 - blk * per16 : 0;
+  u32x4 acc = {0, 0, 0, 0};
+  size_t i = threadIdx.x;
+  for (; i + 768 < n; i += 1024) {
+    u32x4 a, b, c, d;
+    if (NT) {
+      a = __builtin_nontemporal_load(q + i); b = __builtin_nontemporal_load(q + i + 256);
+      c = __builtin_nontemporal_load(q + i + 512); d = __builtin_nontemporal_load(q + i + 768);
+    } else { a = q[i]; b = q[i + 256]; c = q[i + 512]; d = q[i + 768]; }
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n; i += 256) acc ^= q[i];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+int main() {
+  const size_t FL = (size_t)1200 << 20;
+  void *flush, *w; unsigned* out;
+  hipMalloc(&flush, FL); hipMemset(flush, 1, FL);
+  hipMalloc(&w, (size_t)300 << 20); hipMemset(w, 2, (size_t)300 << 20);
+  hipMalloc(&out, 64);
+  hipEvent_t e0, e1, e2; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+  struct { const char* name; size_t bytes; int grid; } shapes[] = {{"qkv", (size_t)4608 * 3584 * 2, 288}, {"o", (size_t)3584 * 3584 * 2, 224},
+                                                                    {"o/512", (size_t)3584 * 3584 * 2, 512}, {"gateup", (size_t)37888 * 3584 * 2, 592},
+                                                                    {"gateup/1024", (size_t)37888 * 3584 * 2, 1024}, {"down", (size_t)3584 * 18944 * 2, 896}};
+  const double pre_mb[] = {0, 8, 16, 24, 32, 48, 64, 128};
+  for (auto& sh : shapes) {
+    const size_t n16 = sh.bytes / 16, per16 = (n16 + sh.grid - 1) / sh.grid;
+    printf("%s: %.1f MB, grid %d\n", sh.name, sh.bytes / 1e6, sh.grid);
+    for (int nt = 0; nt < 2; ++nt)
+      for (int rot = 0; rot <= 3; rot += 3)
+        for (double pm : pre_mb) {
+          if (pm * 1e6 > sh.bytes * 1.3) continue;
+          if (pm == 0 && rot) continue;
+          size_t len16 = (size_t)(pm * 1e6 / 16 / sh.grid);
+          if (len16 > per16) len16 = per16;
+          float t_pre = 0, t_read = 0;
+          const int it = 6;
+          for (int r = 0; r < it; ++r) {
+            hipLaunchKernelGGL(read_kernel<false>, dim3(1024), dim3(256), 0, 0, (const u32x4*)flush, FL / 16 / 1024, FL / 16 / 1024, FL / 16, out, 0);
+            hipEventRecord(e0, 0);
+            if (len16) hipLaunchKernelGGL(read_kernel<false>, dim3(sh.grid), dim3(256), 0, 0, (const u32x4*)w, per16, len16, n16, out, rot);
+            hipEventRecord(e1, 0);
+            if (nt) hipLaunchKernelGGL(read_kernel<true>, dim3(sh.grid), dim3(256), 0, 0, (const u32x4*)w, per16, per16, n16, out, 0);
+            else hipLaunchKernelGGL(read_kernel<false>, dim3(sh.grid), dim3(256), 0, 0, (const u32x4*)w, per16, per16, n16, out, 0);
+            hipEventRecord(e2, 0);
+            hipEventSynchronize(e2);
+            float a, b; hipEventElapsedTime(&a, e0, e1); hipEventElapsedTime(&b, e1, e2);
+            if (r) { t_pre += a * 1e3f / (it - 1); t_read += b * 1e3f / (it - 1); }
+          }
+          printf("  nt=%d map=%s prefetch %5.1f MB: prefetch %6.1f us, read %6.1f us (%5.2f TB/s)\n", nt, rot ? "other-xcd" : "same-xcd", len16 * 16.0 * sh.grid / 1e6, t_pre,
+                 t_read, sh.bytes / t_read / 1e6);
+          fflush(stdout);
+        }
+  }
+  if (hipGetLastError() != hipSuccess) printf("HIP ERROR\n");
+  return 0;
+}
