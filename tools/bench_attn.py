@@ -8,7 +8,8 @@ it = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 if len(sys.argv) > 2:
     lib.omchat_op_set_tuning(8, int(sys.argv[2]))      # 0 = first-generation 16x16x32 kernel
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
-for name, b, S, Hq, Hkv, causal in [("vit", 3, 1025, 25, 25, 0), ("vit24", 24, 1025, 25, 25, 0), ("dec", 1, 3584, 28, 4, 1), ("dec_b4", 4, 3584, 28, 4, 1)]:
+for name, b, S, Hq, Hkv, causal in [("vit", 3, 1025, 25, 25, 0), ("vit24", 24, 1025, 25, 25, 0), ("dec", 1, 3584, 28, 4, 1), ("dec_b4", 4, 3584, 28, 4, 1),
+                                 ("dec_b16", 16, 3584, 28, 4, 1), ("long16k", 1, 16384, 28, 4, 1), ("long33k", 1, 33280, 28, 4, 1)]:
     if only and name not in only:
         continue
     q = torch.randn(b, S, Hq, 128, device="cuda").bfloat16(); k = torch.randn(b, Hkv, S, 128, device="cuda").bfloat16(); v = torch.randn_like(k)

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-timeout 600 python tools/ab_decode2.py 0,8,9,10,12,13,14,15,11 eager 2>&1 | grep "skip="
+echo "--- gen 3 (staggered)"; timeout 300 python tools/bench_attn.py 5 3 dec,dec_b16,long16k,long33k
+echo "--- gen 1"; timeout 300 python tools/bench_attn.py 5 1 dec,dec_b16,long16k,long33k

@@ -8,7 +8,7 @@
 #include <vector>
 void omchat_set_error(const std::string& s) { fprintf(stderr, "ERR %s\n", s.c_str()); }
 
-template <typename T, int NTILE, int NB, int WAVES, int UNROLL, bool XPACK, bool WPACK, bool NTL>
+template <typename T, int NTILE, int NB, int WAVES, int UNROLL, bool XPACK, bool WPACK, bool NTL, bool XFAKE = false>
 __global__ __launch_bounds__(WAVES * 64) void sk_kernel(const T* __restrict__ W, const T* __restrict__ X, float* __restrict__ Y, int N, int K, int b,
                                                         int ksplit) {
   typedef typename V8<T>::type frag_t;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(WAVES * 64) void sk_kernel(const T* __restrict__ W,
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const T* p = XPACK ? xbase[nb] + (size_t)(c * 2 + h) * NB * 512 : xbase[nb] + c * 64 + h * 32;
+          const T* p = XPACK ? xbase[nb] + (size_t)((XFAKE ? (c & 1) : c) * 2 + h) * NB * 512 : xbase[nb] + c * 64 + h * 32;      // XFAKE: x stays in L1 (bound without x traffic; results wrong)
           xf[u][nb][h] = *reinterpret_cast<const frag_t*>(p);
         }
     }
@@ -86,10 +86,10 @@ __global__ __launch_bounds__(WAVES * 64) void sk_kernel(const T* __restrict__ W,
 
 struct Shape { const char* name; int N, K, ks; };
 
-template <int NTILE, int NB, int WAVES, int UNROLL, bool XPACK, bool WPACK, bool NTL>
+template <int NTILE, int NB, int WAVES, int UNROLL, bool XPACK, bool WPACK, bool NTL, bool XFAKE = false>
 float run(const Shape& sh, int b, const std::vector<void*>& W, void* X, void* Y, int iters) {
   dim3 grid((sh.N / 16 + NTILE - 1) / NTILE, sh.ks);
-  auto k = sk_kernel<bf16, NTILE, NB, WAVES, UNROLL, XPACK, WPACK, NTL>;
+  auto k = sk_kernel<bf16, NTILE, NB, WAVES, UNROLL, XPACK, WPACK, NTL, XFAKE>;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(WAVES * 64), 0, 0, (const bf16*)W[i % W.size()], (const bf16*)X, (float*)Y, sh.N, sh.K, b, sh.ks);
   hipEventRecord(e0, 0);
@@ -128,6 +128,8 @@ int main() {
       RUN(2, 2, 4, 8, true, true, true);
       RUN(1, 2, 4, 8, true, true, true);
       RUN(1, 2, 8, 8, true, true, true);
+      { float us = run<2, 2, 8, 4, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=2 waves=8 unroll=4 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
+      { float us = run<4, 2, 4, 2, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=4 waves=4 unroll=2 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
     }
     {
       const int b = 1;
