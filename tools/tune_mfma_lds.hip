@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // SHAPE 0: 16x16x32, acc 8x4 tiles of 16x16; SHAPE 1: 32x32x16, acc 4x2 tiles of 32x32.  LDSR: ds_read_b128 per step (24 = the GEMM).
 #ifndef RANDOM_DATA
-#define RANDOM_DATA 1
+#define RANDOM_DATA 2
 #endif
 template <int SHAPE, int LDSR>
 __global__ __launch_bounds__(512) void k(float* out, int steps) {
@@ -20,7 +20,12 @@ __global__ __launch_bounds__(512) void k(float* out, int steps) {
   // pseudo-random bf16 pairs in (-1, 1): operand toggling (and so power / clocks) like real activations, not like constants
   for (int i = threadIdx.x; i < 32768; i += 512) {
     unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-    const unsigned lo = 0x3f00u | (h & 0x80ffu), hi = 0x3f00u | ((h >> 16) & 0x80ffu);      // sign + 0.5..1.0 magnitudes
+    // two bf16 values uniform in (-1, 1): random sign, mantissa AND exponent bits (RANDOM_DATA 2), or fixed exponent (RANDOM_DATA 1)
+    unsigned lo, hi;
+    if (RANDOM_DATA == 2) {
+      const float f0 = ((h & 0xffffu) / 32768.0f - 1.0f), f1 = ((h >> 16) / 32768.0f - 1.0f);
+      lo = __builtin_bit_cast(unsigned, f0) >> 16; hi = __builtin_bit_cast(unsigned, f1) >> 16;
+    } else { lo = 0x3f00u | (h & 0x80ffu); hi = 0x3f00u | ((h >> 16) & 0x80ffu); }
     reinterpret_cast<unsigned*>(smem)[i] = RANDOM_DATA ? (lo | (hi << 16)) : 0x3c003c00u;
   }
   __syncthreads();
