@@ -177,7 +177,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * always takes the MFMA form, 0 = batch 1 takes the whole-row streaming form; key 4: row count from which a tensor-parallel
  * row-parallel projection is pipelined against its all-reduce in 2 chunks (3x: 4 chunks), default 1024; key 5: 0 = GEMM tile
  * shapes from the cost model instead of the first-use measurement; key 6: 0 = batched decode steps (2 <= b <= 32) read the
- * row-major weights instead of building the packed replica (+ one more copy of the decoder weights)) */
+ * row-major weights instead of building the packed replica (+ one more copy of the decoder weights); key 8: 0 = first-generation
+ * 16x16x32 prefill attention kernel; key 9: 0 = tensor-parallel decode over the peer transport keeps the all-reduce of the split-K
+ * slices and the residual + RMSNorm as two launches instead of omchat_peer_resid_rmsnorm) */
 int omchat_op_set_tuning(int key, int value);
 /* GEMM tile choices are measured on first use of a (dtype, epilogue, ceil(M/256), N, K) class; load / dump persist them as text
  * (returns the number of entries, -1 when the file cannot be opened); omchat_gemm_tune_runs = measurements done by this process */
@@ -208,6 +210,11 @@ int omchat_op_quant_fp8(int dtype, const void* W, int N, int K, void* W8, float*
 int omchat_op_gemv_fp8(int dtype, const void* X, const void* W8, const float* scale, void* Y, int N, int K, const void* bias,
                        const void* resid, int epi, int out_f32, int ksplit, void* stream);
 int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream);
+/* the decode step's fused residual add + RMSNorm (modeling_qwen2.py:283-296 + 247-252): x[rows, H] = T(x + T(sum_s part[s])) in place,
+ * part = fp32 split-K slices [ks][rows][H] of the projection, then xn = T(w * T(x * rsqrt(mean(x^2) + eps))) (w == NULL: skip);
+ * pack_nb != 0 writes xn in the packed x layout of the batched GEMV */
+int omchat_op_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H,
+                            float eps, int pack_nb, void* stream);
 int omchat_op_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total,
                          float eps, float q_scale, void* stream);
 /* q [b,Sq,Hq,128], k/v [b,Hkv,Skv,128] (cache layout), out [b,Sq,Hq,128]; kv_len device int32 [b] or NULL */
@@ -278,6 +285,13 @@ int omchat_peer_set_mode(omchat_peer* p, int fast, size_t oneshot_max_bytes, int
 size_t omchat_peer_capacity(omchat_peer* p);
 /* in-place sum over the ranks, `count` elements of OMCHAT_F16 / BF16 / F32; buf 16-byte aligned, byte count % 16 == 0 */
 int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, int dtype, void* stream);
+/* Tensor-parallel decode, the all-reduce fused with its consumer: part = this rank's fp32 split-K slices [ks][rows][H] of a row-parallel
+ * projection (ks <= 8, rows <= 128, ks * rows * H * 4 <= capacity).  On return (stream order) x[rows, H] = T(x + T(sum over ranks and
+ * slices)) on every rank and, when w != NULL, xn = T(w * T(x * rsqrt(mean(x^2) + eps))) (pack_nb != 0: in the packed x layout of the
+ * batched GEMV).  Same bits as omchat_peer_allreduce(part) followed by the local residual + RMSNorm launch, one launch instead of two.
+ * (reference: the residual adds and RMSNorms of transformers modeling_qwen2.py:283-296, 247-252) */
+int omchat_peer_resid_rmsnorm(omchat_peer* p, int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn,
+                              int rows, int H, float eps, int pack_nb, void* stream);
 /* synchronises the device; *err_out = 1 when a barrier spin timed out (a peer died or never arrived) since the last call */
 int omchat_peer_error(omchat_peer* p, int* err_out);
 void omchat_peer_destroy(omchat_peer* p);

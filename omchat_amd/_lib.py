@@ -74,6 +74,7 @@ _SIGS = {
     "omchat_op_quant_fp8": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
     "omchat_op_gemv_fp8": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "omchat_op_rmsnorm": (_i, [_i, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "omchat_op_resid_rmsnorm": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "omchat_op_vit_qknorm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "omchat_op_attn_prefill": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp]),
     "omchat_op_attn_prefill_d": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp]),
@@ -100,6 +101,7 @@ _SIGS = {
     "omchat_peer_set_mode": (_i, [_vp, _i, _sz, _i]),
     "omchat_peer_capacity": (_sz, [_vp]),
     "omchat_peer_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "omchat_peer_resid_rmsnorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "omchat_peer_error": (_i, [_vp, C.POINTER(_i)]),
     "omchat_peer_destroy": (None, [_vp]),
     "omchat_ctx_set_peer": (_i, [_vp, _vp, _sz, _i]),

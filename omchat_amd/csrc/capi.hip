@@ -19,6 +19,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 4) { model_set_ar_min_rows(value); return 0; }
   if (key == 6) { model_set_pack_replica(value); return 0; }
   if (key == 8) { attn_set_v2(value); return 0; }
+  if (key == 9) { model_set_fuse_peer_norm(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }
@@ -77,6 +78,12 @@ extern "C" int omchat_op_quant_rows_fp8(int dtype, const void* x, const void* no
   return launch_quant_rows_q8(dtype, x, H, y8, H, scale, rows, H, S(stream));
 }
 
+// decode: x = T(x + T(sum_s part[s])) in place, xn = RMSNorm(x) * w; part fp32 [ks][rows][H] (the split-K slices of the skinny GEMM)
+extern "C" int omchat_op_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H,
+                                       float eps, int pack_nb, void* stream) {
+  OM_CHECK(x && part, "null argument");
+  return launch_resid_rmsnorm(dtype, x, ldx, part, ks, w, xn, ldn, rows, H, eps, S(stream), pack_nb);
+}
 extern "C" int omchat_op_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, float eps, void* stream) {
   return launch_rmsnorm(dtype, x, H, w, y, H, rows, H, eps, S(stream));
 }

@@ -173,6 +173,102 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_twoshot_kernel(PeerK k, voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tensor-parallel decode: the all-reduce of the split-K slices fused with the residual add + RMSNorm that consumes them.
+// Unfused, a row-parallel projection of a decode step is  GEMV (fp32 slices [ks][rows][H]) -> one-shot all-reduce of the slices ->
+// resid_rmsnorm_kernel (sums the ks slices, residual, norm): three latency-bound launches.  Here the second and third are one: workgroup
+// `row` writes its rank's slices of that row through to its slot, meets the same workgroup of every peer at the flag barrier, then reads
+// EVERY rank's slices and finishes the row.  Summation order = the unfused one (per slice s: ranks 0..n-1 from 0.f; then the slices in
+// order), so every rank holds the same bits as with omchat_peer_allreduce + launch_resid_rmsnorm (tests/test_gpu_peer.py).
+// Slot layout [s][row][H] fp32 (= the GEMV's own layout), one parity per call as for the all-reduce kernels.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FN_THREADS = 256;
+constexpr int FN_MAXC = 8;            // chunks of 8 elements per thread: H <= 16384
+
+template <typename T>
+__global__ __launch_bounds__(FN_THREADS) void peer_resid_rmsnorm_kernel(PeerK k, int parity, T* x, int ldx, const float* part, int ks, int rows,
+                                                                      const T* w, T* xn, int ldn, int H, float eps, int pack_nb) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[FN_THREADS / 64];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  const size_t slot = PEER_FLAG_BYTES + (size_t)parity * 2 * k.cap;
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(k.base[k.rank] + slot, k.cap);
+  // independent of the exchange: residual row and norm weights join the first round trip
+  v8 xi[FN_MAXC], wv[FN_MAXC];
+#pragma unroll
+  for (int i = 0; i < FN_MAXC; ++i) {
+    const int c = threadIdx.x + i * FN_THREADS;
+    if (c < nchunk) {
+      xi[i] = ld8<T>(x + (size_t)row * ldx + c * 8);
+      if (w) wv[i] = ld8<T>(w + c * 8);
+    }
+  }
+  // my slices of this row -> my slot (write-through)
+  for (int s = 0; s < ks; ++s) {
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>(part + ((size_t)s * rows + row) * H);
+    const int off = (int)((((size_t)s * rows + row) * H) * 4);
+    for (int q = threadIdx.x; q < H / 4; q += FN_THREADS) __builtin_amdgcn_raw_buffer_store_b128(src[q], mine, off + (q << 4), 0, AUX_SYS);
+  }
+  peer_barrier(k);
+  float xv[FN_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < FN_MAXC; ++i) {
+    const int c = threadIdx.x + i * FN_THREADS;
+    if (c < nchunk) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      for (int s = 0; s < ks; ++s) {
+        const int off = (int)((((size_t)s * rows + row) * H + c * 8) * 4);
+        u32x4_t v0[PEER_MAX_RANKS], v1[PEER_MAX_RANKS];
+#pragma unroll
+        for (int r = 0; r < PEER_MAX_RANKS; ++r)
+          if (r < k.size) {
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(k.base[r] + slot, k.cap);
+            v0[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX_SYS);
+            v1[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, AUX_SYS);
+          }
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < PEER_MAX_RANKS; ++r)
+          if (r < k.size) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t[j] += __uint_as_float(v0[r][j]); t[4 + j] += __uint_as_float(v1[r][j]); }
+          }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += t[j];
+      }
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rnd<T>(tof(xi[i][j]) + rnd<T>(a[j]));
+        xv[i][j] = v; o[j] = fromf<T>(v); ss += v * v;
+      }
+      st8<T>(x + (size_t)row * ldx + c * 8, o);
+    }
+  }
+  if (!w) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < FN_THREADS / 64; ++q) tot += red[q];
+  const float inv = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < FN_MAXC; ++i) {
+    const int c = threadIdx.x + i * FN_THREADS;
+    if (c < nchunk) {
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[i][j]) * rnd<T>(xv[i][j] * inv));
+      st8<T>(pack_nb ? xn + packed_x_index(row, c * 8, pack_nb) : xn + (size_t)row * ldn + c * 8, o);
+    }
+  }
+}
+
 }  // namespace
 
 struct omchat_peer {
@@ -284,6 +380,31 @@ extern "C" int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, in
     OM_LAUNCH_CHECK();
     done += piece;
   }
+  return 0;
+}
+
+// x[rows, H] = T(x + T(sum over ranks and slices of part)) in place on every rank, then xn = RMSNorm(x) * w (w == NULL: skip): the fused
+// form of  omchat_peer_allreduce(part) + the residual / RMSNorm launch  for split-K slices part = fp32 [ks][rows][H] (ks <= 8)
+extern "C" int omchat_peer_resid_rmsnorm(omchat_peer* p, int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn,
+                                         int rows, int H, float eps, int pack_nb, void* stream) {
+  OM_CHECK(p && x && part, "null argument");
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16, "bad dtype");
+  OM_CHECK(p->size > 1, "single-rank group: use the local kernel");
+  for (int r = 0; r < p->size; ++r) OM_CHECK(p->base[r], "peer group is not connected");
+  OM_CHECK(rows >= 1 && rows <= PEER_MAX_BLOCKS && ks >= 1 && ks <= 8, "1 <= rows <= 128, 1 <= ks <= 8");
+  OM_CHECK(H % 8 == 0 && H <= FN_THREADS * FN_MAXC * 8 && ldx % 8 == 0 && (!w || (xn && ldn % 8 == 0)), "H % 8, H <= 16384, ld % 8");
+  OM_CHECK((size_t)ks * rows * H * 4 <= p->cap, "slices exceed the peer slot capacity");
+  OM_CHECK(pack_nb == 0 || (rows <= 16 * pack_nb && H % 64 == 0), "packed output: rows <= 16 * NB, H % 64 == 0");
+  PeerK k{};
+  for (int r = 0; r < p->size; ++r) k.base[r] = (char*)p->base[r];
+  k.ctr = p->ctr; k.err = p->err; k.rank = p->rank; k.size = p->size; k.fast = p->fast; k.cap = p->cap;
+  const int parity = (int)(p->calls++ & 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMCHAT_F16)
+    hipLaunchKernelGGL(peer_resid_rmsnorm_kernel<f16>, dim3(rows), dim3(FN_THREADS), 0, s, k, parity, (f16*)x, ldx, part, ks, rows, (const f16*)w, (f16*)xn, ldn, H, eps, pack_nb);
+  else
+    hipLaunchKernelGGL(peer_resid_rmsnorm_kernel<bf16>, dim3(rows), dim3(FN_THREADS), 0, s, k, parity, (bf16*)x, ldx, part, ks, rows, (const bf16*)w, (bf16*)xn, ldn, H, eps, pack_nb);
+  OM_LAUNCH_CHECK();
   return 0;
 }
 

@@ -69,6 +69,9 @@ struct Route {
 
 }  // namespace
 
+int g_fuse_peer_norm = 1;      // omchat_op_set_tuning key 9: 0 = tensor-parallel decode keeps the all-reduce and the residual + RMSNorm as two launches (A/B)
+void model_set_fuse_peer_norm(int v) { g_fuse_peer_norm = v; }
+
 struct omchat_ctx {
   omchat_config c;
   int dt = OMCHAT_BF16;
@@ -194,6 +197,20 @@ struct omchat_ctx {
     ncclResult_t r = ncclAllReduce(buf, buf, count, t, ncclSum, comm, s);
     if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return 3; }
     return 0;
+  }
+  // decode: sum of the split-K slices over the ranks + residual + RMSNorm.  With the peer transport that is ONE launch
+  // (omchat_peer_resid_rmsnorm, same bits); with the hook or RCCL: all-reduce of the slices, then the local kernel.
+  long n_fused_norm = 0;
+  int reduce_resid_rmsnorm(void* x, int ldx, float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps, int pack_nb,
+                           hipStream_t s) {
+    const size_t bytes = (size_t)ks * rows * H * 4;
+    if (tp_size > 1 && !hook && peer && g_fuse_peer_norm && rows <= 128 && bytes <= omchat_peer_capacity(peer) &&
+        (bytes <= peer_max || !comm || peer_all)) {
+      ++n_fused_norm;
+      return omchat_peer_resid_rmsnorm(peer, dt, x, ldx, part, ks, w, xn, ldn, rows, H, eps, pack_nb, s);
+    }
+    if (tp_size > 1) { const int rc = allreduce_any(part, (size_t)ks * rows * H, OMCHAT_F32, s); if (rc) return rc; }
+    return launch_resid_rmsnorm(dt, x, ldx, part, ks, w, xn, ldn, rows, H, eps, s, pack_nb);
   }
   int allreduce(void* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, dt, s); }
   int allreduce_f32(float* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, OMCHAT_F32, s); }
@@ -1029,9 +1046,8 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     OM_CHECK(b <= 32, "split-K decode path handles b <= 32");
     const GemvArgs g = gemv_args(X, ldx, W, K, ctx->tw_part, H, b, H, nullptr, nullptr, EPI_PARTIAL, ks, W8, sc, WP, false);
     TRY(launch_gemv(ctx->dt, g, s));
-    // tensor parallelism: the slices hold this rank's partial sums; they are all-reduced in fp32 (<= 3 x 3584 floats at batch 1,
-    // latency-bound like any small message) and the same fused residual + RMSNorm kernel then runs identically on every rank
-    if (ctx->tp_size > 1) TRY(ctx->allreduce_f32(ctx->tw_part, (size_t)ks * b * H, s));
+    // tensor parallelism: the slices hold this rank's partial sums; reduce_resid_rmsnorm sums them over the ranks in fp32 (<= 3 x 3584
+    // floats at batch 1, latency-bound like any small message) together with the residual + RMSNorm, identically on every rank
     return 0;
   };
   const bool fused = b <= 32;
@@ -1079,7 +1095,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     TRY(launch_attn_decode(ctx->dt, a, s));
     if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
-      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+      TRY(ctx->reduce_resid_rmsnorm(x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, pk, s));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -1097,7 +1113,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (fused) {
       TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd, P.wd));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
-      TRY(launch_resid_rmsnorm(ctx->dt, x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+      TRY(ctx->reduce_resid_rmsnorm(x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, pk, s));
     } else if (ctx->tp_size == 1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID));
     } else {
@@ -1216,7 +1232,7 @@ extern "C" int omchat_ctx_allreduce(omchat_ctx* ctx, void* buf, size_t count, in
 
 extern "C" int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls) {
   OM_CHECK(ctx, "null ctx");
-  if (peer_calls) *peer_calls = ctx->n_ar_peer;
+  if (peer_calls) *peer_calls = ctx->n_ar_peer + ctx->n_fused_norm;
   if (rccl_calls) *rccl_calls = ctx->n_ar_rccl;
   return 0;
 }

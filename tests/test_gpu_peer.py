@@ -107,7 +107,63 @@ def _proc_selftest(rank, size, port, q, fast=False):
         dist.destroy_process_group()
 
 
-def _proc_tp_engine(rank, size, port, q):
+def _proc_fused_norm(rank, size, port, q):
+    """omchat_peer_resid_rmsnorm == omchat_peer_allreduce(slices) + the local residual + RMSNorm kernel, bit for bit, on every rank"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        lib = _lib.lib()
+        peer = tp.init_peer(rank, size, cap_bytes=8 << 20, max_blocks=8)
+        ok, detail = True, ""
+        cases = [("bf16", 1, 3584, 3, 0), ("f16", 1, 3584, 8, 0), ("bf16", 5, 448, 1, 0), ("bf16", 32, 3584, 8, 2), ("f16", 12, 1024, 2, 1),
+                 ("bf16", 1, 3584, 3, 0)]          # the first case again: slot parity / epoch bookkeeping after mixed calls
+        for i, (dt, rows, H, ks, nb) in enumerate(cases):
+            tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+            code = _lib.BF16 if dt == "bf16" else _lib.F16
+            g = lambda seed: torch.Generator().manual_seed(seed)
+            x0 = torch.randn(rows, H, generator=g(7 + i)).to(tdt)                       # replicated residual stream
+            w = (torch.randn(H, generator=g(9 + i)) * 0.1 + 1).to(tdt)
+            part = torch.randn(ks, rows, H, generator=g(1000 * rank + i)) * 0.3         # this rank's slices
+            n_out = rows * H if nb == 0 else 16 * nb * H
+            outs = []
+            for fused in (True, False, True):
+                x = x0.cuda().clone(); pt = part.cuda().clone(); xn = torch.zeros(n_out, dtype=tdt, device="cuda")
+                if fused:
+                    _lib.check(lib.omchat_peer_resid_rmsnorm(peer, code, _lib.ptr(x), H, _lib.ptr(pt), ks, _lib.ptr(w.cuda()), _lib.ptr(xn), H, rows, H,
+                                                             1e-6, nb, _lib.cur_stream()))
+                else:
+                    _lib.check(lib.omchat_peer_allreduce(peer, _lib.ptr(pt), ks * rows * H, _lib.F32, _lib.cur_stream()))
+                    _lib.check(lib.omchat_op_resid_rmsnorm(code, _lib.ptr(x), H, _lib.ptr(pt), ks, _lib.ptr(w.cuda()), _lib.ptr(xn), H, rows, H, 1e-6, nb,
+                                                           _lib.cur_stream()))
+                torch.cuda.synchronize()
+                outs.append((x.cpu(), xn.cpu()))
+            for j in (1, 2):
+                if not (torch.equal(outs[0][0], outs[j][0]) and torch.equal(outs[0][1], outs[j][1])):
+                    ok, detail = False, f"case {i} {dt} rows={rows} H={H} ks={ks} nb={nb}: fused != unfused (run {j})"
+            if not torch.isfinite(outs[0][1].float()).all():
+                ok, detail = False, f"case {i}: non-finite"
+            gathered = [None] * size
+            dist.all_gather_object(gathered, outs[0][0].float().numpy().tobytes())      # every rank must hold the same bits
+            if any(gb != gathered[0] for gb in gathered):
+                ok, detail = False, f"case {i}: ranks differ"
+        err = C.c_int(0)
+        _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
+        if err.value:
+            ok, detail = False, "barrier timeout"
+        dist.barrier()
+        lib.omchat_peer_destroy(peer)
+        q.put((rank, ok, detail))
+    except BaseException as e:      # noqa
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _proc_tp_engine(rank, size, port, q, fuse=1):
     import torch.distributed as dist
     from omchat_amd.engine import Engine
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -117,6 +173,7 @@ def _proc_tp_engine(rank, size, port, q):
     try:
         cfg = tiny(q_heads=7, kv_heads=1, heads_v=3)
         peer = tp.init_peer(rank, size, cap_bytes=4 << 20, max_blocks=8)
+        _lib.check(_lib.lib().omchat_op_set_tuning(9, fuse))      # 1: decode sums + residual + RMSNorm in one peer launch; 0: two launches
         e = Engine(cfg, dtype="bf16", max_seq=128, max_batch=2, max_tiles=2, tp_rank=rank, tp_size=size, comm=None)
         e.set_peer(peer, 0, all_sizes=True)
         e.fill_synthetic(13)                   # device-side sharding of the TP = 1 synthetic values
@@ -172,6 +229,14 @@ def _spawn(target, size, timeout=240, extra=()):
     return sorted(res, key=lambda x: x[0])
 
 
+@pytest.mark.parametrize("size", [2, 4])
+def test_peer_fused_reduce_resid_rmsnorm_equals_two_launches(gpu_lib, size):
+    res = _spawn(_proc_fused_norm, size)
+    assert len(res) == size
+    for rank, ok, detail in res:
+        assert ok, (rank, detail)
+
+
 @pytest.mark.parametrize("size,fast", [(2, False), (4, False), (8, False), (4, True)])
 def test_peer_allreduce_across_processes_ipc(gpu_lib, size, fast):
     res = _spawn(_proc_selftest, size, extra=(fast,))
@@ -192,6 +257,10 @@ def test_tp2_engine_processes_over_peer_allreduce_equal_tp1(gpu_lib):
         assert r[5]["peer_allreduces"] > 0 and r[5]["rccl_allreduces"] == 0
     assert np.array_equal(res[0][1], res[1][1])
     assert res[0][3] == res[1][3]
+    # the fused decode launch (all-reduce + residual + RMSNorm) changes nothing: same token ids with it switched off
+    res2 = _spawn(_proc_tp_engine, 2, extra=(0,))
+    assert res2[0][1] is not None, res2[0][2]
+    assert res2[0][3] == res[0][3] and res2[1][3] == res[0][3]
     cfg = tiny(q_heads=7, kv_heads=1, heads_v=3)
     e = Engine(cfg, dtype="bf16", max_seq=128, max_batch=2, max_tiles=2)
     e.fill_synthetic(13)
