@@ -37,6 +37,7 @@ struct AttnP {
   void* k_cache_w; void* v_cache_w;                          // writable views of K / V (same strides as K / V)
   int rope_max;
   const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;      // fp8 KV cache (decode only)
+  int tpw;                // decode: key tiles per wave (attn_decode_multi_kernel): a split is tpw x KV_TILE keys
 };
 
 // 8 e4m3 bytes -> 8 T (exact widening)
@@ -739,16 +740,184 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode attention for LARGE grids (batched decode): one wave walks p.tpw consecutive 64-key tiles of its (kv head, sequence) with a
+// running max / sum, so the partials that are written here and read back by the merge (3.6 KB per 32 KB of K / V with one tile per
+// wave) shrink by that factor.  The one-tile kernel above keeps every load of its tile in flight at once (a single sequence has few
+// waves: latency is everything); here thousands of waves hide each other's latency, so a tile's K and V loads share ONE register
+// block -- K, S^T = K Q^T, then V into the same registers while the softmax runs -- which keeps the running output tile resident
+// without spilling.  16-bit cache, fused RoPE + append as in the one-tile kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ __attribute__((aligned(256))) char Vs[KV_TILE * 256];
+  const int lane = threadIdx.x, fc = lane & 15, fg = lane >> 4;
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  const int key_base = split * KV_TILE * p.tpw;
+  float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
+  if (key_base >= kv_len) {                   // empty split (uniform): neutral partial
+    if (fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
+    return;
+  }
+  const bool fuse = p.rope != nullptr;
+  const int pp = kv_len - 1;
+  const int pt = pp < p.rope_max ? pp : p.rope_max - 1;
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
+  const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
+
+  frag_t qf[4];
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
+    if (fuse) {
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
+        const frag_t lo = qf[ds], hi = qf[ds + 2];
+        qf[ds] = rope_chunk<T>(lo, hi, cs, false);
+        qf[ds + 2] = rope_chunk<T>(hi, lo, cs, true);
+      }
+    }
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;
+  const int vswz = ((vrow_lo & 7) << 1);
+
+  for (int tt = 0; tt < p.tpw; ++tt) {
+    const int key0 = key_base + tt * KV_TILE;
+    if (key0 >= kv_len) break;                // uniform
+    frag_t kv[16];                            // K fragments [kt][ds] first, then the V image rows of the same tile
+    f32x4 s[4];
+    {
+      bool kfresh[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int key = key0 + kt * 16 + fc;
+        kfresh[kt] = fuse && key >= pp;
+        const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) kv[kt * 4 + ds] = ld8<T>(src + ds * 32 + fg * 8);
+      }
+      if (fuse && key0 + KV_TILE > pp) {      // only the tile that owns the new position (uniform)
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            if (kfresh[kt]) {
+              const frag_t kl = kv[kt * 4 + ds], kh = kv[kt * 4 + ds + 2];
+              kv[kt * 4 + ds] = rope_chunk<T>(kl, kh, cs, false);
+              kv[kt * 4 + ds + 2] = rope_chunk<T>(kh, kl, cs, true);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          if (key0 + kt * 16 + fc == pp) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds)
+              st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ds * 32 + fg * 8, kv[kt * 4 + ds]);
+          }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kv[kt * 4 + ds], qf[ds], s[kt]);
+      }
+    }
+    // ---- V of the same tile into the K registers; the softmax below runs under these loads
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = key0 + i * 4 + fg;
+      const bool fresh = fuse && key >= pp;
+      const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+      kv[i] = ld8<T>(src + fc * 8);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? s[kt][r] : NEG_BIG;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = max_xor32(max_xor16(mx));
+    if (tt > 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      l_run *= alpha;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) o[dn] *= alpha;
+      mx = m_new;
+    }
+    m_run = mx;
+    const float mc = mx * p.c;
+    float psum = 0.f;
+    frag_t pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typedef float f32x8 __attribute__((ext_vector_type(8)));
+      f32x8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
+        psum += e[j];
+      }
+      pf[ks] = __builtin_convertvector(e, frag_t);
+    }
+    l_run += psum;
+    if (tt > 0) __syncthreads();              // the previous tile's transposed reads are done
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 4 + fg;
+      *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ ((row & 7) << 1)) << 4)) = kv[i];
+      if (fuse && key0 + row == pp)
+        st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + fc * 8, kv[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) {
+        const int ch = (2 * dn + (tp >> 1)) ^ vswz;
+        const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+        const s16x4 lo = tr_read(a0);
+        const s16x4 hi = tr_read(a0 + 16 * 256);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
+      }
+  }
+  const float l = sum_xor32(sum_xor16(l_run));
+  if (fc < n_rep) {
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
+    if (fg == 0) { wsb[128] = m_run; wsb[129] = l; }
+  }
+}
+
 // merge split-KV partials: one 128-thread block per (sequence, head).  Phase 1: thread s owns split s (max, weight);
 // phase 2: thread d sums its column over the splits with independent (unrolled) loads.
 template <typename T>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
-                                                         T* O, int64_t o_sb, int64_t o_sh, int pack_nb) {
+                                                         T* O, int64_t o_sb, int64_t o_sh, int pack_nb, int split_keys) {
   __shared__ float fw[1024];
   __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const int len = kv_len ? kv_len[b] : L;
-  int ns = (len + KV_TILE - 1) / KV_TILE;
+  int ns = (len + split_keys - 1) / split_keys;
   ns = ns < nsplit ? ns : nsplit;
   const float* w = ws + (size_t)(b * q_heads + h) * nsplit * WS_STRIDE;
   if (ns <= 64) {
@@ -855,6 +1024,8 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
   return 0;
 }
 
+int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
+void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
 void attn_set_v2(int v) { g_attn_v2 = v; }
 
@@ -911,12 +1082,17 @@ size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len) {
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   OM_CHECK(a.q_heads % a.kv_heads == 0 && a.q_heads / a.kv_heads <= 16, "group size must be <= 16");
   OM_CHECK(a.L > 0 && a.batch > 0, "empty attention");
-  const int nsplit = cdiv(a.L, KV_TILE);
+  // key tiles per wave: one 64-key tile keeps the most waves in flight (single sequences); once the grid is several waves per SIMD deep,
+  // 2 or 4 tiles per wave (attn_decode_multi_kernel, 16-bit cache) cut the partials written here and read back by the merge by that factor
+  const bool kv8 = a.k_scale != nullptr;
+  const long waves1 = (long)cdiv(a.L, KV_TILE) * a.kv_heads * a.batch;
+  int tpw = kv8 ? 1 : (waves1 >= 6144 ? 4 : (waves1 >= 3072 ? 2 : 1));
+  if (g_attn_tpw > 0 && !kv8) tpw = g_attn_tpw;
+  const int nsplit = cdiv(a.L, KV_TILE * tpw);
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
-          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh};
-  const bool kv8 = a.k_scale != nullptr;
+          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh, tpw};
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
   OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
@@ -924,12 +1100,14 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
     if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
+    else if (tpw > 1) hipLaunchKernelGGL(attn_decode_multi_kernel<f16>, grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
-    hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
+    hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else if (dtype == OMCHAT_BF16) {
     if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
+    else if (tpw > 1) hipLaunchKernelGGL(attn_decode_multi_kernel<bf16>, grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
-    hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb);
+    hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

@@ -318,12 +318,18 @@ def test_attn_decode(gpu_lib, dt, b, Hq, Hkv, cap, lens):
     ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
     dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
     scale = 128 ** -0.5
-    _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), scale, ptr(ws), wsb, None))
-    sync()
     kk = torch.nan_to_num(k); vv = torch.nan_to_num(v)
     ref = _attn_ref(q[:, None], kk, vv, scale, 0, 0, lens)[:, 0]
-    assert torch.isfinite(out.float()).all()
-    assert rel(out, ref) < TOL[dt], rel(out, ref)
+    try:
+        for tpw in (0, 1, 2, 4):                      # key tiles per wave: automatic, then each forced split size (running max / sum inside a wave)
+            gpu_lib.omchat_op_set_tuning(10, tpw)
+            out.fill_(float("nan")); ws.fill_(float("nan"))
+            _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), scale, ptr(ws), wsb, None))
+            sync()
+            assert torch.isfinite(out.float()).all(), tpw
+            assert rel(out, ref) < TOL[dt], (tpw, rel(out, ref))
+    finally:
+        gpu_lib.omchat_op_set_tuning(10, 0)
 
 
 @pytest.mark.parametrize("dt", DTS)
