@@ -241,3 +241,37 @@ def test_batched_decode_packed_path_vs_oracle(gpu_lib, dt, replica):
             e.close(); e1.close()
     finally:
         gpu_lib.omchat_op_set_tuning(6, 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_decode_attention_tiles_per_wave_in_the_model(gpu_lib, dt):
+    """the multi-tile decode attention kernel (several 64-key tiles per wave, running max / sum, fused RoPE + KV append in the tile that
+    owns the new position) inside the decode step: contexts that cross tile and split boundaries, ragged lengths, 4 steps; logits against
+    the one-tile kernel (tuning key 10)"""
+    cfg = tiny(q_heads=4, kv_heads=2)
+    sd = {k: v for k, v in synth.state_dict(cfg, 5).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    b, S = 4, 200
+    x = torch.randn(b, S, 256, generator=torch.Generator().manual_seed(11)) * 0.5
+    lens = [200, 127, 129, 64]              # new positions 200.. (4th tile), 127 (last row of a tile), 129, 64 (first row of a tile)
+    runs = {}
+    try:
+        for tpw in (1, 2, 4):
+            gpu_lib.omchat_op_set_tuning(10, tpw)
+            e = Engine(cfg, dtype=dt, max_seq=256, max_batch=b, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x, lens)
+            tok = torch.arange(b) % 300 + 7
+            out = []
+            for _ in range(4):
+                tok, lg = e.decode_step(tok, want_logits=True)
+                out.append((tok.cpu().clone(), lg.float().cpu().clone()))
+            sync()
+            runs[tpw] = out
+            e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(10, 0)
+    for tpw in (2, 4):
+        for step in range(4):
+            assert torch.isfinite(runs[tpw][step][1]).all()
+            r = rel(runs[tpw][step][1], runs[1][step][1])
+            assert r < (2e-2 if dt == "bf16" else 4e-3), (tpw, step, r)      # another split of the same sum: 16-bit rounding of P and of the partial merge
