@@ -19,4 +19,7 @@ for f in glob.glob(R+"/gpurun_out/$TAG/p*/**/*counter_collection.csv", recursive
 for g,d in agg.items():
     print("kernel/grid", g)
     for k,v in sorted(d.items()): print(f"  {k:36s} {sum(v)/len(v):16.0f}")
+    m={k:sum(v)/len(v) for k,v in d.items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:      # GUI summed over 8 XCDs, MFMA busy over 1024 SIMDs
+        print(f"  -> MFMA pipe busy = {m['SQ_VALU_MFMA_BUSY_CYCLES']/(m['GRBM_GUI_ACTIVE']*128):.3f} of the kernel's cycles")
 PY

@@ -19,5 +19,6 @@ for g,d in sorted(agg.items()):
     v={k:sum(x)/len(x) for k,x in d.items()}
     for k in sorted(v): print(f"  {k:30s} {v[k]:16.0f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-        print(f"  -> MFMA busy / (GUI_ACTIVE * 1024 SIMDs) = {v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']*1024):.3f}")
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs: busy fraction = busy / (GUI / 8 * 1024)
+        print(f"  -> MFMA pipe busy = {v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']*128):.3f} of the kernel's cycles ({v['GRBM_GUI_ACTIVE']/8/1e3:.0f} k cycles per XCD)")
 PY
