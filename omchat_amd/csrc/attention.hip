@@ -424,14 +424,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   float m_run = M_FLOOR, l_run = 0.f;
 
   // ---- staging: piece = i * NT + tid -> LDS row = piece >> 4, physical chunk = piece & 15 (lane-linear destination, permuted source)
+  // A whole tile (every key < kv_len) is addressed as  wave-uniform tile base + a 32-bit lane offset computed once  (the per-tile 64-bit
+  // row * stride products were ~60 of the ~200 VALU instructions a key tile costs, and VALU time adds to MFMA time here: profiles/
+  // r02_b_pmc_attn.txt); only the last, partial tile clamps its rows (masked keys must stay finite) the long way.
+  unsigned koff[ROUNDS], voff[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int piece = i * NT + tid, row = piece >> 4, pc = piece & 15;
+    const int ch = pc ^ swz_b(row);
+    koff[i] = (unsigned)row * (unsigned)(p.k_sr * 2) + ch * 16;
+    voff[i] = (unsigned)row * (unsigned)(p.v_sr * 2) + ch * 16;
+  }
   auto issue_tile = [&](int t, int buf) {
     char* const Kw = smem + buf * BUF;
     char* const Vw = Kw + TILE;
+    if ((t + 1) * KV_TILE <= kv_len) {                                     // whole tile (uniform)
+      const char* Kt = (const char*)(Kg + (int64_t)t * KV_TILE * p.k_sr);
+      const char* Vt = (const char*)(Vg + (int64_t)t * KV_TILE * p.v_sr);
+#pragma unroll
+      for (int i = 0; i < ROUNDS; ++i) {
+        if ((i + 1) * NT <= NPIECE || i * NT + wave * 64 < NPIECE) {       // whole waves only (wave-uniform)
+          __builtin_amdgcn_global_load_lds((gptr_t)(Kt + koff[i]), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(Vt + voff[i]), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) {
-      if ((i + 1) * NT <= NPIECE || i * NT + wave * 64 < NPIECE) {         // whole waves only (wave-uniform)
+      if ((i + 1) * NT <= NPIECE || i * NT + wave * 64 < NPIECE) {
         const int piece = i * NT + tid, row = piece >> 4, pc = piece & 15;
-        int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;    // masked keys must stay finite
+        int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;
         const int ch = pc ^ swz_b(row);
         __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)kr * p.k_sr + ch * 8), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)kr * p.v_sr + ch * 8), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
@@ -507,7 +530,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
     }
     const float nmc = -m_run * p.c;
     frag_t pf[2][2];
-    float psum = 0.f;
+    // two scores per instruction (v_pk_fma_f32 / v_pk_add_f32): the softmax's VALU instructions add to the MFMA time on this SIMD
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c2 = {p.c, p.c}, nmc2 = {nmc, nmc};
+    f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -515,13 +541,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
         typedef float f32x8 __attribute__((ext_vector_type(8)));
         f32x8 e;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          e[j] = __builtin_amdgcn_exp2f(fmaf(sc[kt][8 * s2 + j], p.c, nmc));
-          psum += e[j];
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2 sv = {sc[kt][8 * s2 + j], sc[kt][8 * s2 + j + 1]};
+          const f32x2 x = __builtin_elementwise_fma(sv, c2, nmc2);
+          const f32x2 ev = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          e[j] = ev[0]; e[j + 1] = ev[1];
+          psum2 += ev;
         }
         pf[kt][s2] = __builtin_convertvector(e, frag_t);
       }
-    l_run += psum;
+    l_run += psum2[0] + psum2[1];
 
     // ---- O^T += V^T P^T
 #pragma unroll

@@ -1,7 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-mkdir -p gpurun_out
-timeout 1500 bash tools/pmc_gemm.sh > gpurun_out/pmc_gemm_summary.txt 2>&1; echo "pmc_gemm rc=$?"
-timeout 1500 bash tools/pmc_attn.sh 1 pmc_attn_r02b > gpurun_out/pmc_attn_summary.txt 2>&1; echo "pmc_attn rc=$?"
-tail -30 gpurun_out/pmc_gemm_summary.txt
-tail -40 gpurun_out/pmc_attn_summary.txt
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "attn or mha" 2>&1 | tail -2
+for rep in 1 2 3; do
+for v in new new2; do
+  echo "--- $v (rep $rep)"; OMCHAT_LIB=$PWD/ab_lib/$v.so timeout 300 python tools/bench_attn.py 20 1 vit,vit24,dec,dec_b4,long16k 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
+done
+done
