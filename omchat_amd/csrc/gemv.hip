@@ -209,6 +209,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pk_kernel(GemvP p) {
     else { int r = tl * 16 + fr; r = r < p.N ? r : p.N - 1; wbase[t] = W + (size_t)r * p.ldw + fg * 8; }
   }
   const T* xbase = (const T*)p.X + lane * 8;
+  // lanes whose batch row (16 nb + fr) does not exist load nothing: the x re-read of every workgroup (half of the CU-side traffic at
+  // b = 32, tools/tune_gemv32.hip) then scales with b instead of with the 16-row padding of the packed layout
+  bool xrow[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) xrow[nb] = nb * 16 + fr < p.b;
 
   f32x4 acc[NTILE][NB];
 #pragma unroll
@@ -231,7 +236,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pk_kernel(GemvP p) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) xf[u][nb][h] = ld8<T>(xbase + ((size_t)(c * 2 + h) * NB + nb) * 512);
+        for (int h = 0; h < 2; ++h) {
+          frag_t z;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] = fromf<T>(0.f);
+          xf[u][nb][h] = xrow[nb] ? ld8<T>(xbase + ((size_t)(c * 2 + h) * NB + nb) * 512) : z;
+        }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {

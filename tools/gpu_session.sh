@@ -1,9 +1,6 @@
 #!/bin/bash
-# scratch driver for one gpurun call (rewritten per experiment): the round's closing verification
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/full_gpu_tests.log 2>&1; echo "gpu tests rc=$?"
-grep -a "passed\|failed" gpurun_out/full_gpu_tests.log | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 1200 bash tools/collect_profiles.sh r02_c > gpurun_out/collect.log 2>&1; echo "collect rc=$?"
-head -c 900 gpurun_out/r02_c/bench.json; echo
+for v in base xmask base xmask; do
+echo "--- $v"; OMCHAT_LIB=$PWD/ab_lib/$v.so timeout 900 python tools/bench_decode_batch.py 2>&1 | grep -v amdgpu | tr '\n' ' '; echo
+done
+timeout 600 python -m pytest tests/test_gpu_round2.py tests/test_gpu_ops.py -q -x -k "packed or gemv" 2>&1 | tail -2
