@@ -128,6 +128,10 @@ int main() {
       RUN(2, 2, 4, 8, true, true, true);
       RUN(1, 2, 4, 8, true, true, true);
       RUN(1, 2, 8, 8, true, true, true);
+      RUN(4, 2, 8, 4, true, true, true);
+      RUN(8, 2, 8, 2, true, true, true);
+      RUN(8, 2, 8, 1, true, true, true);
+      RUN(8, 2, 4, 2, true, true, true);
       { float us = run<2, 2, 8, 4, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=2 waves=8 unroll=4 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
       { float us = run<4, 2, 4, 2, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=4 waves=4 unroll=2 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
     }
