@@ -511,6 +511,8 @@ def main():
         "decode_hbm_frac": hs["decode_hbm_frac"],
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
+        # GEMM tile choices come from the committed omchat_amd/gemm_tune_gfx950.txt: 0 = no first-use tuning ran in this process
+        "gemm_tune_measurements": int(_lib.lib().omchat_gemm_tune_runs()),
         "decode_graph": eng.decode_graph_stats() if (a.graph and world == 1) else None,
     }
     if do4 and full:
