@@ -189,6 +189,109 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 // Wave w of a workgroup walks K chunks (64 wide) c_lo + UNROLL * (w + WAVES * i) + u; partial tiles are summed through LDS in a
 // fixed order by all waves, which also apply the epilogue.
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// x-stationary form of the packed batched GEMV for the long launches (gate|up, lm_head; K = 64 * 8 * NCH, no split-K).  In gemv_pk_kernel
+// every workgroup re-reads the whole packed x (229 KB at K = 3584, NB = 2): as many bytes through the CU's load path as its share of
+// the weights (tools/tune_gemv32.hip: with x served from L1 gate|up takes 47.6 instead of 53.3 us).  Here one persistent workgroup per
+// CU keeps x in REGISTERS -- wave w owns K chunks w, w + 8, ... for the whole launch -- and walks 16-row weight tiles with stride
+// gridDim.x; the eight partial tiles meet in LDS (parity double buffer: one barrier per tile) and the NEXT tile's weight fragments are
+// loaded before the current tile is reduced, so the weight stream never stops.  Measured in the harness: gate|up 53.3 -> 48.6 us,
+// lm_head 219 -> 191 us at b = 32.  SwiGLU: the workgroup takes tiles in (gate, up) pairs; the thread that reduces element (row, batch)
+// of the gate tile reduces the same element of the up tile and keeps the gate value in a register.
+// Same summation order per output as gemv_pk_kernel with WAVES = 8 would give only if its chunk -> wave deal were identical; it is not
+// (there: groups of UNROLL consecutive chunks per wave), so results agree to fp32 rounding of the K sum, not bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, int NB, int NCH>
+__global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
+  typedef typename V8<T>::type frag_t;
+  constexpr int WAVES = 8;
+  __shared__ float red[2][WAVES][NB][256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nchunk_all = p.K >> 6, n_tiles = p.N >> 4;
+  // K = 64 * 8 * NCH exactly (host-checked), dealt to the waves chunk by chunk: wave w owns chunks w, w + 8, ...  No guards inside the load
+  // groups on purpose: a ragged / split-K variant with per-chunk validity tests kept the compiler from issuing a tile's 2 * NCH weight
+  // loads back to back and measured 8 % SLOWER than gemv_pk_kernel.
+  const T* W = (const T*)p.W;
+  frag_t xf[NCH][NB][2];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = wave + WAVES * i;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        frag_t z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = fromf<T>(0.f);
+        xf[i][nb][h] = nb * 16 + fr < p.b ? ld8<T>((const T*)p.X + ((size_t)(c * 2 + h) * NB + nb) * 512 + lane * 8) : z;
+      }
+  }
+  auto load_w = [&](frag_t (&wf)[NCH][2], int tile) {
+    const T* base = W + (size_t)tile * nchunk_all * 1024 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[i][h] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(base + (size_t)(wave + WAVES * i) * 1024 + h * 512));
+  };
+  // j-th tile of this workgroup: SwiGLU walks (gate, up) pairs, the others single tiles
+  const int n_units = EPI == EPI_SWIGLU ? n_tiles >> 1 : n_tiles;
+  const int my_units = (int)blockIdx.x < n_units ? (n_units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int my_tiles = EPI == EPI_SWIGLU ? 2 * my_units : my_units;
+  auto tile_of = [&](int j) { return EPI == EPI_SWIGLU ? 2 * ((int)blockIdx.x + (j >> 1) * (int)gridDim.x) + (j & 1) : (int)blockIdx.x + j * (int)gridDim.x; };
+  const T* bias = (const T*)p.bias;
+  float gate = 0.f;
+  auto finish = [&](frag_t (&wf)[NCH][2], int j) {
+    const int tile = tile_of(j), par = j & 1;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb] = mfma16(wf[i][0], xf[i][nb][0], acc[nb]);
+        acc[nb] = mfma16(wf[i][1], xf[i][nb][1], acc[nb]);
+      }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[par][wave][nb][(fg * 4 + r) * 16 + fr] = acc[nb][r];
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < NB * 256) {
+      const int nb = i >> 8, e = i & 255, nl = e >> 4, bi = nb * 16 + (e & 15);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += red[par][w][nb][e];      // fixed order: deterministic
+      if constexpr (EPI == EPI_SWIGLU) {
+        if ((j & 1) == 0) gate = rnd<T>(v);
+        else if (bi < p.b) {
+          const int n = (tile >> 1) * 16 + nl;
+          const T y = fromf<T>(rnd<T>(silu(gate)) * rnd<T>(v));
+          if (p.y_packed) ((T*)p.Y)[packed_x_index(bi, n, NB)] = y;
+          else ((T*)p.Y)[(size_t)bi * p.ldy + n] = y;
+        }
+      } else if (bi < p.b) {
+        const int n = tile * 16 + nl;
+        const float y = v + (bias ? tof(bias[n]) : 0.f);
+        if (p.out_f32) ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
+        else ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
+      }
+    }
+  };
+  frag_t wa[NCH][2], wb[NCH][2];
+  if (my_tiles > 0) load_w(wa, tile_of(0));
+  for (int j = 0; j < my_tiles; j += 2) {
+    if (j + 1 < my_tiles) load_w(wb, tile_of(j + 1));
+    finish(wa, j);
+    if (j + 1 < my_tiles) {
+      if (j + 2 < my_tiles) load_w(wa, tile_of(j + 2));
+      finish(wb, j + 1);
+    }
+  }
+}
+
 template <typename T, int NTILE, int EPI, int WAVES, int UNROLL, int NB, bool WPACK>
 __global__ __launch_bounds__(WAVES * 64) void gemv_pk_kernel(GemvP p) {
   typedef typename V8<T>::type frag_t;
@@ -346,6 +449,7 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 // epilogue.  Split-K slices are chunk ranges of 512 elements, <= RW_MAXC chunks each.
 // ---------------------------------------------------------------------------------------------------------
 int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
+int g_gemv_no_xs = 0;          // tuning knob (key 11): 1 = batched decode never takes the x-stationary persistent kernel (A/B)
 constexpr int RW_MAXC = 8;
 typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -555,6 +659,21 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     else { if (a.w_packed) hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, true>), grid, dim3(WV_ * 64), 0, s, p);            \
            else hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, false>), grid, dim3(WV_ * 64), 0, s, p); }                     \
   } while (0)
+    // long launches with K = 64 * 8 * 7 (= 3584: gate|up, lm_head): x-stationary persistent form, one workgroup per CU, >= 4 units each
+    if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && a.N / 16 >= 4 * 256 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE)) {
+      static int n_cu = 0;
+      if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+      const dim3 grid(n_cu);
+      if (a.epi == EPI_SWIGLU) {
+        if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
+      } else {
+        if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_NONE, 2, 7>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_NONE, 1, 7>), grid, dim3(512), 0, s, p);
+      }
+      OM_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.epi == EPI_SWIGLU) OM_PK(2, EPI_SWIGLU, 8, 4);
     else if (a.epi == EPI_PARTIAL) { if (a.K / ks >= 1536) OM_PK(4, EPI_PARTIAL, 4, 2); else OM_PK(2, EPI_PARTIAL, 8, 4); }
     else if (a.N >= 32768) OM_PK(4, EPI_NONE, 4, 4);
@@ -606,6 +725,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 }  // namespace
 
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
+void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 
 namespace {
 // one wave per row: absmax, then e4m3 (round to nearest even) of w / scale, 8 weights per lane per step

@@ -85,6 +85,83 @@ __global__ __launch_bounds__(WAVES * 64) void sk_kernel(const T* __restrict__ W,
 }
 
 struct Shape { const char* name; int N, K, ks; };
+// x-stationary persistent variant (K = 64 * WAVES * NCH): every wave keeps the x fragments of ITS chunks in registers for the whole launch,
+// workgroups walk 16-row weight tiles (stride gridDim.x), the waves' partial tiles meet in LDS (parity double buffer, one barrier per
+// tile), the next tile's weight fragments are loaded before the reduction of the current one.  No x re-reads at all.
+template <typename T, int NB, int WAVES, int NCH>
+__global__ __launch_bounds__(WAVES * 64) void xs_kernel(const T* __restrict__ W, const T* __restrict__ X, float* __restrict__ Y, int N, int K, int b) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ float red[2][WAVES][NB][256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchunk_all = K / 64, n_tiles = N / 16;
+  frag_t xf[NCH][NB][2];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[i][nb][h] = *reinterpret_cast<const frag_t*>(X + ((size_t)((wave + WAVES * i) * 2 + h) * NB + nb) * 512 + lane * 8);
+  auto load_w = [&](frag_t (&wf)[NCH][2], int tile) {
+    const T* base = W + (size_t)tile * nchunk_all * 1024 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[i][h] = __builtin_nontemporal_load(reinterpret_cast<const frag_t*>(base + (size_t)(wave + WAVES * i) * 1024 + h * 512));
+  };
+  auto finish = [&](frag_t (&wf)[NCH][2], int tile, int par) {
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb] = mfma16(wf[i][0], xf[i][nb][0], acc[nb]);
+        acc[nb] = mfma16(wf[i][1], xf[i][nb][1], acc[nb]);
+      }
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[par][wave][nb][(fg * 4 + r) * 16 + fr] = acc[nb][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB * 256; i += WAVES * 64) {
+      const int nb = i >> 8, e = i & 255;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) sum += red[par][w][nb][e];
+      const int n = tile * 16 + (e >> 4), bi = nb * 16 + (e & 15);
+      if (bi < b) Y[(size_t)bi * N + n] = sum;
+    }
+  };
+  frag_t wa[NCH][2], wb[NCH][2];
+  int tile = blockIdx.x;
+  if (tile < n_tiles) load_w(wa, tile);
+  for (; tile < n_tiles; tile += 2 * gridDim.x) {
+    const int t2 = tile + gridDim.x, t3 = tile + 2 * gridDim.x;
+    if (t2 < n_tiles) load_w(wb, t2);
+    finish(wa, tile, 0);
+    if (t2 < n_tiles) {
+      if (t3 < n_tiles) load_w(wa, t3);
+      finish(wb, t2, 1);
+    }
+  }
+}
+
+template <int NB, int WAVES, int NCH>
+float run_xs(const Shape& sh, int b, const std::vector<void*>& W, void* X, void* Y, int iters, int grid) {
+  auto k = xs_kernel<bf16, NB, WAVES, NCH>;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), 0, 0, (const bf16*)W[i % W.size()], (const bf16*)X, (float*)Y, sh.N, sh.K, b);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), 0, 0, (const bf16*)W[i % W.size()], (const bf16*)X, (float*)Y, sh.N, sh.K, b);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  if (hipGetLastError() != hipSuccess) printf("LAUNCH ERROR\n");
+  return ms * 1e3f / iters;
+}
+
+
 
 template <int NTILE, int NB, int WAVES, int UNROLL, bool XPACK, bool WPACK, bool NTL, bool XFAKE = false>
 float run(const Shape& sh, int b, const std::vector<void*>& W, void* X, void* Y, int iters) {
@@ -132,6 +209,10 @@ int main() {
       RUN(8, 2, 8, 2, true, true, true);
       RUN(8, 2, 8, 1, true, true, true);
       RUN(8, 2, 4, 2, true, true, true);
+      if (sh.K == 3584) {
+        for (int grid : {256, 512, 296, 1184})
+          { float us = run_xs<2, 8, 7>(sh, b, W, X, Y, iters, grid); printf("  %-8s b=32 x-stationary waves=8 nch=7 grid=%-4d: %7.1f us %5.2f TB/s\n", sh.name, grid, us, bytes / us / 1e6); }
+      }
       { float us = run<2, 2, 8, 4, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=2 waves=8 unroll=4 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
       { float us = run<4, 2, 4, 2, true, true, true, true>(sh, b, W, X, Y, iters); printf("  %-8s b=32 NTILE=4 waves=4 unroll=2 XFAKE (x from L1): %7.1f us %5.2f TB/s\n", sh.name, us, bytes / us / 1e6); }
     }
