@@ -201,22 +201,22 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 // Same summation order per output as gemv_pk_kernel with WAVES = 8 would give only if its chunk -> wave deal were identical; it is not
 // (there: groups of UNROLL consecutive chunks per wave), so results agree to fp32 rounding of the K sum, not bit for bit.
 // ---------------------------------------------------------------------------------------------------------
+// c_base: first K chunk of this workgroup's slice (the slice is exactly 8 * NCH chunks), slice: its index for the split-K output
 template <typename T, int EPI, int NB, int NCH>
-__global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
+__device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][NB][256], int c_base, int slice) {
   typedef typename V8<T>::type frag_t;
   constexpr int WAVES = 8;
-  __shared__ float red[2][WAVES][NB][256];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int nchunk_all = p.K >> 6, n_tiles = p.N >> 4;
-  // K = 64 * 8 * NCH exactly (host-checked), dealt to the waves chunk by chunk: wave w owns chunks w, w + 8, ...  No guards inside the load
-  // groups on purpose: a ragged / split-K variant with per-chunk validity tests kept the compiler from issuing a tile's 2 * NCH weight
-  // loads back to back and measured 8 % SLOWER than gemv_pk_kernel.
+  // The slice is dealt to the waves chunk by chunk: wave w owns chunks c_base + w, c_base + w + 8, ...  No guards inside the load groups on
+  // purpose: a ragged variant with per-chunk validity tests kept the compiler from issuing a tile's 2 * NCH weight loads back to back and
+  // measured 8 % SLOWER than gemv_pk_kernel.
   const T* W = (const T*)p.W;
   frag_t xf[NCH][NB][2];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = wave + WAVES * i;
+    const int c = c_base + wave + WAVES * i;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
       }
   }
   auto load_w = [&](frag_t (&wf)[NCH][2], int tile) {
-    const T* base = W + (size_t)tile * nchunk_all * 1024 + lane * 8;
+    const T* base = W + ((size_t)tile * nchunk_all + c_base) * 1024 + lane * 8;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
           if (p.y_packed) ((T*)p.Y)[packed_x_index(bi, n, NB)] = y;
           else ((T*)p.Y)[(size_t)bi * p.ldy + n] = y;
         }
+      } else if constexpr (EPI == EPI_PARTIAL) {
+        if (bi < p.b) ((float*)p.Y)[((size_t)slice * p.b + bi) * p.ldy + tile * 16 + nl] = v;      // [ksplit][b][ldy]
       } else if (bi < p.b) {
         const int n = tile * 16 + nl;
         const float y = v + (bias ? tof(bias[n]) : 0.f);
@@ -290,6 +292,23 @@ __global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
       finish(wb, j + 1);
     }
   }
+}
+
+template <typename T, int EPI, int NB, int NCH>
+__global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
+  __shared__ float red[2][8][NB][256];
+  gemv_xs_body<T, EPI, NB, NCH>(p, red, 0, 0);
+}
+
+// split-K form (down_proj): the K = 64 * 8 * q chunks are cut into slices that deal evenly to the 8 waves -- n5 slices of 40 chunks
+// (5 per wave) then slices of 16 chunks (2 per wave), blockIdx.y = slice -- each written as one fp32 slice [ksplit][b][ldy] for the
+// fused residual + RMSNorm kernel.  (q = 37 for K = 18944: 7 x 40 + 1 x 16 = 8 slices.)
+template <typename T, int NB>
+__global__ __launch_bounds__(512) void gemv_xs_split_kernel(GemvP p, int n5) {
+  __shared__ float red[2][8][NB][256];
+  const int y = blockIdx.y;
+  if (y < n5) gemv_xs_body<T, EPI_PARTIAL, NB, 5>(p, red, y * 40, y);
+  else gemv_xs_body<T, EPI_PARTIAL, NB, 2>(p, red, n5 * 40 + (y - n5) * 16, y);
 }
 
 template <typename T, int NTILE, int EPI, int WAVES, int UNROLL, int NB, bool WPACK>
@@ -673,6 +692,23 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       }
       OM_LAUNCH_CHECK();
       return 0;
+    }
+    // split-K launch whose chunks cut into ks slices of 40 and 16 (down_proj at TP = 1: 296 = 7 x 40 + 16, ks = 8): same form, one slice per blockIdx.y
+    if (a.w_packed && !g_gemv_no_xs && a.epi == EPI_PARTIAL && ks > 1 && (a.K >> 6) % 8 == 0 && a.N % 16 == 0) {
+      const int q = (a.K >> 6) / 8;                 // chunks per wave over the whole K
+      // q = 5 * a5 + 2 * a2 with a5 + a2 == ks
+      int a5 = -1;
+      for (int t = 0; t <= ks; ++t) if (5 * t + 2 * (ks - t) == q) a5 = t;
+      static int n_cu2 = 0;
+      if (!n_cu2) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu2 <= 0) n_cu2 = 256; }
+      const int gx = std::max(1, n_cu2 / ks);
+      if (a5 >= 0 && a.N / 16 >= 4 * gx) {
+        const dim3 grid(gx, ks);
+        if (a.b > 16) hipLaunchKernelGGL((gemv_xs_split_kernel<T, 2>), grid, dim3(512), 0, s, p, a5);
+        else hipLaunchKernelGGL((gemv_xs_split_kernel<T, 1>), grid, dim3(512), 0, s, p, a5);
+        OM_LAUNCH_CHECK();
+        return 0;
+      }
     }
     if (a.epi == EPI_SWIGLU) OM_PK(2, EPI_SWIGLU, 8, 4);
     else if (a.epi == EPI_PARTIAL) { if (a.K / ks >= 1536) OM_PK(4, EPI_PARTIAL, 4, 2); else OM_PK(2, EPI_PARTIAL, 8, 4); }
