@@ -464,7 +464,7 @@ def main():
         roof = roof_pre = roof_vit = None
         if n:
             avg_s = ms / n / 1e3
-            kern = "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream, batch 1)" if b == 1 else f"gemv_kernel<EPI_SWIGLU, NB=2> (decode gate|up weight stream, batch {b})"
+            kern = "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream, batch 1)" if b == 1 else f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
             tr, src = pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if (world == 1 and full and b == 1) else (None, None)
             roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
