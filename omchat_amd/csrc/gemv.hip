@@ -679,9 +679,11 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
            else hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, false>), grid, dim3(WV_ * 64), 0, s, p); }                     \
   } while (0)
     // long launches with K = 64 * 8 * 7 (= 3584: gate|up, lm_head): x-stationary persistent form, one workgroup per CU, >= 4 units each
-    if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && a.N / 16 >= 4 * 256 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE)) {
-      static int n_cu = 0;
-      if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
+    if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
+        (a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu) {
       const dim3 grid(n_cu);
       if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
