@@ -184,7 +184,7 @@ def _unpack_x(packed, b, K, NB):
 @pytest.mark.parametrize("b,N,K,ks", [(2, 320, 512, 1), (16, 4608, 3584, 1), (17, 320, 576, 2), (32, 3584, 18944, 8), (32, 37888, 3584, 1),
                                       (24, 160, 64, 1), (5, 3584, 3584, 3), (32, 32768 + 64, 256, 1),
                                       # x-stationary persistent forms (packed W, K = 3584 in one piece / 18944 in 7 x 40 + 16 chunks): ragged batches
-                                      (17, 16384, 3584, 1), (3, 16384, 3584, 1), (20, 3584, 18944, 8)])
+                                      (17, 32768, 3584, 1), (3, 16384, 3584, 1), (20, 3584, 18944, 8)])
 def test_gemv_packed_operands(gpu_lib, dt, wp, b, N, K, ks):
     from test_gpu_ops import _gemm_ref
     from gpu_util import randn
