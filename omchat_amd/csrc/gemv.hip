@@ -683,8 +683,10 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
-        (a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu) {
-      const dim3 grid(n_cu);
+        ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu))) {
+      // the fused qkv projection (288 tiles on 256 CUs) cannot give every CU 4 units: it takes HALF as many workgroups as tiles, two tiles
+      // each -- x is read 144 times instead of 288 and the second tile's loads run under the first's reduction (13.3 -> 11.7 us at b = 32)
+      const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : a.N / 32);
       if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
