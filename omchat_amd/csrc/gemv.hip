@@ -705,8 +705,11 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       for (int t = 0; t <= ks; ++t) if (5 * t + 2 * (ks - t) == q) a5 = t;
       static int n_cu2 = 0;
       if (!n_cu2) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu2 <= 0) n_cu2 = 256; }
-      const int gx = std::max(1, n_cu2 / ks);
-      if (a5 >= 0 && a.N / 16 >= 4 * gx) {
+      int gx = std::max(1, n_cu2 / ks);
+      const int tiles = a.N / 16;
+      // short launches (o_proj: 224 tiles x 2 slices): two tiles per workgroup instead of >= 4 units on every CU (as for qkv)
+      if (tiles < 4 * gx && tiles % 2 == 0 && (long)tiles * ks >= n_cu2 && (long)tiles * ks <= 2L * n_cu2) gx = tiles / 2;
+      if (a5 >= 0 && (tiles >= 4 * gx || gx == tiles / 2)) {
         const dim3 grid(gx, ks);
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_split_kernel<T, 2>), grid, dim3(512), 0, s, p, a5);
         else hipLaunchKernelGGL((gemv_xs_split_kernel<T, 1>), grid, dim3(512), 0, s, p, a5);

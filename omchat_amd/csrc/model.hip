@@ -1055,7 +1055,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // the MFMA form (b > 1) wants ~2-3 workgroups per CU
   // (tools/tune_rows.hip: down_proj 18944 -> 8 slices 23.3 us vs 5 slices 27.6 us; o_proj is latency-bound, 1-3 slices alike)
   auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return nch >= 16 ? std::min(DEC_KS_MAX, nch) : std::max(1, std::min(3, nch)); };
-  const int ks_o = b == 1 ? ks_rows(qd) : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16)))));
+  // batched o_proj: K = 3584 cuts into two exact slices for the x-stationary form (40 + 16 chunks, gemv_xs_split_kernel) when the packed
+  // replica is in use; otherwise ~2 workgroups per CU for the MFMA form
+  const int ks_o = b == 1 ? ks_rows(qd) : (wpk && qd == 3584 ? 2 : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16))))));
   const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
   if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
