@@ -1,10 +1,13 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_round2.py tests/test_gpu_fullsize.py -q -x -k "packed or gemv or batch" 2>&1 | tail -2
-for t in 1 0 1 0; do
-  echo "--- configs2 no_xs=$t"
-  timeout 900 python bench.py --no-cpu-baseline --workload configs2 --steps 1 --warmup 1 --tuning 11=$t 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print({k:d[k] for k in d if 'decode_ms' in k}, d['value'])"
-done
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/full_gpu_tests.log 2>&1; echo "gpu tests rc=$?"
+grep -a "passed\|failed" gpurun_out/full_gpu_tests.log | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_final.json').read().strip().splitlines()[-1])
+c=d['configs2']
+print(d['value'], d['decode_ms_per_token_p50'], d['vit_ms_p50'], d['prefill_ms_p50'], d['ttft_ms_p50'], c['tokens_per_sec'], c['decode_ms_per_step_p50'], d['cpu_baseline']['value'])
+PY
