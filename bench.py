@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- OmChat-13B hot path on MI355X: ViT tiles -> projector -> splice -> prefill -> greedy decode.
+"""bench.py -- OmChat hot path on MI355X: ViT tiles -> projector -> splice -> prefill -> greedy decode.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gen G] [--workload both|configs1|configs2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gen G] [--workload both|configs1|configs2|configs3|configs4]
+    python bench.py --shard-of 8 [...]            # ONE rank of a TP = 8 group on one GPU, exchanges removed (kernel time per rank)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process never touches the GPU; it starts N rank processes
-(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each), relays rank 0's JSON line and exits with the worst exit code.
-Under torchrun the ranks are already there.  Ranks form ONE tensor-parallel group (Megatron TP, omchat_amd/tp.py): the
-all-reduces run on RCCL over xGMI (large messages) and on the peer one-shot kernel of csrc/comm.hip (decode-sized ones).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process never touches the GPU (not even to count devices); it
+starts N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each), relays rank 0's JSON line and exits with the
+worst exit code.  Under torchrun the ranks are already there.  Ranks form ONE tensor-parallel group (Megatron TP, omchat_amd/tp.py):
+the all-reduces run on RCCL over xGMI (large messages) and on the peer one-shot kernel of csrc/comm.hip (decode-sized ones).
 
-Workloads (BASELINE.json):
+Workloads (BASELINE.json `configs`):
   configs1  one sample = one 448x448 picture => 3 anyres tiles (mm_utils.py:28-37,151) + 512 text ids => S = 3584 prefill
             tokens, then G greedy tokens, batch 1.  `value` = generated tokens / s over whole steps (prefill included).
   configs2  32 such samples per step: 96 tiles through the ViT, right-padded batch prefill of 32 x 3584 rows, G batched
             decode steps.  Reported under "configs2" (tokens / s, samples / s, HBM fraction of the decode steps); it is `value`
             only with --workload configs2.
-  configs4  (only on request) one 32-frame clip: 32 tiles through the ViT, prefill of 32 x 1024 + 512 = 33 280 positions (>= 16 k
-            visual + text tokens), G greedy tokens with the fp8 modes on: e4m3 decode weights, e4m3 KV cache, fp8 x fp8 MFMA for the
-            qkv / gate|up prefill GEMMs.  A quantised computation: not comparable with `value` of configs1.
+  configs3  OmChat-2.1-8B (InternViT-300M + Qwen2-7B): one sample = 8 pictures of 448x448, each through the dynamic tiling of
+            mm_utils.py:276-323 (device front end, bit-exact) -> 8 tiles in ONE batched tower pass, prefill of 8 x 1024 + 512 = 8704
+            positions, G greedy tokens.  Side block "configs3" of the default run (own context); `value` with --workload configs3.
+  configs4  one 32-frame clip: 32 tiles through the ViT, prefill of 32 x 1024 + 512 = 33 280 positions (>= 16 k visual + text
+            tokens), greedy tokens with the fp8 modes on: e4m3 decode weights, e4m3 KV cache, fp8 x fp8 MFMA for the qkv / gate|up
+            prefill GEMMs.  A quantised computation: not comparable with `value` of configs1.  Side block "configs4" of the default
+            run (own context, 64 tokens); `value` with --workload configs4.
 Inputs are resident in HBM before the timed region.  Weights: deterministic synthetic (omchat_amd/synth.py) at the full
-OmChat-13B geometry, generated on the device; under TP every rank keeps its SHARD of the same values, and the first 32
-greedy ids are checked against a TP = 1 context that rank 0 runs first in the same process ("tokens_match_tp1").
+geometry, generated on the device; under TP every rank keeps its SHARD of the same values, and the first 32 greedy ids are
+checked against a TP = 1 context that rank 0 runs first in the same process ("tokens_match_tp1").
 
 Prints ONE JSON line (rank 0): `roofline` = dominant kernel of the step (decode gate|up weight stream, HBM-bound) from HIP
 events on the launch stream inside the timed region; `cpu_baseline` = the oracle on a bounded sample (N = 1 only).
@@ -44,11 +49,13 @@ MARGIN_GUARD = {"bf16": 0.05, "f16": 0.02}      # top-1 / top-2 logit gap below 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="both", choices=["both", "configs1", "configs2", "configs4"])
+    ap.add_argument("--workload", default="both", choices=["both", "configs1", "configs2", "configs3", "configs4"])
     ap.add_argument("--frames", type=int, default=32, help="configs4: video frames (one 448x448 tile = 1024 visual tokens each)")
+    ap.add_argument("--images", type=int, default=8, help="configs3: pictures per sample")
     ap.add_argument("--graph", action="store_true", help="replay each decode step as one captured hipGraph instead of ~230 eager launches "
                     "(measured SLOWER on ROCm 7.2 / MI355X: 3.21 vs 2.96 ms per token, so it is off by default)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the (untimed) weight-only fp8 decode measurement")
+    ap.add_argument("--no-side", action="store_true", help="default workload: skip the configs3 / configs4 side blocks")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gen", type=int, default=256, help="greedy decode tokens per step")
@@ -61,7 +68,14 @@ def parse():
     ap.add_argument("--vit", default="both", choices=["tp", "dp", "both"],
                     help="N > 1: vision tower tensor-parallel (north star; the headline), data-parallel over the tiles with a replicated tower and "
                          "one gather (SURVEY 8e optional throughput mode), or tp as the headline with dp measured beside it")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N",
+                    help="N = 1 GPU only: run rank 0's share of a TP = N group (its shard shapes and launch sequence) with the exchanges removed "
+                         "(omchat_allreduce_noop): per-rank kernel time without an N-GPU node.  The outputs are not the model's outputs; "
+                         "the line carries shard_of and is not a throughput claim")
     ap.add_argument("--no-tp1-check", action="store_true")
+    ap.add_argument("--tp1-check-dtype", default="", choices=["", "bf16", "f16"],
+                    help="N > 1: dtype of the TP = N vs TP = 1 logit / id cross-check contexts (default f16: every position clears the margin "
+                         "guard there; the timed run keeps --dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny geometry (NOT the benchmark config)")
     ap.add_argument("--tuning", default="", help="debug: comma-separated key=value pairs for omchat_op_set_tuning (include/omchat_hip.h)")
@@ -69,13 +83,31 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# N > 1 without a launcher: start the ranks ourselves (before anything initialises HIP in this process)
+# N > 1 without a launcher: start the ranks ourselves (this process never initialises HIP)
 # ----------------------------------------------------------------------------------------------------------------------
+def count_gpus_without_hip():
+    """GPUs of this node from the KFD topology (nodes with SIMDs), honouring HIP / ROCR_VISIBLE_DEVICES: the spawning parent must never
+    reach the HIP runtime (its children are started from it), and it does not need to."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(a):
     import socket
     import tempfile
-    import torch
-    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    ndev = count_gpus_without_hip()
     oversub = os.environ.get("OMCHAT_BENCH_OVERSUBSCRIBE") == "1"
     if ndev < a.gpus and not oversub:
         print(json.dumps({"error": f"--gpus {a.gpus} but only {ndev} GPU(s) visible", "n_gpus": a.gpus}))
@@ -173,11 +205,11 @@ def cpu_baseline(cfg, S, gen, n_tiles):
             "decode_tokens_per_sec": 1.0 / (t["num_hidden_layers"] * t_dec + t_lm)}
 
 
-def pmc_traffic(substrings):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json; counters cannot be
+def pmc_traffic(substrings, pattern="*pmc_traffic.json"):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json; counters cannot be
     collected together with the timed run).  Picks the kernel whose mangled name contains all `substrings`."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None, None
     ks = json.load(open(files[-1]))["kernels"]
@@ -187,10 +219,31 @@ def pmc_traffic(substrings):
     return None, None
 
 
+def algorithmic(cfg):
+    """algorithmic FLOPs / bytes of the path for a configuration (13B: 11.945 + 0.0498 TF per tile, 13.05 GF per prefill
+    token + 200 704 S^2, 14.14 GB of weights + 57 344 B of KV per cached position per decode step)."""
+    v, t = cfg.vision, cfg.text
+    C, I, Lv = v["hidden_size"], v["intermediate_size"], v["num_hidden_layers"]
+    npch = cfg.num_image_tokens
+    ntok = npch + 1
+    H, It, Lt = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"]
+    qd, kvd = t["num_attention_heads"] * t["head_dim"], t["num_key_value_heads"] * t["head_dim"]
+    vit_layer = 2.0 * ntok * (4 * C * C + 2 * C * I) + 4.0 * ntok * ntok * C
+    vit_tile = Lv * vit_layer + 2.0 * npch * (3 * v["patch_size"] ** 2) * C + 2.0 * npch * (C * H + H * H)
+    dec_params = H * (qd + 2 * kvd) + qd * H + 3 * H * It
+    lm = t["vocab_size"] * H
+    return {"vit_tile": vit_tile,
+            "prefill": lambda S: S * 2.0 * Lt * dec_params + Lt * 2.0 * S * S * qd + 2.0 * lm,
+            "decode_weight_bytes": (Lt * dec_params + lm) * 2.0,
+            "kv_bytes_per_pos": Lt * 2.0 * kvd * 2.0}
+
+
 def main():
     a = parse()
     if a.workload == "configs4":
         a.no_tp1_check = True          # a quantised computation: there is no TP = 1 16-bit twin to compare ids with
+    if a.shard_of and a.gpus > 1:
+        raise SystemExit("--shard-of runs on ONE GPU (it is one rank of the group with the exchanges removed)")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
@@ -209,21 +262,28 @@ def main():
         dist.init_process_group("gloo", init_method="env://")       # bootstrap only; the data path is RCCL + peer kernels inside the library
 
     from omchat_amd import synth, _lib
-    from omchat_amd.config import omchat13b, tiny
+    from omchat_amd.config import omchat13b, omchat8b_21, tiny, tiny300m
     from omchat_amd.engine import Engine
     from omchat_amd import tp
 
     for kv in filter(None, a.tuning.split(",")):
         k, v = kv.split("=")
         _lib.check(_lib.lib().omchat_op_set_tuning(int(k), int(v)))
-    cfg = tiny() if a.tiny else omchat13b()
+    do3 = a.workload == "configs3"
     do4 = a.workload == "configs4"
-    n_tiles = a.frames if do4 else 3
+    if do3:
+        cfg = tiny300m() if a.tiny else omchat8b_21()
+    else:
+        cfg = tiny() if a.tiny else omchat13b()
+    n_tiles = a.frames if do4 else (a.images if do3 else 3)
     ntok = cfg.num_image_tokens
     S = n_tiles * ntok + a.text_tokens
-    do1 = a.workload in ("both", "configs1", "configs4")      # configs4 runs through the batch-1 leg with its own tile count and fp8 modes
+    do1 = a.workload in ("both", "configs1", "configs3", "configs4")      # configs3 / 4 run through the batch-1 leg with their own tiles / modes
     do2 = a.workload in ("both", "configs2")
     B2 = a.batch2 if do2 else 1
+    shard = a.shard_of if a.shard_of > 1 else 0
+    tp_size = shard or world
+    full = not a.tiny
 
     # ---- transports of the tensor-parallel sums
     comm, peer, transport = None, None, {"requested": a.transport}
@@ -260,10 +320,17 @@ def main():
             transport["rccl_nranks"] = n.value
 
     vit_dp = world > 1 and a.vit == "dp"
-    eng = Engine(cfg, dtype=a.dtype, max_seq=S + max(a.gen, TP1_CHECK_TOKENS + 1) + 8, max_batch=B2, max_tiles=min(24, n_tiles * B2), max_prefill_rows=S * B2,
-                 tp_rank=rank, tp_size=world, comm=comm, vision=not vit_dp)
-    if peer is not None:
-        eng.set_peer(peer, 0, all_sizes=(comm is None or a.transport == "peer"))
+
+    def new_engine(cfg_, S_, gen_, b_, tiles_, dtype=None, vision=True):
+        e = Engine(cfg_, dtype=dtype or a.dtype, max_seq=S_ + max(gen_, TP1_CHECK_TOKENS + 1) + 8, max_batch=b_, max_tiles=min(24, tiles_),
+                   max_prefill_rows=S_ * b_, tp_rank=rank, tp_size=tp_size, comm=comm, vision=vision)
+        if peer is not None:
+            e.set_peer(peer, 0, all_sizes=(comm is None or a.transport == "peer"))
+        if shard:
+            e.set_noop_allreduce()
+        return e
+
+    eng = new_engine(cfg, S, a.gen, B2, n_tiles * B2, vision=not vit_dp)
     tower = None
 
     def make_tower():          # replicated vision-only context of this rank (data-parallel tower)
@@ -275,30 +342,52 @@ def main():
     encode = (lambda px: eng.encode_images_dp(tower, px)) if vit_dp else (lambda px: eng.encode_images(px))
 
     # synthetic inputs, resident in HBM before the timed region
-    def make_inputs(b):
-        px = torch.from_numpy(synth.pixels(n_tiles * b, cfg.vision["image_size"], 0)).to("cuda", eng.torch_dtype)
+    def make_ids(cfg_, nt, b):
         rows = []
         for i in range(b):
-            text = synth.token_ids(a.text_tokens, min(cfg.text["vocab_size"], 151643), 1 + i).tolist()
+            text = synth.token_ids(a.text_tokens, min(cfg_.text["vocab_size"], 151643), 1 + i).tolist()
             # "<image>\npatch:<image>\npatch:<image>\n{question}" layout (make_context.py:30): sentinel, 1 separator id between
             row = []
-            for tix in range(n_tiles):
+            for tix in range(nt):
                 row += [-200, text[tix]]
-            rows.append(row[:-1] + text[n_tiles - 1:])
+            rows.append(row[:-1] + text[nt - 1:])
         ids = torch.tensor(rows, dtype=torch.int64)
-        assert ids.shape[1] - n_tiles + n_tiles * ntok == S
-        return px, ids
+        assert ids.shape[1] == nt + a.text_tokens
+        return ids
 
-    # ---- TP = 1 reference on rank 0 (same seed, same inputs), before the TP context is filled: greedy ids + full logits
-    tp1 = None
-    V = cfg.text["vocab_size"]
+    def make_inputs(b, e=None, cfg_=None, nt=None):
+        e, cfg_, nt = e or eng, cfg_ or cfg, nt or n_tiles
+        px = torch.from_numpy(synth.pixels(nt * b, cfg_.vision["image_size"], 0)).to("cuda", e.torch_dtype)
+        return px, make_ids(cfg_, nt, b)
+
+    def make_inputs_dynamic(e, cfg_, n_img):
+        """configs3: n_img pictures of tile size through dynamic_preprocess + per-tile preprocess on the device (mm_utils.py:276-323;
+        a 448 x 448 picture picks the 1 x 1 grid: one tile, no thumbnail) -> one flat tile batch for the whole sample."""
+        from omchat_amd.image_processing import HipImageProcessor
+        edge = cfg_.vision["image_size"]
+        proc = HipImageProcessor(crop_size=edge)
+        rng = np.random.default_rng(0)
+        pics = [rng.integers(0, 256, (edge, edge, 3), dtype=np.uint8) for _ in range(n_img)]
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            tiles = [proc.process_dynamic(p, max_num=6, dtype=e.torch_dtype) for p in pics]
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        px = torch.cat(tiles, 0).contiguous()
+        return px, make_ids(cfg_, int(px.shape[0]), 1), sorted(ts[1:])[len(ts[1:]) // 2]
+
+    # ---- TP = N against TP = 1 on rank 0 (same seed, same inputs): greedy ids + full logits.  Default in f16 contexts (round 3): the
+    # fp16 comparison is the convincing one -- 5e-3 logit error, every one of the 33 positions clears the margin guard (VERDICT r02) -- and
+    # it is independent of the timed run's dtype; --tp1-check-dtype bf16 keeps the round-2 form (8-9 guarded positions of 33).
+    tp1_check, tokens_match = None, None
     if world > 1 and not a.no_tp1_check:
+        cdt = a.tp1_check_dtype or "f16"
         ref_ids = torch.zeros(TP1_CHECK_TOKENS + 1, dtype=torch.int64)
         ref_logits = None
         if rank == 0:
-            e1 = Engine(cfg, dtype=a.dtype, max_seq=S + TP1_CHECK_TOKENS + 8, max_batch=1, max_tiles=n_tiles, max_prefill_rows=S)
+            e1 = Engine(cfg, dtype=cdt, max_seq=S + TP1_CHECK_TOKENS + 8, max_batch=1, max_tiles=n_tiles, max_prefill_rows=S)
             e1.fill_synthetic(0)
-            px, ids = make_inputs(1)
+            px, ids = make_inputs(1, e1)
             embeds, lengths, _ = e1.splice(ids, None, e1.encode_images(px))
             logits, _ = e1.prefill(embeds, lengths)
             rows = []
@@ -313,47 +402,50 @@ def main():
             torch.cuda.empty_cache()
         dist.broadcast(ref_ids, src=0)
         tp1 = ref_ids
-
-    eng.fill_synthetic(0)
-    if a.graph and world == 1:
-        eng.enable_decode_graph(True)      # one graph launch per token; every 8th step stays eager for the HIP-event brackets
-    if do4:
-        eng.enable_fp8_decode(True); eng.enable_fp8_kv(True); eng.enable_fp8_prefill(True)
-
-    if tp1 is not None:
         # teacher-forced on the TP = 1 ids: the TP = N logits (vocab shards gathered on rank 0) against the TP = 1 logits, and the
         # greedy pick at every position whose TP = 1 top-1 / top-2 margin is above the noise of this very comparison
-        px, ids = make_inputs(1)
-        embeds, lengths, _ = eng.splice(ids, None, encode(px))
-        logits, _ = eng.prefill(embeds, lengths)
-        got, shard_rows = [int(eng.argmax(logits)[0])], [logits[0].cpu()]
+        same = cdt == a.dtype and not vit_dp
+        ec = eng if same else new_engine(cfg, S, TP1_CHECK_TOKENS + 1, 1, n_tiles, dtype=cdt)
+        ec.fill_synthetic(0)
+        px, ids = make_inputs(1, ec)
+        embeds, lengths, _ = ec.splice(ids, None, ec.encode_images(px))
+        logits, _ = ec.prefill(embeds, lengths)
+        got, shard_rows = [int(ec.argmax(logits)[0])], [logits[0].cpu()]
         for i in range(TP1_CHECK_TOKENS):
-            nxt, lg = eng.decode_step(tp1[i:i + 1].to(torch.int32), want_logits=True)
+            nxt, lg = ec.decode_step(tp1[i:i + 1].to(torch.int32), want_logits=True)
             got.append(int(nxt[0])); shard_rows.append(lg[0].cpu())
+        torch.cuda.synchronize()
+        if not same:
+            ec.close(); del ec
+            torch.cuda.empty_cache()
         mine = torch.stack(shard_rows).contiguous()
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
-        tp1_check, tokens_match = None, None
         if rank == 0:
             Ln, L1 = torch.cat(parts, dim=-1).double(), ref_logits.double()
             rel_err = float((Ln - L1).norm() / L1.norm())
             rms = float((Ln - L1).pow(2).mean().sqrt())
             top2 = torch.topk(ref_logits, 2, dim=-1).values
             margin = (top2[:, 0] - top2[:, 1]).double()
-            guard = max(MARGIN_GUARD[a.dtype], 6.0 * rms)      # a gap difference has sd sqrt(2) x rms: ~4 sd
+            guard = max(MARGIN_GUARD[cdt], 6.0 * rms)      # a gap difference has sd sqrt(2) x rms: ~4 sd
             want = [int(x) for x in tp1]
             guarded = [i for i in range(len(want)) if float(margin[i]) > guard]
-            # two 16-bit evaluation orders of the full 45 + 28 layer model: measured 4.2e-2 (bf16) for TP = 2 and TP = 4 alike, next to
-            # 3.7e-2 between the prefill and the decode kernels of ONE context (tests/test_gpu_fullsize.py CONSIST_TOL); a sharding
-            # or transport error shows as >= 1e-1 (the two-shot segment bug of round 2 read 2.3e-1).  The tiny geometry keeps TOL_DEEP.
-            tol = ((8e-2 if a.dtype == "bf16" else 1.5e-2) if not a.tiny else (3e-2 if a.dtype == "bf16" else 6e-3))
-            tp1_check = {"mode": "teacher-forced on the TP=1 ids", "compared": len(want), "equal": sum(int(g == w) for g, w in zip(got, want)),
+            # two 16-bit evaluation orders of the full 45 + 28 layer model: measured 4.2e-2 (bf16) / 5.3e-3 (f16) for TP = 2 and TP = 4 alike,
+            # next to 3.7e-2 between the prefill and the decode kernels of ONE bf16 context (tests/test_gpu_fullsize.py CONSIST_TOL); a
+            # sharding or transport error shows as >= 1e-1 (the two-shot segment bug of round 2 read 2.3e-1).  The tiny geometry keeps TOL_DEEP.
+            tol = ((6e-2 if cdt == "bf16" else 1.2e-2) if not a.tiny else (3e-2 if cdt == "bf16" else 6e-3))
+            tp1_check = {"mode": "teacher-forced on the TP=1 ids", "dtype": cdt, "compared": len(want),
+                         "equal": sum(int(g == w) for g, w in zip(got, want)),
                          "guarded": len(guarded), "guarded_equal": sum(int(got[i] == want[i]) for i in guarded), "margin_guard": guard,
                          "logit_rel_err": rel_err, "logit_rms_diff": rms, "logit_tolerance": tol, "min_margin": float(margin.min()),
                          "median_margin": float(margin.median())}
             tokens_match = bool(tp1_check["guarded_equal"] == tp1_check["guarded"] and rel_err < tol)
-    else:
-        tp1_check, tokens_match = None, None
+
+    eng.fill_synthetic(0, local=bool(shard))
+    if a.graph and world == 1 and not shard:
+        eng.enable_decode_graph(True)      # one graph launch per token; every 8th step stays eager for the HIP-event brackets
+    if do4:
+        eng.enable_fp8_decode(True); eng.enable_fp8_kv(True); eng.enable_fp8_prefill(True)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -363,53 +455,125 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_workload(b, steps, warmup):
-        px, ids = make_inputs(b)
+    def run_workload(e, enc, px, ids, steps, warmup, gen):
+        b = ids.shape[0]
 
         def step():
-            e = [ev() for _ in range(5)]
-            e[0].record()
-            feats = encode(px)
-            e[1].record()
-            embeds, lengths, _ = eng.splice(ids, None, feats)
-            logits, _ = eng.prefill(embeds, lengths)
-            tok = eng.argmax(logits)
-            e[2].record()
+            t = [ev() for _ in range(5)]
+            t[0].record()
+            feats = enc(px)
+            t[1].record()
+            embeds, lengths, _ = e.splice(ids, None, feats)
+            logits, _ = e.prefill(embeds, lengths)
+            tok = e.argmax(logits)
+            t[2].record()
             first = tok.clone()
-            e[3].record()
+            t[3].record()
             out = [first]
-            for _ in range(a.gen - 1):
-                tok, _ = eng.decode_step(tok)
+            for _ in range(gen - 1):
+                tok, _ = e.decode_step(tok)
                 out.append(tok)
-            e[4].record()
+            t[4].record()
             torch.cuda.synchronize()
-            return (e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[3].elapsed_time(e[4]), torch.stack(out))
+            return (t[0].elapsed_time(t[1]), t[1].elapsed_time(t[2]), t[3].elapsed_time(t[4]), torch.stack(out))
 
         for _ in range(warmup):
             step()
-        eng.prof_enable(True)
+        e.prof_enable(True)
         for c in range(3):
-            eng.prof_read(c, reset=True)
+            e.prof_read(c, reset=True)
         barrier()
         t0 = time.perf_counter()
         parts = [step() for _ in range(steps)]
         barrier()
         wall = time.perf_counter() - t0
-        eng.prof_enable(False)
+        e.prof_enable(False)
         if world > 1:
             tw = torch.tensor([wall], dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             wall = float(tw[0])
-        prof = {c: eng.prof_read(c) for c in range(3)}
+        prof = {c: e.prof_read(c) for c in range(3)}
         med = lambda xs: sorted(xs)[len(xs) // 2]
-        return dict(wall=wall, steps=steps, b=b, prof=prof, vit_ms=med([p[0] for p in parts]), pre_ms=med([p[1] for p in parts]),
-                    dec_ms=med([p[2] for p in parts]))
+        tiles = int(px.shape[0])
+        return dict(wall=wall, steps=steps, b=b, gen=gen, tiles=tiles, S=int(ids.shape[1]) + (tiles // b) * (e.ntok - 1),
+                    prof=prof, vit_ms=med([p[0] for p in parts]), pre_ms=med([p[1] for p in parts]), dec_ms=med([p[2] for p in parts]),
+                    max_tiles=e.c.max_tiles, local=e.local)
 
-    r1 = run_workload(1, a.steps, a.warmup) if do1 else None
+    def summarise(r, cfg_, decode_bytes=None):
+        """decode_bytes(b, L) -> algorithmic bytes of one decode step (default: 16-bit weights + 16-bit KV)"""
+        al = algorithmic(cfg_)
+        b, gen, S_ = r["b"], r["gen"], r["S"]
+        tiles = r["tiles"]
+        dec_step_s = r["dec_ms"] / 1e3 / max(gen - 1, 1)
+        vit_s, pre_s = r["vit_ms"] / 1e3, r["pre_ms"] / 1e3
+        db = decode_bytes or (lambda bb, L: al["decode_weight_bytes"] + al["kv_bytes_per_pos"] * L * bb)
+        return {
+            "tokens_per_sec": b * gen * r["steps"] / r["wall"], "samples_per_sec": b * r["steps"] / r["wall"], "ms_per_step": r["wall"] / r["steps"] * 1e3,
+            "steps": r["steps"], "batch": b, "decode_tokens_per_sec": b / dec_step_s, "images_per_sec": tiles / vit_s,
+            "ttft_ms_p50": r["vit_ms"] + r["pre_ms"], "vit_ms_p50": r["vit_ms"], "prefill_ms_p50": r["pre_ms"],
+            "decode_ms_per_step_p50": dec_step_s * 1e3,
+            "vit_mfma_frac": tiles * al["vit_tile"] / vit_s / 1e12 / MFMA_PEAK_TFLOPS / tp_size if full else None,
+            # the north star states its 40 % target on "ViT + decoder prefill": both together over the time to first token
+            "ttft_mfma_frac": (tiles * al["vit_tile"] + b * al["prefill"](S_)) / (vit_s + pre_s) / 1e12 / MFMA_PEAK_TFLOPS / tp_size if full else None,
+            "prefill_mfma_frac": b * al["prefill"](S_) / pre_s / 1e12 / MFMA_PEAK_TFLOPS / tp_size if full else None,
+            # algorithmic bytes of one decode step (SURVEY.md 8d): weights once + KV of every sequence at the mean decode length
+            "decode_hbm_frac": (db(b, S_ + gen / 2) / tp_size / dec_step_s / 1e9 / HBM_PEAK_GBS) if full else None,
+        }
+
+    def rooflines(r, cfg_, f8=False):
+        b, S_ = r["b"], r["S"]
+        v, t = cfg_.vision, cfg_.text
+        prof, ld = r["prof"], r["local"]
+        gu_bytes = 2.0 * ld["t_mlp"] * t["hidden_size"] * (1 if f8 else 2)      # algorithmic bytes per launch = the (rank-local) gate|up weights
+        ms, n = prof[_lib.PROF_DECODE_GATEUP]
+        roof = roof_pre = roof_vit = None
+        plain = tp_size == 1 and full and cfg_.vision["hidden_size"] == 3200
+        if n:
+            avg_s = ms / n / 1e3
+            if f8:
+                kern = "gemv_rows_kernel<EPI_SWIGLU, F8> (decode gate|up e4m3 weight stream, batch 1)"
+            elif b == 1:
+                kern = "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream, batch 1)"
+            else:
+                kern = f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
+            tr, src = (None, None)
+            if plain and not f8:
+                tr, src = pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if b == 1 else pmc_traffic(["gemv_xs_kernelI", "Li4E"], "*pmc_traffic_configs2.json")
+            roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
+                    "launches": n, "bytes_per_launch": gu_bytes}
+        ms, n = prof[_lib.PROF_PREFILL_GATEUP]
+        if n:
+            fl = 2.0 * b * S_ * (2 * ld["t_mlp"]) * t["hidden_size"]
+            avg_s = ms / n / 1e3
+            tr, src = pmc_traffic(["gemm8_kernel", "Li4E"]) if (plain and b == 1 and not f8) else (None, None)
+            roof_pre = {"bound": "mfma", "kernel": "gemm8_kernel<256x256,EPI_SWIGLU" + (",F8" if f8 else "") + "> (prefill gate|up)", "achieved": fl / avg_s / 1e12,
+                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": tr,
+                        "traffic_source": src, "avg_launch_us": avg_s * 1e6, "launches": n, "flops_per_launch": fl}
+        ms, n = prof[_lib.PROF_VIT_FC1]
+        if n:
+            tiles_per_launch = min(r["max_tiles"], r["tiles"])
+            fl = 2.0 * tiles_per_launch * (cfg_.num_image_tokens + 1) * ld["v_mlp"] * v["hidden_size"]
+            avg_s = ms / n / 1e3
+            roof_vit = {"bound": "mfma", "kernel": "gemm_kernel<EPI_GELU> (ViT fc1)", "achieved": fl / avg_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                        "launches": n, "flops_per_launch": fl}
+        return roof, roof_pre, roof_vit
+
+    frontend3_ms = None
+    r1 = None
+    if do3:
+        px1, ids1, frontend3_ms = make_inputs_dynamic(eng, cfg, n_tiles)
+    elif do1:
+        px1, ids1 = make_inputs(1)
+    if do1:
+        r1 = run_workload(eng, encode, px1, ids1, a.steps, a.warmup, a.gen)
     r2 = None
     if do2:
         steps2 = a.steps if not do1 else (a.steps2 or min(a.steps, 3))
-        r2 = run_workload(B2, steps2, a.warmup if not do1 else 1)
+        px2, ids2 = make_inputs(B2)
+        r2 = run_workload(eng, encode, px2, ids2, steps2, a.warmup if not do1 else 1, a.gen)
+        del px2
     comm_stats = eng.comm_stats() if world > 1 else None
     # data-parallel tower beside the tensor-parallel headline: same tiles, replicated tower, one gather (all ranks take part)
     vit_dp_side = None
@@ -433,77 +597,32 @@ def main():
             dist.barrier()
         return
 
-    v, t = cfg.vision, cfg.text
-    ld = eng.local
-    full = not a.tiny
-    vit_flops_tile = (45 * (2 * 1025 * 122.88e6 + 4 * 1025 ** 2 * 3200) + 2 * 1024 * 588 * 3200 + 2 * 1024 * (3200 * 3584 + 3584 ** 2)) if full else 0.0
-    pre_flops_seq = (S * 2 * 28 * 233.06e6 + 28 * 2 * S * S * 3584 + 2 * 545e6) if full else 0.0
-
-    def summarise(r):
-        b = r["b"]
-        dec_step_s = r["dec_ms"] / 1e3 / (a.gen - 1)
-        out = {
-            "tokens_per_sec": b * a.gen * r["steps"] / r["wall"], "samples_per_sec": b * r["steps"] / r["wall"], "ms_per_step": r["wall"] / r["steps"] * 1e3,
-            "steps": r["steps"], "batch": b, "decode_tokens_per_sec": b / dec_step_s, "images_per_sec": n_tiles * b / (r["vit_ms"] / 1e3),
-            "ttft_ms_p50": r["vit_ms"] + r["pre_ms"], "vit_ms_p50": r["vit_ms"], "prefill_ms_p50": r["pre_ms"],
-            "decode_ms_per_step_p50": dec_step_s * 1e3,
-            "vit_mfma_frac": b * n_tiles * vit_flops_tile / (r["vit_ms"] / 1e3) / 1e12 / MFMA_PEAK_TFLOPS / world,
-            # the north star states its 40 % target on "ViT + decoder prefill": both together over the time to first token
-            "ttft_mfma_frac": b * (n_tiles * vit_flops_tile + pre_flops_seq) / ((r["vit_ms"] + r["pre_ms"]) / 1e3) / 1e12 / MFMA_PEAK_TFLOPS / world,
-            "prefill_mfma_frac": b * pre_flops_seq / (r["pre_ms"] / 1e3) / 1e12 / MFMA_PEAK_TFLOPS / world,
-            # algorithmic bytes of one decode step: weights once + KV of every sequence at the mean decode length
-            "decode_hbm_frac": ((14.14e9 + 57344.0 * (S + a.gen / 2) * b) / world / dec_step_s / 1e9 / HBM_PEAK_GBS) if full else None,
-        }
-        return out
-
-    def rooflines(r):
-        b = r["b"]
-        prof = r["prof"]
-        gu_bytes = 2.0 * ld["t_mlp"] * t["hidden_size"] * 2      # algorithmic bytes per launch = the (rank-local) gate|up weights
-        ms, n = prof[_lib.PROF_DECODE_GATEUP]
-        roof = roof_pre = roof_vit = None
-        if n:
-            avg_s = ms / n / 1e3
-            kern = "gemv_rows_kernel<EPI_SWIGLU> (decode gate|up weight stream, batch 1)" if b == 1 else f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
-            tr, src = pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if (world == 1 and full and b == 1) else (None, None)
-            roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
-                    "launches": n, "bytes_per_launch": gu_bytes}
-        ms, n = prof[_lib.PROF_PREFILL_GATEUP]
-        if n:
-            fl = 2.0 * b * S * (2 * ld["t_mlp"]) * t["hidden_size"]
-            avg_s = ms / n / 1e3
-            tr, src = pmc_traffic(["gemm8_kernel", "Li4E"]) if (world == 1 and full and b == 1) else (None, None)
-            roof_pre = {"bound": "mfma", "kernel": "gemm_kernel<256x256,EPI_SWIGLU> (prefill gate|up)", "achieved": fl / avg_s / 1e12,
-                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": tr,
-                        "traffic_source": src, "avg_launch_us": avg_s * 1e6, "launches": n, "flops_per_launch": fl}
-        ms, n = prof[_lib.PROF_VIT_FC1]
-        if n:
-            tiles_per_launch = min(eng.c.max_tiles, n_tiles * b)
-            fl = 2.0 * tiles_per_launch * (ntok + 1) * ld["v_mlp"] * v["hidden_size"]
-            avg_s = ms / n / 1e3
-            roof_vit = {"bound": "mfma", "kernel": "gemm_kernel<EPI_GELU> (ViT fc1)", "achieved": fl / avg_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
-                        "launches": n, "flops_per_launch": fl}
-        return roof, roof_pre, roof_vit
-
+    al4 = algorithmic(cfg)
+    bytes_f8 = lambda bb, L: al4["decode_weight_bytes"] / 2 + al4["kv_bytes_per_pos"] / 2 * L * bb
     head = r1 if do1 else r2
-    hs = summarise(head)
-    roof, roof_pre, roof_vit = rooflines(head)
-    name = "OmChat-13B (InternViT-6B 45L + Qwen2-7B 28L)" if full else "TINY DEBUG GEOMETRY"
+    hs = summarise(head, cfg, bytes_f8 if do4 else None)
+    roof, roof_pre, roof_vit = rooflines(head, cfg, f8=do4)
+    if a.tiny:
+        name = "TINY DEBUG GEOMETRY"
+    elif do3:
+        name = "OmChat-2.1-8B (InternViT-300M 24L + Qwen2-7B 28L)"
+    else:
+        name = "OmChat-13B (InternViT-6B 45L + Qwen2-7B 28L)"
     wl1 = (f"{name}, configs[1]: 1 sample = {n_tiles} tiles of 448x448 + {a.text_tokens} text ids -> prefill S={S}, "
            f"{a.gen} greedy decode tokens, batch 1")
-    if do4:
-        wl1 = (f"{name}, configs[4]: one {n_tiles}-frame clip = {n_tiles} tiles + {a.text_tokens} text ids -> prefill S={S}, {a.gen} greedy decode "
-               f"tokens, batch 1; fp8: e4m3 decode weights + e4m3 KV cache + fp8 x fp8 MFMA qkv / gate|up prefill GEMMs")
+    wl3 = (f"{name}, configs[3]: 1 sample = {n_tiles} pictures of 448x448 -> dynamic tiling -> {n_tiles} tiles in one tower batch + {a.text_tokens} "
+           f"text ids -> prefill S={S}, {a.gen} greedy decode tokens, batch 1")
+    wl4 = (f"{name}, configs[4]: one {n_tiles}-frame clip = {n_tiles} tiles + {a.text_tokens} text ids -> prefill S={S}, {a.gen} greedy decode "
+           f"tokens, batch 1; fp8: e4m3 decode weights + e4m3 KV cache + fp8 x fp8 MFMA qkv / gate|up prefill GEMMs")
     wl2 = (f"{name}, configs[2]: {B2} samples per step = {n_tiles * B2} tiles + {B2} x {a.text_tokens} text ids -> batch prefill {B2} x {S}, "
            f"{a.gen} batched greedy decode steps")
+    wl = wl4 if do4 else (wl3 if do3 else (wl1 if do1 else wl2))
     res = {
         "metric": "images/sec prefill + decode tokens/sec, OmChat-13B TP=1/8; p50 TTFT",
         "value": hs["tokens_per_sec"], "unit": "tokens/s", "n_gpus": world, "steps": head["steps"], "warmup": a.warmup,
         "ms_per_step": hs["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": wl1 if do1 else wl2, "parallelism": f"tp{world}", "tiles": n_tiles * head["b"], "prefill_tokens": S * head["b"],
+        "config": {"workload": wl, "parallelism": f"tp{world}", "tiles": n_tiles * head["b"], "prefill_tokens": S * head["b"],
                    "gen_tokens": a.gen, "batch": head["b"]},
         "decode_tokens_per_sec": hs["decode_tokens_per_sec"], "images_per_sec": hs["images_per_sec"], "ttft_ms_p50": hs["ttft_ms_p50"],
         "vit_ms_p50": hs["vit_ms_p50"], "prefill_ms_p50": hs["prefill_ms_p50"], "decode_ms_per_token_p50": hs["decode_ms_per_step_p50"],
@@ -511,21 +630,18 @@ def main():
         "decode_hbm_frac": hs["decode_hbm_frac"],
         "roofline": roof, "roofline_prefill": roof_pre, "roofline_vit": roof_vit,
         "device_gb": eng.device_bytes() / 1e9,
-        # GEMM tile choices come from the committed omchat_amd/gemm_tune_gfx950.txt: 0 = no first-use tuning ran in this process
-        "gemm_tune_measurements": int(_lib.lib().omchat_gemm_tune_runs()),
-        "decode_graph": eng.decode_graph_stats() if (a.graph and world == 1) else None,
+        "decode_graph": eng.decode_graph_stats() if (a.graph and world == 1 and not shard) else None,
     }
+    if shard:
+        res["shard_of"] = shard
+        res["config"]["parallelism"] = f"rank 0 of tp{shard}, exchanges removed (omchat_allreduce_noop)"
+        res["shard_note"] = ("ONE rank's share of a TP group on one GPU: shard shapes and launch sequence, no communication; every *_frac is "
+                             "this rank's algorithmic share (1 / N of the FLOPs / bytes) over its own time.  Not a throughput claim.")
+    if do3:
+        res["frontend_ms_p50"] = frontend3_ms
     if do4 and full:
-        dec_s = head["dec_ms"] / 1e3 / (a.gen - 1)
         res["dtype"] = a.dtype + " activations, e4m3 weights (decode GEMVs, qkv / gate|up prefill GEMMs) and KV cache"
-        res["decode_hbm_frac"] = (7.07e9 + 28672.0 * (S + a.gen / 2)) / world / dec_s / 1e9 / HBM_PEAK_GBS
         res["decode_hbm_note"] = "algorithmic bytes per token: 7.07 GB of e4m3 weights + 28 672 B of e4m3 KV per cached position"
-        if roof:
-            roof["bytes_per_launch"] = gu_bytes_f8 = ld["t_mlp"] * t["hidden_size"] * 2.0
-            roof["achieved"] = gu_bytes_f8 / (roof["avg_launch_us"] * 1e-6) / 1e9
-            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-            roof["kernel"] = "gemv_rows_kernel<EPI_SWIGLU, F8> (decode gate|up e4m3 weight stream, batch 1)"
-            roof["traffic"] = None; roof["traffic_source"] = None
     if world > 1:
         res["rccl_nranks"] = transport.get("rccl_nranks")
         res["tokens_match_tp1"] = tokens_match
@@ -536,13 +652,13 @@ def main():
         if vit_dp_side is not None:
             res["vit_data_parallel"] = dict(vit_dp_side, note="replicated tower, tiles dealt to the ranks, one all-reduce gathers the features; NOT part of `value`")
     if do1 and do2:
-        s2 = summarise(r2)
-        ro2, rp2, rv2 = rooflines(r2)
+        s2 = summarise(r2, cfg)
+        ro2, rp2, rv2 = rooflines(r2, cfg)
         s2.update({"workload": wl2, "roofline": ro2, "roofline_prefill": rp2, "roofline_vit": rv2,
                    "note": "side measurement in the same process and context; NOT part of `value`"})
         res["configs2"] = s2
     # weight-only fp8 decode (row f-2 / configs[4]), outside the timed region: same prompt, 64 greedy tokens on the e4m3 replica
-    if world == 1 and not a.no_fp8 and not do4:
+    if world == 1 and not shard and not a.no_fp8 and not do4 and not do3:
         px, ids = make_inputs(1)
         eng.enable_fp8_decode(True)
         n8 = min(64, a.gen)
@@ -560,10 +676,11 @@ def main():
             t8.append(e0.elapsed_time(e1) / n8)
         eng.enable_fp8_decode(False)
         res["fp8_decode"] = {"decode_ms_per_token": min(t8), "decode_tokens_per_sec": 1e3 / min(t8),
-                             "hbm_frac": ((14.14e9 / 2 + 57344.0 * S) / (min(t8) / 1e3) / 1e9 / HBM_PEAK_GBS) if full else None,
+                             "hbm_frac": ((al4["decode_weight_bytes"] / 2 + al4["kv_bytes_per_pos"] * S) / (min(t8) / 1e3) / 1e9 / HBM_PEAK_GBS) if full else None,
                              "note": "decoder GEMV weights as OCP e4m3 + per-row fp32 scale (7.07 GB/step instead of 14.14); "
                                      "prefill, KV cache and activations stay 16-bit; NOT part of `value`"}
-    if world == 1:
+    rgb = pins = None
+    if world == 1 and not shard and not do3:
         # image front-end (row f-1), outside the timed region: raw RGB bytes on the host -> normalised tiles in HBM
         pins = [(448, 896), (896, 448), (896, 896), (1344, 448), (448, 1344), (1344, 1344)]
         rgb = np.random.default_rng(0).integers(0, 256, (380, 570, 3), dtype=np.uint8)       # size of the reference's sample picture -> 3 tiles
@@ -575,8 +692,53 @@ def main():
             proc.process_anyres(rgb, pins, dtype=eng.torch_dtype)
             torch.cuda.synchronize(); fe.append((time.perf_counter() - t0) * 1e3)
         res["frontend_ms_p50"] = sorted(fe[2:])[len(fe[2:]) // 2]
-        if not a.no_cpu_baseline:          # CPU baseline: rank 0 at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(cfg, S, a.gen, n_tiles)
+
+    # ---- side blocks of the default run (N = 1): BASELINE configs[3] and configs[4], each in its own context
+    side = a.workload == "both" and world == 1 and not shard and not a.no_side and full
+    if side:
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+        # configs[3]
+        cfg3 = omchat8b_21()
+        S3 = a.images * cfg3.num_image_tokens + a.text_tokens
+        e3 = new_engine(cfg3, S3, a.gen, 1, a.images)
+        e3.fill_synthetic(0)
+        px3, ids3, fe3 = make_inputs_dynamic(e3, cfg3, a.images)
+        r3 = run_workload(e3, e3.encode_images, px3, ids3, min(a.steps, 3), 1, a.gen)
+        s3 = summarise(r3, cfg3)
+        ro, rp, rv = rooflines(r3, cfg3)
+        s3.update({"workload": f"OmChat-2.1-8B (InternViT-300M 24L + Qwen2-7B 28L), configs[3]: 1 sample = {a.images} pictures of 448x448 -> dynamic "
+                               f"tiling -> {int(px3.shape[0])} tiles in one tower batch + {a.text_tokens} text ids -> prefill S={r3['S']}, {a.gen} greedy "
+                               f"decode tokens, batch 1",
+                   "roofline": ro, "roofline_prefill": rp, "roofline_vit": rv, "frontend_ms_p50": fe3, "device_gb": e3.device_bytes() / 1e9,
+                   "note": "side measurement in its own context; NOT part of `value`"})
+        res["configs3"] = s3
+        e3.close(); del e3, px3
+        torch.cuda.empty_cache()
+        # configs[4]
+        gen4 = min(64, a.gen)
+        S4 = a.frames * cfg.num_image_tokens + a.text_tokens
+        e4 = new_engine(cfg, S4, gen4, 1, a.frames)
+        e4.fill_synthetic(0)
+        e4.enable_fp8_decode(True); e4.enable_fp8_kv(True); e4.enable_fp8_prefill(True)
+        px4, ids4 = make_inputs(1, e4, cfg, a.frames)
+        r4 = run_workload(e4, e4.encode_images, px4, ids4, min(a.steps, 2), 1, gen4)
+        s4 = summarise(r4, cfg, bytes_f8)
+        ro, rp, rv = rooflines(r4, cfg, f8=True)
+        s4.update({"workload": f"OmChat-13B, configs[4]: one {a.frames}-frame clip = {a.frames} tiles + {a.text_tokens} text ids -> prefill S={S4}, {gen4} "
+                               f"greedy decode tokens, batch 1; fp8: e4m3 decode weights + e4m3 KV cache + fp8 x fp8 MFMA qkv / gate|up prefill GEMMs",
+                   "dtype": a.dtype + " activations, e4m3 weights (decode GEMVs, qkv / gate|up prefill GEMMs) and KV cache",
+                   "roofline": ro, "roofline_prefill": rp, "roofline_vit": rv, "device_gb": e4.device_bytes() / 1e9,
+                   "note": "side measurement in its own context, a quantised computation; NOT part of `value`"})
+        res["configs4"] = s4
+        e4.close(); del e4, px4
+        torch.cuda.empty_cache()
+    # GEMM tile choices come from the committed omchat_amd/gemm_tune_gfx950.txt: 0 = no first-use tuning ran in this process
+    res["gemm_tune_measurements"] = int(_lib.lib().omchat_gemm_tune_runs())
+    if world == 1 and not shard and not a.no_cpu_baseline:          # CPU baseline: rank 0 at N = 1 only
+        res["cpu_baseline"] = cpu_baseline(cfg, S, a.gen, n_tiles)
+        if rgb is not None:
             from PIL import Image
             from transformers import CLIPImageProcessor
             from oracle.preproc import pil_process_anyres_image      # the reference's PIL recipe (checker side), timed as the CPU baseline

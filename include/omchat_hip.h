@@ -310,6 +310,10 @@ int omchat_ctx_allreduce(omchat_ctx* ctx, void* buf, size_t count, int dtype, vo
  * verified with several rank contexts on ONE GPU; production contexts never set it. */
 typedef int (*omchat_allreduce_fn)(void* user, void* buf, size_t count, int dtype, void* stream);
 int omchat_set_allreduce_hook(omchat_ctx* ctx, omchat_allreduce_fn fn, void* user);
+/* Measurement seam (bench.py --shard-of N): an omchat_allreduce_fn that does nothing.  A context created with tp_size = N and this
+ * hook runs ONE rank's share of the tensor-parallel work (its GEMM / GEMV / attention shard shapes and launch sequence) on a single
+ * GPU with the exchanges removed: kernel time per rank without an N-GPU node.  The results are NOT the model's outputs. */
+int omchat_allreduce_noop(void* user, void* buf, size_t count, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

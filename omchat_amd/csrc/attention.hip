@@ -372,14 +372,37 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int swz_b(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <typename T, int NW, bool GQA>
+// LDS images of the second-generation kernel.  Head dim 128: 256-byte rows, K and V share image (b) above.  Head dim 64 (InternViT-300M,
+// round 3): 128-byte rows, two key rows per 256-byte bank row R = row >> 1, slot = ((row & 1) << 3 | chunk) ^ f(R) with
+//   K: f = R & 7          (the 32-row ds_read_b128 operand read: a 16-lane group holds 8 distinct R whose low 3 bits differ, and the two
+//                          rows of one R differ in slot bit 3)
+//   V: f = (R & 1) << 2   (a transposed read's 32-lane half takes rows r0 .. r0 + 3 (two R) x 4 consecutive chunks: bit 3 = row parity,
+//                          bit 2 = R parity, low bits = chunk: 16 distinct slots)
+// tile_off<D, IS_V>(row, ch) = byte offset of 16-byte chunk ch of key row `row`; tile_src<D, IS_V>(slot_index) = (row, chunk) stored at a
+// lane-linear LDS slot (the LDS-DMA destination is lane-linear, so the permutation is applied to the SOURCE address).
+template <int D, bool IS_V> __device__ __forceinline__ int tile_off(int row, int ch) {
+  if constexpr (D == 128) return 256 * row + 16 * (ch ^ swz_b(row));
+  const int R = row >> 1, f = IS_V ? ((R & 1) << 2) : (R & 7);
+  return 256 * R + 16 * ((((row & 1) << 3) | ch) ^ f);
+}
+template <int D, bool IS_V> __device__ __forceinline__ void tile_src(int piece, int& row, int& ch) {
+  if constexpr (D == 128) { row = piece >> 4; ch = (piece & 15) ^ swz_b(row); return; }
+  const int R = piece >> 4, f = IS_V ? ((R & 1) << 2) : (R & 7);
+  const int vc = (piece & 15) ^ f;
+  row = 2 * R + (vc >> 3); ch = vc & 7;
+}
+
+template <typename T, int NW, bool GQA, int D = 128>
 __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   constexpr int NT = NW * 64;
-  constexpr int TILE = KV_TILE * 256;                 // bytes of one K (or V) tile
+  constexpr int RB = 2 * D;                           // bytes per key row
+  constexpr int TILE = KV_TILE * RB;                  // bytes of one K (or V) tile
   constexpr int BUF = 2 * TILE;
-  constexpr int NPIECE = KV_TILE * 16;                // 16-byte pieces per tile
+  constexpr int NPIECE = TILE / 16;                   // 16-byte pieces per tile
   constexpr int ROUNDS = (NPIECE + NT - 1) / NT;
+  constexpr int KS = D / 16;                          // k-steps of S^T = K Q^T
+  constexpr int DB = D / 32;                          // 32-row blocks of O^T
   __shared__ __attribute__((aligned(256))) char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -407,32 +430,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const bool wave_active = (GQA ? wave < n_rep : true) && q0 < p.Sq;       // wave-uniform
 
   // ---- Q fragments (B operand of S^T): lane holds Q[query qc][d = 16 s + 8 hh + j]
-  frag_t qf[8];
+  frag_t qf[KS];
   const int qrow = q0 + qc;
   {
     const int rr = qrow < p.Sq ? qrow : p.Sq - 1;
     const T* qp = (const T*)p.Q + b * p.q_sb + (wave_active ? hq : 0) * p.q_sh + (int64_t)rr * p.q_sr;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = ld8<T>(qp + s * 16 + hh * 8);
+    for (int s = 0; s < KS; ++s) qf[s] = ld8<T>(qp + s * 16 + hh * 8);
   }
 
-  f32x16 o[4];
+  f32x16 o[DB];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = M_FLOOR, l_run = 0.f;
 
-  // ---- staging: piece = i * NT + tid -> LDS row = piece >> 4, physical chunk = piece & 15 (lane-linear destination, permuted source)
+  // ---- staging: piece = i * NT + tid -> lane-linear LDS slot, permuted source (tile_src)
   // A whole tile (every key < kv_len) is addressed as  wave-uniform tile base + a 32-bit lane offset computed once  (the per-tile 64-bit
   // row * stride products were ~60 of the ~200 VALU instructions a key tile costs, and VALU time adds to MFMA time here: profiles/
   // r02_b_pmc_attn.txt); only the last, partial tile clamps its rows (masked keys must stay finite) the long way.
   unsigned koff[ROUNDS], voff[ROUNDS];
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
-    const int piece = i * NT + tid, row = piece >> 4, pc = piece & 15;
-    const int ch = pc ^ swz_b(row);
+    int row, ch;
+    tile_src<D, false>(i * NT + tid, row, ch);
     koff[i] = (unsigned)row * (unsigned)(p.k_sr * 2) + ch * 16;
+    tile_src<D, true>(i * NT + tid, row, ch);
     voff[i] = (unsigned)row * (unsigned)(p.v_sr * 2) + ch * 16;
   }
   auto issue_tile = [&](int t, int buf) {
@@ -453,10 +477,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i) {
       if ((i + 1) * NT <= NPIECE || i * NT + wave * 64 < NPIECE) {
-        const int piece = i * NT + tid, row = piece >> 4, pc = piece & 15;
+        int row, ch;
+        tile_src<D, false>(i * NT + tid, row, ch);
         int kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;
-        const int ch = pc ^ swz_b(row);
         __builtin_amdgcn_global_load_lds((gptr_t)(Kg + (int64_t)kr * p.k_sr + ch * 8), (lptr_t)(Kw + (i * NT + wave * 64) * 16), 16, 0, 0);
+        tile_src<D, true>(i * NT + tid, row, ch);
+        kr = t * KV_TILE + row; kr = kr < kv_len ? kr : kv_len - 1;
         __builtin_amdgcn_global_load_lds((gptr_t)(Vg + (int64_t)kr * p.v_sr + ch * 8), (lptr_t)(Vw + (i * NT + wave * 64) * 16), 16, 0, 0);
       }
     }
@@ -488,11 +514,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
       const int row = kt * 32 + qc;
-      const char* kb = Ks + row * 256;
-      const int sw = swz_b(row);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const frag_t kf = *reinterpret_cast<const frag_t*>(kb + (((2 * s + hh) ^ sw) << 4));
+      for (int s = 0; s < KS; ++s) {
+        const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + tile_off<D, false>(row, 2 * s + hh));
         sc[kt] = mfma32(kf, qf[s], sc[kt]);
       }
     }
@@ -526,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] *= alpha;
+      for (int d = 0; d < DB; ++d) o[d] *= alpha;
     }
     const float nmc = -m_run * p.c;
     frag_t pf[2][2];
@@ -558,13 +582,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int r_lo = kt * 32 + s2 * 16 + v_row_lo, r_hi = r_lo + 8;
-        const char* rb_lo = Vs + r_lo * 256 + v_byte;
-        const char* rb_hi = Vs + r_hi * 256 + v_byte;
-        const int sw_lo = swz_b(r_lo), sw_hi = swz_b(r_hi);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const s16x4 lo = tr_read(rb_lo + (((4 * db + v_ch_lo) ^ sw_lo) << 4));
-          const s16x4 hi = tr_read(rb_hi + (((4 * db + v_ch_lo) ^ sw_hi) << 4));
+        for (int db = 0; db < DB; ++db) {
+          const s16x4 lo = tr_read(Vs + tile_off<D, true>(r_lo, 4 * db + v_ch_lo) + v_byte);
+          const s16x4 hi = tr_read(Vs + tile_off<D, true>(r_hi, 4 * db + v_ch_lo) + v_byte);
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[db] = mfma32(__builtin_bit_cast(frag_t, cat), pf[kt][s2], o[db]);
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     T* op = (T*)p.O + b * p.o_sb + hq * p.o_sh + (int64_t)qrow * p.o_sr + 4 * hh;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         typename V8<T>::half_type h4;
@@ -1068,6 +1089,13 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
+  if (hd == 64 && g_attn_v2 && a.q_heads == a.kv_heads) {      // InternViT-300M on the second-generation kernel (round 3)
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false, 64>), grid, dim3(256), 0, s, p);
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false, 64>), grid, dim3(256), 0, s, p);
+    else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
   if (hd == 64) {
     if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn_kernel<f16, 4, 2, 64>), grid, dim3(256), 0, s, p);
     else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn_kernel<bf16, 4, 2, 64>), grid, dim3(256), 0, s, p);

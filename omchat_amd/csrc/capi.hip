@@ -26,6 +26,8 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   return 1;
 }
 
+extern "C" int omchat_allreduce_noop(void*, void*, size_t, int, void*) { return 0; }
+
 extern "C" int omchat_gemm_tune_load(const char* path) { OM_CHECK(path, "null path"); return gemm_tune_load(path); }
 extern "C" int omchat_gemm_tune_dump(const char* path) { OM_CHECK(path, "null path"); return gemm_tune_dump(path); }
 extern "C" long omchat_gemm_tune_runs(void) { return gemm_tune_runs(); }

@@ -14,7 +14,12 @@
 // Slots alternate with the call parity, which makes ONE barrier per call enough: a rank overwrites slot k&1 in call k+2 only
 // after it has left the barrier of call k+1, which every peer enters after its kernel of call k (its reads of that slot) is
 // complete (kernels of one rank are stream-ordered).  Barrier = per (block, source rank) monotonic epoch flags; the epoch
-// lives in a private per-block counter that the kernel itself advances (replay-invariant arguments: hipGraph-safe).
+// lives in a private per-block counter that the kernel itself advances.
+// ORDERING REQUIREMENT: the slot parity is a HOST counter baked into the launch arguments, so all peer kernels of a rank must be issued
+// in ONE total order that is the same on every rank, each launched exactly once per host call: never capture a peer call into a
+// hipGraph (a replay would repeat the captured parity: two consecutive calls on one slot) and never interleave peer calls from
+// unordered streams.  The launchers below refuse a capturing stream; model.hip restricts decode graphs to tp_size == 1 and chains the
+// communication stream to the launch stream with events (gemm_allreduce).
 // Visibility: payload stores are sc0 sc1 (system-scope write-through) and drained (vmcnt(0)) by every storing wave before the
 // workgroup barrier that precedes the flag stores; payload loads are sc0 sc1 (bypass L1 / L2).  Unless the `fast` mode is set,
 // one lane additionally issues a system-scope release before the flags and a system-scope acquire after the poll
@@ -348,6 +353,16 @@ extern "C" int omchat_peer_set_mode(omchat_peer* p, int fast, size_t oneshot_max
 
 extern "C" size_t omchat_peer_capacity(omchat_peer* p) { return p ? p->cap : 0; }
 
+static int peer_refuse_capture(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    omchat_set_error("peer all-reduce launched on a capturing stream: the slot parity is a host counter and is not replay-invariant");
+    return 1;
+  }
+  (void)hipGetLastError();
+  return 0;
+}
+
 extern "C" int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, int dtype, void* stream) {
   OM_CHECK(p && buf, "null argument");
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == 2, "bad dtype");
@@ -356,6 +371,7 @@ extern "C" int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, in
   const size_t esz = dtype == 2 ? 4 : 2;
   OM_CHECK(((uintptr_t)buf & 15) == 0 && (count * esz) % 16 == 0, "buffer and byte count must be multiples of 16");
   hipStream_t s = (hipStream_t)stream;
+  if (peer_refuse_capture(s)) return 1;
   PeerK k{};
   for (int r = 0; r < p->size; ++r) k.base[r] = (char*)p->base[r];
   k.ctr = p->ctr; k.err = p->err; k.rank = p->rank; k.size = p->size; k.fast = p->fast; k.cap = p->cap;
@@ -398,8 +414,9 @@ extern "C" int omchat_peer_resid_rmsnorm(omchat_peer* p, int dtype, void* x, int
   PeerK k{};
   for (int r = 0; r < p->size; ++r) k.base[r] = (char*)p->base[r];
   k.ctr = p->ctr; k.err = p->err; k.rank = p->rank; k.size = p->size; k.fast = p->fast; k.cap = p->cap;
-  const int parity = (int)(p->calls++ & 1);
   hipStream_t s = (hipStream_t)stream;
+  if (peer_refuse_capture(s)) return 1;
+  const int parity = (int)(p->calls++ & 1);
   if (dtype == OMCHAT_F16)
     hipLaunchKernelGGL(peer_resid_rmsnorm_kernel<f16>, dim3(rows), dim3(FN_THREADS), 0, s, k, parity, (f16*)x, ldx, part, ks, rows, (const f16*)w, (f16*)xn, ldn, H, eps, pack_nb);
   else

@@ -15,6 +15,8 @@
 #include <array>
 #include <stdio.h>
 #include <stdlib.h>
+#include <limits.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -678,6 +680,18 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_tune_mu);
   auto it = g_tuned.find(key);
   if (it != g_tuned.end()) return it->second;
+  {
+    // a measured class of the same (dtype, epilogue, N, K, ldc) whose row-tile count is within one tile or 1/8: prompts come in every
+    // length, and a live request must not pay 5 candidates x 4 launches because its S rounds to a row-tile count nobody has seen
+    int best_d = INT_MAX, best_t = 0;
+    for (auto& kv : g_tuned) {
+      const auto& k = kv.first;
+      if (k[0] != key[0] || k[2] != key[2] || k[3] != key[3] || k[4] != key[4]) continue;
+      const int d = k[1] > key[1] ? k[1] - key[1] : key[1] - k[1];
+      if (d < best_d) { best_d = d; best_t = kv.second; }
+    }
+    if (best_t && best_d <= std::max(1, key[1] / 8)) return best_t;          // not cached under the new key: the file stays what was measured
+  }
   const int heuristic = pick_tile(a.M, a.N, a.epi);
   if ((double)a.M * a.N * a.K < 4e9) return g_tuned[key] = heuristic;            // < 8 GFLOP: launch-bound, nothing to choose
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

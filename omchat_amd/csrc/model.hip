@@ -97,7 +97,7 @@ struct omchat_ctx {
   struct DecLayerP { void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr; };
   std::vector<DecLayerP> dlp;
   void* t_lmP = nullptr;
-  bool pk_ready = false;
+  bool pk_ready = false, pk_unavailable = false;
   void* t_lm8 = nullptr; float* t_lm8_s = nullptr;
   bool fp8_decode = false, fp8_stale = false;
   // BASELINE configs[4]: fp8 KV cache for decode (e4m3 bytes in the layout of the 16-bit cache + one fp32 scale per (layer, sequence,
@@ -875,6 +875,7 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
   OM_CHECK(omchat_weights_missing(ctx) == 0, std::string(omchat_last_error()));
   for (int i = 0; i < b; ++i) OM_CHECK(lengths[i] >= 1 && lengths[i] <= S, "lengths must be in [1, S]");
   hipStream_t s = (hipStream_t)stream;
+  if (ctx->fp8_prefill && ctx->fp8_stale) TRY(ensure_fp8_weights(ctx));      // weights were reloaded: re-quantise in place
   const int H = c.t_hidden, It = c.t_mlp, rows = b * S, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   const bool lead = ctx->tp_rank == 0;
 
@@ -977,19 +978,40 @@ extern "C" int omchat_prefill_left(omchat_ctx* ctx, const void* embeds, int b, i
   return prefill_impl(ctx, embeds, b, S, lengths, logits_last, hidden_out, stream, true);
 }
 
-// (re)build the packed weight replica of the decode-streamed decoder weights; synchronous, never inside a graph capture
+// (re)build the packed weight replica of the decode-streamed decoder weights; synchronous, never inside a graph capture.
+// The replica is optional (+14 GB at OmChat-13B): when it does not fit, the context remembers that (pk_unavailable) and batched decode
+// keeps streaming the row-major weights (w_packed = 0), which every kernel still supports.
 static int ensure_packed(omchat_ctx* ctx) {
-  if (!g_pack_replica || ctx->pk_ready) return 0;
+  if (!g_pack_replica || ctx->pk_ready || ctx->pk_unavailable) return 0;
   const omchat_config& c = ctx->c;
   const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   if (qkvd % 16 || H % 16 || c.t_vocab % 16) return 0;          // odd geometry: stay on the row-major weights
   if (ctx->dlp.empty()) {
-    ctx->dlp.resize(c.t_layers);
-    for (auto& P : ctx->dlp) {
-      TRY(ctx->alloc(&P.wqkv, (size_t)qkvd * H * 2)); TRY(ctx->alloc(&P.wo, (size_t)H * qd * 2));
-      TRY(ctx->alloc(&P.wgu, (size_t)2 * It * H * 2)); TRY(ctx->alloc(&P.wd, (size_t)H * It * 2));
+    // allocate into locals and commit only when every buffer exists: a half-built table must never reach launch_pack_w
+    std::vector<omchat_ctx::DecLayerP> fresh(c.t_layers);
+    std::vector<void*> got;
+    void* lmP = nullptr;
+    auto grab = [&](void** p, size_t n) -> bool {
+      if (hipMalloc(p, n) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+      got.push_back(*p);
+      return true;
+    };
+    bool ok = true;
+    for (auto& P : fresh) {
+      ok = ok && grab(&P.wqkv, (size_t)qkvd * H * 2) && grab(&P.wo, (size_t)H * qd * 2) && grab(&P.wgu, (size_t)2 * It * H * 2) &&
+           grab(&P.wd, (size_t)H * It * 2);
+      if (!ok) break;
     }
-    TRY(ctx->alloc(&ctx->t_lmP, (size_t)c.t_vocab * H * 2));
+    ok = ok && grab(&lmP, (size_t)c.t_vocab * H * 2);
+    if (!ok) {
+      for (void* p : got) (void)hipFree(p);
+      ctx->pk_unavailable = true;
+      return 0;
+    }
+    for (void* p : got) ctx->allocs.push_back(p);
+    ctx->bytes += (size_t)c.t_layers * ((size_t)qkvd * H + (size_t)H * qd + (size_t)2 * It * H + (size_t)H * It) * 2 + (size_t)c.t_vocab * H * 2;
+    ctx->dlp.swap(fresh);
+    ctx->t_lmP = lmP;
   }
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i]; auto& P = ctx->dlp[i];
@@ -1178,6 +1200,9 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   OM_CHECK(Lmax <= c.max_seq, "KV cache full (max_seq)");
   hipStream_t s = (hipStream_t)stream;
   if (b > 1 && b <= 32) TRY(ensure_packed(ctx));      // first batched step (or after a weight reload): build the packed replica
+  // a weight reload (omchat_load_tensor) leaves the e4m3 replica stale: re-quantise IN PLACE before streaming it (same device
+  // pointers, so a captured decode graph stays valid and replays the fresh bytes)
+  if (ctx->fp8_decode && ctx->fp8_stale) TRY(ensure_fp8_weights(ctx));
   ctx->graph_steps++;
   // graph replay needs replay-invariant arguments: single-GPU fused path only; with profiling on, every 8th step runs eagerly
   // so that the HIP-event brackets of the dominant kernel are still recorded inside the timed region

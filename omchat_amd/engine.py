@@ -87,11 +87,13 @@ class Engine:
             if n:
                 raise KeyError(self.lib.omchat_last_error().decode())
 
-    def fill_synthetic(self, seed=0):
-        """Deterministic synthetic weights (omchat_amd/synth.py's generator, evaluated on the device).  Under tensor parallelism
+    def fill_synthetic(self, seed=0, local=False):
+        """local=True (shard profiling, bench.py --shard-of): every tensor of THIS rank's shapes is filled directly -- right geometry,
+        not a sharding of the TP = 1 values.
+        Deterministic synthetic weights (omchat_amd/synth.py's generator, evaluated on the device).  Under tensor parallelism
         every rank generates each FULL tensor on its GPU and keeps its shard (tp.shard_tensor semantics: zero-padded heads,
         replicated kv heads), so a TP = N group computes the same function as the TP = 1 context filled with the same seed."""
-        if self.tp_size == 1:
+        if self.tp_size == 1 or local:
             check(self.lib.omchat_fill_synthetic(self.h, seed))
             return
         import math
@@ -111,6 +113,12 @@ class Engine:
                 torch.cuda.current_stream().synchronize()
                 self.load_tensor(key, shard_tensor(key, full.view(*shape), self.cfg, self.tp_rank, self.tp_size))
                 del full
+
+    def set_noop_allreduce(self):
+        """Measurement only (bench.py --shard-of N): the tensor-parallel sums of this context become no-ops, so one rank's share of the
+        work runs alone on one GPU.  The outputs are then NOT the model's outputs."""
+        fn = C.cast(self.lib.omchat_allreduce_noop, C.c_void_p)
+        check(self.lib.omchat_set_allreduce_hook(self.h, fn, None))
 
     def set_peer(self, peer, max_bytes=0, all_sizes=False):
         """attach a peer all-reduce group member (tp.init_peer) for the tensor-parallel sums of this context"""

@@ -186,7 +186,13 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         if streamer is not None:
             streamer.put(input_ids.cpu())
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True)
-        tok = self.engine.argmax(out.logits[:, 0]) if self.engine.tp_size == 1 else torch.argmax(out.logits[:, 0], dim=-1).to(torch.int32)
+        if self.engine.tp_size == 1:
+            tok = self.engine.argmax(out.logits[:, 0])
+        else:
+            # gathered [b, V] logits: first index wins an exact tie, the rule Engine.argmax / omchat_greedy implement (torch.argmax
+            # does not promise it)
+            lg = out.logits[:, 0]
+            tok = (lg == lg.max(dim=-1, keepdim=True).values).to(torch.int32).argmax(dim=-1).to(torch.int32)
         # The KV cache is context-owned with a fixed capacity (the reference's DynamicCache grows without bound): generate as
         # many tokens as fit and stop cleanly, returning what was produced, instead of failing mid-stream with 'KV cache full'.
         room = self.engine.c.max_seq - max(self.engine.kv_lengths(b)) + 1

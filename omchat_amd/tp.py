@@ -213,19 +213,32 @@ def peer_selftest(peer, rank, size, iters=48, sizes=(16, 3584 * 4, 3 * 3584 * 4,
         ref = sum(val(r) for r in range(size))
         return int((x.to(torch.float32) != ref).sum())
 
+    # Every verdict is taken COLLECTIVELY (MIN of the ok flag over the bootstrap group): a rank that left alone would leave the others
+    # issuing all-reduces against a peer that no longer takes part -- one barrier timeout per call -- and would leave the per-block
+    # epochs of the ranks out of step.
+    def agree(ok):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or size == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    def healthy():
+        _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
+        return agree(not err.value and not bad)
+
     # one small call first, checked at once: a group that cannot talk (a peer that never arrives, a mapping that does not work across
     # these devices) shows as a barrier timeout here, and the test must cost ONE timeout, not one per call
     bad += one(0, 3584 * 4, torch.float32, _lib.F32)
-    _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
-    if err.value or bad:
+    if not healthy():
         return False, dict(mismatched_elements=bad, timeout=bool(err.value), iters=0)
     for it in range(iters):
         for nbytes in sizes:
             for dt, code in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16)):
                 bad += one(it, nbytes, dt, code)
         if it in (0, 1, 7):                                  # early exits: never sit through hundreds of timeouts
-            _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
-            if err.value or bad:
+            if not healthy():
                 return False, dict(mismatched_elements=bad, timeout=bool(err.value), iters=it + 1)
-    _lib.check(lib.omchat_peer_error(peer, C.byref(err)))
-    return bad == 0 and err.value == 0, dict(mismatched_elements=bad, timeout=bool(err.value), iters=iters)
+    ok = healthy()
+    return ok, dict(mismatched_elements=bad, timeout=bool(err.value), iters=iters)

@@ -1,0 +1,211 @@
+"""Round-3 GPU tests (all through the C ABI):
+  * BASELINE configs[3] at FULL size: OmChat-2.1-8B geometry (InternViT-300M 24 layers + Qwen2-7B 28 layers), one sample = 8 pictures
+    through the dynamic tiling of mm_utils.py:276-323 -> 8 tiles in one tower batch, S = 8704: size-independent properties
+    (determinism, batch independence of the tower at 8 tiles, splice = pure copy, prefill / decode consistency)
+  * the second-generation prefill attention at head_dim 64 (intern_vit_300m/modeling_intern_vit.py:205-222 shapes) vs fp32 torch
+  * a weight reload while fp8 decode stays ENABLED must not stream the stale e4m3 replica
+  * bench.py --shard-of: one rank's shard context with the no-op all-reduce runs the whole path
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from gpu_util import DT, CODE, TOL, dev, rnd, rel, sync, ptr, randn
+from test_gpu_ops import _attn_ref
+from omchat_amd import synth, _lib
+from omchat_amd.config import omchat8b_21, omchat13b, tiny
+from omchat_amd.engine import Engine
+from omchat_amd.image_processing import HipImageProcessor
+
+DTS = ["bf16", "f16"]
+CONSIST_TOL = {"bf16": 6e-2, "f16": 1e-2}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# head_dim 64 on attn2_kernel: MHA shapes (the GQA shapes of test_gpu_vit300m.py stay on the first-generation kernel)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,S,H,causal,lens", [
+    (3, 1025, 16, 0, None),            # InternViT-300M: 16 heads, 1024 + 1 tokens (ragged last key tile with ONE key, last query block with one row)
+    (2, 200, 4, 0, [200, 77]),         # ragged key lengths
+    (1, 300, 2, 1, None),              # causal diagonal inside tiles
+    (2, 129, 3, 1, [129, 64]),
+    (1, 64, 1, 0, None),               # exactly one tile
+    (1, 1, 2, 0, None),                # a single token
+])
+def test_attn2_head_dim_64_mha(gpu_lib, dt, b, S, H, causal, lens):
+    D = 64
+    q = rnd(randn((b, S, H, D), 11), dt); k = rnd(randn((b, H, S, D), 12), dt); v = rnd(randn((b, H, S, D), 13), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    out = torch.full((b, S, H, D), float("nan"), dtype=DT[dt], device="cuda")
+    dl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    _lib.check(gpu_lib.omchat_op_attn_prefill_d(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, S, S, H, H, D, ptr(dl), causal, 0, 0.125, None))
+    sync()
+    ref = _attn_ref(q, k, v, 0.125, causal, 0, lens or [S] * b)
+    for i in range(b):
+        n = S if lens is None else lens[i]
+        assert torch.isfinite(out[i, :n].float()).all()
+        assert rel(out[i, :n], ref[i, :n]) < TOL[dt], rel(out[i, :n], ref[i, :n])
+    # the first-generation kernel (tuning key 8 = 0) computes the same quantity: A/B seam stays usable
+    out1 = torch.full_like(out, float("nan"))
+    _lib.check(gpu_lib.omchat_op_set_tuning(8, 0))
+    try:
+        _lib.check(gpu_lib.omchat_op_attn_prefill_d(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out1), b, S, S, H, H, D, ptr(dl), causal, 0, 0.125, None))
+        sync()
+    finally:
+        _lib.check(gpu_lib.omchat_op_set_tuning(8, 1))
+    for i in range(b):
+        n = S if lens is None else lens[i]
+        assert rel(out1[i, :n], out[i, :n]) < 2 * TOL[dt]
+
+
+def test_attn2_head_dim_64_rescale_branch_is_exercised(gpu_lib):
+    """cdna_hip_programming.md rule 26: the lazy-rescale branch (running max moves by > 2^8) must be FORCED: one key row is spiked against
+    every query late in the sequence so that the reference point jumps at a chosen tile"""
+    dt, D, S, H = "bf16", 64, 320, 2
+    q = rnd(randn((1, S, H, D), 21), dt); k = rnd(randn((1, H, S, D), 22), dt); v = rnd(randn((1, H, S, D), 23), dt)
+    k[0, :, 200] = rnd(q[0, 5] * 12.0, dt)            # scores ~ 12 * |q|^2 * 0.125 ~ 100 >> 8 / log2(e): forces the rescale at key tile 3
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    out = torch.full((1, S, H, D), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_attn_prefill_d(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), 1, S, S, H, H, D, None, 0, 0, 0.125, None))
+    sync()
+    ref = _attn_ref(q, k, v, 0.125, 0, 0, [S])
+    assert torch.isfinite(out.float()).all()
+    assert rel(out[0], ref[0]) < TOL[dt], rel(out[0], ref[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] at full size
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def eng8b(gpu_lib):
+    cfg = omchat8b_21()
+    S = 8 * 1024 + 512
+    e = Engine(cfg, dtype="bf16", max_seq=S + 40, max_batch=1, max_tiles=8, max_prefill_rows=S + 8)
+    e.fill_synthetic(0)
+    yield e
+    e.close()
+
+
+def _eight_pictures(e):
+    """8 pictures of 448 x 448 through dynamic_preprocess + preprocess on the device: a square tile-sized picture picks the 1 x 1 grid
+    (no thumbnail: mm_utils.py:307), so the sample is 8 tiles"""
+    proc = HipImageProcessor(crop_size=448)
+    rng = np.random.default_rng(3)
+    tiles = [proc.process_dynamic(rng.integers(0, 256, (448, 448, 3), dtype=np.uint8), max_num=6, dtype=e.torch_dtype) for _ in range(8)]
+    assert all(t.shape == (1, 3, 448, 448) for t in tiles)
+    return torch.cat(tiles, 0).contiguous()
+
+
+def test_full_size_configs3_tower_8_tiles(eng8b):
+    px = _eight_pictures(eng8b)
+    a = eng8b.encode_images(px); sync()
+    b = eng8b.encode_images(px); sync()
+    assert a.shape == (8, 1024, 3584) and torch.isfinite(a.float()).all()
+    assert torch.equal(a, b)                                              # determinism
+    # batch independence at 8 tiles: tile i alone, and the tiles in another order, give the same rows
+    one = eng8b.encode_images(px[5:6]); sync()
+    assert rel(one[0], a[5]) < 1e-6
+    perm = torch.tensor([7, 2, 5, 0, 1, 6, 3, 4])
+    c = eng8b.encode_images(px[perm]); sync()
+    assert rel(c, a[perm]) < 1e-6
+    # a wide picture takes the multi-tile branch of the same front end: 896 x 448 -> 2 x 1 grid + thumbnail = 3 tiles in the same batch
+    proc = HipImageProcessor(crop_size=448)
+    wide = proc.process_dynamic(np.random.default_rng(4).integers(0, 256, (448, 896, 3), dtype=np.uint8), max_num=6, dtype=eng8b.torch_dtype)
+    assert wide.shape[0] == 3
+    w = eng8b.encode_images(torch.cat([wide, px[:5]], 0)); sync()
+    assert rel(w[3:], a[:5]) < 1e-6
+
+
+def test_full_size_configs3_prefill_decode_consistency(eng8b):
+    S = 8 * 1024 + 512
+    runs0 = _lib.lib().omchat_gemm_tune_runs()
+    px = _eight_pictures(eng8b)
+    feats = eng8b.encode_images(px)
+    text = synth.token_ids(512, 151643, 1).tolist()
+    row = []
+    for i in range(8):
+        row += [-200, text[i]]
+    ids = torch.tensor([row[:-1] + text[7:]])
+    embeds, lengths, valid = eng8b.splice(ids, None, feats); sync()
+    assert lengths == [S] and bool(valid.all())
+    for i in range(8):                                                   # pure copies, tile i at its sentinel (omchat_arch.py:133-158)
+        assert torch.equal(embeds[0, i * 1025:i * 1025 + 1024], feats[i])
+    logits_a, _ = eng8b.prefill(embeds, [S]); sync()
+    tok = int(torch.argmax(logits_a[0]))
+    nxt, step_logits = eng8b.decode_step(torch.tensor([tok]), want_logits=True); sync()
+    seq = [tok, int(nxt[0])]
+    t2 = nxt
+    for _ in range(6):
+        t2, _ = eng8b.decode_step(t2)
+        seq.append(int(t2[0]))
+    ids2 = torch.cat([ids, torch.tensor([[tok]])], dim=1)
+    embeds2, _, _ = eng8b.splice(ids2, None, feats)
+    logits_b, _ = eng8b.prefill(embeds2, [S + 1]); sync()
+    r = rel(step_logits[0], logits_b[0])
+    print("configs3 shape prefill/decode consistency", r)
+    assert torch.isfinite(logits_b).all() and r < CONSIST_TOL["bf16"], r
+    logits_c, _ = eng8b.prefill(embeds, [S])
+    assert torch.equal(logits_c, logits_a)
+    t3 = eng8b.argmax(logits_c)
+    seq2 = [int(t3[0])]
+    for _ in range(7):
+        t3, _ = eng8b.decode_step(t3)
+        seq2.append(int(t3[0]))
+    assert seq2 == seq
+    assert _lib.lib().omchat_gemm_tune_runs() == runs0, "a GEMM class of the configs[3] workload is missing from gemm_tune_gfx950.txt"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ADVICE r02 (model.hip): reload with fp8 decode left on
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("graph", [False, True])
+def test_fp8_decode_follows_a_reload_without_reenabling(gpu_lib, graph):
+    cfg = tiny()
+    sd = synth.state_dict(cfg, 5)
+    e = Engine(cfg, dtype="bf16", max_seq=64, max_batch=1, max_tiles=1, vision=False)
+    e.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
+    if graph:
+        e.enable_decode_graph(True)
+    x = torch.randn(1, 9, 256, generator=torch.Generator().manual_seed(0)) * 0.5
+    e.enable_fp8_decode(True)
+
+    def step():
+        e.prefill(x)
+        _, lg = e.decode_step(torch.tensor([7]), want_logits=True); sync()
+        return lg.clone()
+    a = step()
+    name = "model.layers.1.mlp.down_proj.weight"
+    e.load_tensor(name, torch.from_numpy(sd[name]) * 3.0)               # fp8 decode stays enabled; nobody calls enable again
+    b = step()
+    assert not torch.equal(a, b), "decode streamed the stale e4m3 replica after a weight reload"
+    e.enable_fp8_decode(False)
+    if graph:
+        e.enable_decode_graph(False)
+    ref = step()
+    assert rel(b, ref) < 0.12                                           # e4m3 weights vs the 16-bit weights of the SAME (new) values
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --shard-of N: a rank context of a TP group with the no-op all-reduce
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 8])
+def test_shard_context_runs_the_whole_path(gpu_lib, n):
+    cfg = tiny(heads_v=2, q_heads=8, kv_heads=2, mlp_v=1024, mlp_t=1024, vocab=512) if n == 2 else tiny(heads_v=2, q_heads=8, kv_heads=4, mlp_v=1024, mlp_t=1024, vocab=512)
+    e = Engine(cfg, dtype="bf16", max_seq=96, max_batch=2, max_tiles=2, tp_rank=0, tp_size=n)
+    e.set_noop_allreduce()
+    e.fill_synthetic(0, local=True)
+    px = torch.from_numpy(synth.pixels(2, cfg.vision["image_size"], 0))
+    feats = e.encode_images(px)
+    ids = torch.tensor([[3, -200, 5, 6], [4, -200, 8, 9]])
+    embeds, lengths, _ = e.splice(ids, None, feats)
+    logits, _ = e.prefill(embeds, lengths)
+    tok = e.argmax(logits)
+    for _ in range(3):
+        tok, _ = e.decode_step(tok)
+    sync()
+    assert logits.shape[1] == cfg.text["vocab_size"] // n and torch.isfinite(logits).all()
+    assert all(0 <= int(t) < cfg.text["vocab_size"] for t in tok)
+    e.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Measure the GEMM tile choice of every GEMM class the OmChat-13B hot path launches (TP 1 / 2 / 4 / 8; the 3-tile sample and the
-32-sample batch of bench.py) on this GPU and write omchat_amd/gemm_tune_gfx950.txt, which the binding loads with the library so
+"""Measure the GEMM tile choice of every GEMM class the hot path launches in bench.py (OmChat-13B: the 3-tile sample, the 32-sample batch
+and the 32-frame clip; OmChat-2.1-8B: the 8-picture sample of configs[3]; TP 1 / 2 / 4 / 8 each) on this GPU and write omchat_amd/gemm_tune_gfx950.txt, which the binding loads with the library so
 that first-use tuning never runs on a live request or inside a timed / multi-rank region.
 
     python tools/gen_gemm_tune.py          # on the MI355X box (gpurun); commit the resulting file
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from omchat_amd import _lib
-from omchat_amd.config import omchat13b
+from omchat_amd.config import omchat13b, omchat8b_21
 from omchat_amd.tp import local_dims
 
 NONE, GELU, LS_RESID, RESID, SWIGLU = 0, 1, 2, 3, 4
@@ -34,7 +34,7 @@ def chunks(M, tp):
 def classes(cfg, tp, tiles, rows):
     d = local_dims(cfg, 0, tp)
     C, H = cfg.vision["hidden_size"], cfg.text["hidden_size"]
-    Cq, I = d["v_heads"] * 128, d["v_mlp"]
+    Cq, I = d["v_heads"] * cfg.vision.get("head_dim", 128), d["v_mlp"]
     qd, kvd, It = d["t_heads"] * 128, d["t_kv_heads"] * 128, d["t_mlp"]
     qkvd = qd + 2 * kvd
     M = tiles * 1025
@@ -50,10 +50,13 @@ def classes(cfg, tp, tiles, rows):
 
 def main():
     lib = _lib.lib()
-    cfg = omchat13b()
     todo = []
+    # (config, tiles per tower launch, prefill rows): configs[1], configs[2] (24-tile tower chunks), configs[4] (24 + 8 tile chunks,
+    # 33 280 rows), configs[3] (InternViT-300M, 8 tiles, 8704 rows)
+    work = [(omchat13b(), 3, 3584), (omchat13b(), 24, 32 * 3584), (omchat13b(), 8, 32 * 1024 + 512), (omchat13b(), 24, 32 * 1024 + 512),
+            (omchat8b_21(), 8, 8 * 1024 + 512)]
     for tp in (1, 2, 4, 8):
-        for tiles, rows in ((3, 3584), (24, 32 * 3584)):
+        for cfg, tiles, rows in work:
             for c in classes(cfg, tp, tiles, rows):
                 if c not in todo:
                     todo.append(c)
