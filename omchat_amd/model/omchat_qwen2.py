@@ -183,6 +183,14 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
         pad = pad_token_id if pad_token_id is not None else self.generation_config.pad_token_id
         b = input_ids.shape[0]
+        if (max_new_tokens > 1 and attention_mask is not None and getattr(self.config, "tokenizer_padding_side", "right") == "left"
+                and bool(attention_mask.eq(0).any())):
+            # before any work is done: a left-padded batch can be prefilled (one token) but not decoded.  The reference pads the TOKEN-level
+            # mask with ones to the SPLICED cache length and sets position_ids = sum(mask) - 1 (omchat_arch.py:61-70): the padded rows are
+            # rotated to positions before their own prompt and attend to padded cache slots whose contents depend on the attention backend
+            # (tests/golden/leftpad_decode.npz: positions [40, 34] after a prefill that ended at 39)
+            raise NotImplementedError("generate() on a left-padded batch with max_new_tokens > 1: the reference positions these decode steps "
+                                      "inconsistently (omchat_arch.py:61-70); pad on the right (tokenizer_padding_side='right')")
         if streamer is not None:
             streamer.put(input_ids.cpu())
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True)

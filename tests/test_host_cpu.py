@@ -358,3 +358,32 @@ def test_make_context_and_get_context_vs_ids_captured_from_the_reference():
         assert inp == c["raw_text"], c["name"]
         assert ids == c["context_tokens"], c["name"]
         assert ids.count(-200) == c["raw_text"].count("<image>") or c.get("chat_format") == "raw"
+
+
+def test_decode_branch_of_the_splice_mirror_vs_reference_golden():
+    """omchat_arch.py:61-70 (the decode short-circuit of prepare_inputs_labels_for_multimodal) in omchat_amd/model/omchat_qwen2.py against
+    the mask / position_ids the reference's own code returned (tests/golden/leftpad_decode.npz, tools/make_golden_r3.py): integer work,
+    bit-exact, for the right- AND the left-padded batch; no GPU involved (the cache is probed through the legacy [-1][-1].shape[-2])."""
+    import types
+    import torch
+    from conftest import golden
+    from omchat_amd.model.omchat_qwen2 import OmChatMetaForCausalLM
+
+    class M(OmChatMetaForCausalLM):
+        def get_vision_tower(self):
+            return object()
+
+    g = golden("leftpad_decode")
+    m = M()
+    for side in ("left", "right"):
+        tok_mask = torch.from_numpy(g["mask"]).long()
+        L = int(g[side + "_S"])
+        for k in range(int(g["steps"])):
+            tok_mask = torch.cat([tok_mask, torch.ones(2, 1, dtype=torch.long)], dim=1)
+            probe = types.SimpleNamespace(shape=(2, 1, L + k, 128))
+            cache = [(probe, probe)]
+            ids, pos, mask, past, emb, labels = m.prepare_inputs_labels_for_multimodal(torch.zeros(2, 1, dtype=torch.long), None, tok_mask, cache,
+                                                                                     None, torch.zeros(3, 3, 8, 8))
+            assert emb is None and labels is None and past is cache and ids.shape == (2, 1)
+            assert mask.dtype == torch.long and np.array_equal(mask.numpy(), g[f"{side}_dec_mask_{k}"])
+            assert np.array_equal(pos.numpy(), g[f"{side}_dec_pos_{k}"])

@@ -200,3 +200,36 @@ def test_int_tables():
             return types.SimpleNamespace(input_ids=[1000 + ord(ch) for ch in s])
     ids = tokenizer_image_token("<image>\npatch:<image>\npatch:<image>\nhello", Tok(), -200)
     assert ids == [int(x) for x in g["prompt_ids"]]
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_padded_batch_prefill_and_decode_steps(side):
+    """SURVEY 8 f-4 (omchat_arch.py:61-70,176-193): what the reference computes on the decode steps after a padded batch prefill --
+    token-level mask padded with ones to the spliced cache length, position_ids = sum(mask) - 1 -- captured by tools/make_golden_r3.py.
+    The oracle restates it exactly (mask / positions bit for bit, logits to fp32 noise), including the LEFT-padded case whose padded
+    row is positioned BEFORE the tokens it follows (the evidence behind the product's refusal)."""
+    g = golden("leftpad_decode")
+    cfg = tiny()
+    sd = sd_torch(cfg, int(g["seed"]))
+    ids, mask = T(g["ids"], torch.long), T(g["mask"], torch.long)
+    feats = [f for f in T(g["feats"])]
+    embeds, mask_sp, lengths = oracle.splice_inputs(ids, mask, feats, sd["model.embed_tokens.weight"], side, None)
+    assert lengths == [int(x) for x in g["lengths"]] and embeds.shape[1] == int(g[side + "_S"])
+    cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+    oracle.qwen2_model(embeds, sd, cfg.text, cache, None, mask_sp)
+    tok_mask = mask
+    for k in range(int(g["steps"])):
+        nxt = T(g[f"{side}_tok_{k}"], torch.long)
+        tok_mask = torch.cat([tok_mask, torch.ones(2, 1, dtype=torch.long)], dim=1)
+        m, pos = oracle.decode_step_inputs(tok_mask, cache.get_seq_length())
+        assert np.array_equal(m.numpy(), g[f"{side}_dec_mask_{k}"]) and np.array_equal(pos.numpy(), g[f"{side}_dec_pos_{k}"])
+        h = oracle.qwen2_model(sd["model.embed_tokens.weight"][nxt][:, None], sd, cfg.text, cache, pos, m)
+        logits = oracle.lm_head(h, sd)[:, -1]
+        assert rel_err(logits, g[f"{side}_logits_{k}"]) < FP32_TOL
+    if side == "left":
+        # the padded row (row 1) is rotated to a position before its own last prompt token, and its mask hides slots 4..9 of the
+        # spliced cache while exposing the padded slots around them: there is no consistent computation to be identical to
+        assert int(g["left_dec_pos_0"][1, 0]) < int(g["last_prefill_pos"]) < int(g["left_dec_pos_0"][0, 0])
+        row1 = g["left_dec_mask_0"][1]
+        S, n1 = int(g["left_S"]), int(g["lengths"][1])
+        assert row1[:4].all() and not row1[4:10].any() and row1[10:S - n1].all()      # padded slots [0, S - n1) partly visible
