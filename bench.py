@@ -538,7 +538,7 @@ def main():
                 kern = f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
             tr, src = (None, None)
             if plain and not f8:
-                tr, src = pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if b == 1 else pmc_traffic(["gemv_xs_kernelI", "Li4E"], "*pmc_traffic_configs2.json")
+                tr, src = pmc_traffic(["gemv_rows_kernelI", "Li4ELi4ELi4E"]) if b == 1 else pmc_traffic(["gemv_xs_kernelI", f"Li4ELi{2 if b > 16 else 1}E"], "*pmc_traffic_configs2.json")
             roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
                     "launches": n, "bytes_per_launch": gu_bytes}

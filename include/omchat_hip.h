@@ -137,7 +137,8 @@ int omchat_decode_graph_stats(omchat_ctx* ctx, long* steps, long* replays, long*
 /* ---- weight-only fp8 for decode (BASELINE configs[4]) -------------------------------------------- */
 /* Builds (once) an OCP e4m3 replica of the decoder weights that a decode step streams (fused qkv, o, gate|up, down,
  * lm_head): per output row scale = absmax / 448, W8 = e4m3_rne(W / scale).  With on != 0, batch-1 decode steps on a
- * TP = 1 context read these bytes (half the HBM traffic of the 16-bit weights) and apply the scale after the fp32
+ * context (any tensor-parallel degree: each rank quantises its own shard, one scale per local output row) read these bytes (half the
+ * HBM traffic of the 16-bit weights) and apply the scale after the fp32
  * row reduction; prefill and b > 1 steps keep the 16-bit weights.  Not part of the reference (it has no quantised
  * path): parity is against the oracle run on the de-quantised weights. */
 int omchat_enable_fp8_decode(omchat_ctx* ctx, int on);
@@ -181,7 +182,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * 16x16x32 prefill attention kernel; key 9: 0 = tensor-parallel decode over the peer transport keeps the all-reduce of the split-K
  * slices and the residual + RMSNorm as two launches instead of omchat_peer_resid_rmsnorm; key 10: key tiles (of 64) per wave of the
  * split-KV decode attention, 0 = chosen from the grid size (1 for single sequences, up to 4 for large batches); key 11: 1 = the batched
- * decode GEMV never takes its x-stationary persistent form) */
+ * decode GEMV never takes its x-stationary persistent form; key 12: 0 = the batched decode attention loads its K tiles fragment-shaped
+ * straight to registers instead of whole rows through LDS) */
 int omchat_op_set_tuning(int key, int value);
 /* GEMM tile choices are measured on first use of a (dtype, epilogue, ceil(M/256), N, K) class; load / dump persist them as text
  * (returns the number of entries, -1 when the file cannot be opened); omchat_gemm_tune_runs = measurements done by this process */

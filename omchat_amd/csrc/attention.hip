@@ -798,7 +798,12 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
 // block -- K, S^T = K Q^T, then V into the same registers while the softmax runs -- which keeps the running output tile resident
 // without spilling.  16-bit cache, fused RoPE + append as in the one-tile kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+// KLDS (round 3): the K tile is loaded like the V tile -- whole 256-byte rows, 1 KiB contiguous per wave instruction -- and reaches the
+// MFMA A-fragment order through the SAME 16 KiB LDS buffer the V image uses afterwards (K image: chunk' = chunk ^ (row & 15), conflict-free
+// ds_read_b128 operand reads).  The register-direct form loads fragment-shaped K (16 rows x 64 B per instruction): half of this kernel's
+// bytes then arrive as half cache lines per request, and the load path, not HBM, sets its 5 TB/s (cdna_hip_programming.md section 5,
+// "x through LDS in full lines").  Costs 16 ds_write_b128 + 16 ds_read_b128 + one single-wave barrier per tile.
+template <typename T, bool KLDS = false>
 __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
   __shared__ __attribute__((aligned(256))) char Vs[KV_TILE * 256];
@@ -849,7 +854,52 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
     if (key0 >= kv_len) break;                // uniform
     frag_t kv[16];                            // K fragments [kt][ds] first, then the V image rows of the same tile
     f32x4 s[4];
-    {
+    if constexpr (KLDS) {
+      // lane (fg, fc) loads chunk fc of key row key0 + 4 i + fg
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = key0 + i * 4 + fg;
+        const bool fresh = fuse && key >= pp;
+        const T* src = fresh ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+        kv[i] = ld8<T>(src + fc * 8);
+      }
+      if (fuse && key0 + KV_TILE > pp) {      // only the tile that owns the new position (uniform): rotate the fresh row, append it
+        const float* cs = p.rope + ((size_t)pt * 64 + (fc & 7) * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (key0 + i * 4 + 3 >= pp) {         // uniform: this register holds a row >= pp in some lane group
+            // rotate-half partner of chunk fc is chunk fc ^ 8 of the same row: lane ^ 8
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 own = __builtin_bit_cast(i32x4, kv[i]);
+            i32x4 oth;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) oth[w] = __shfl_xor(own[w], 8, 64);
+            const frag_t rot = rope_chunk<T>(kv[i], __builtin_bit_cast(frag_t, oth), cs, fc >= 8);
+            if (key0 + i * 4 + fg >= pp) kv[i] = rot;
+            if (key0 + i * 4 + fg == pp)
+              st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + fc * 8, kv[i]);
+          }
+        }
+      }
+      if (tt > 0) __syncthreads();            // the previous tile's transposed V reads are done
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = i * 4 + fg;
+        *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ (row & 15)) << 4)) = kv[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+          kv[kt * 4 + ds] = *reinterpret_cast<const frag_t*>(Vs + (kt * 16 + fc) * 256 + (((ds * 4 + fg) ^ fc) << 4));
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kv[kt * 4 + ds], qf[ds], s[kt]);
+      }
+    } else {
       bool kfresh[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -928,7 +978,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
       pf[ks] = __builtin_convertvector(e, frag_t);
     }
     l_run += psum;
-    if (tt > 0) __syncthreads();              // the previous tile's transposed reads are done
+    if (KLDS || tt > 0) __syncthreads();      // the previous tile's transposed reads (KLDS: this tile's K fragment reads) are done
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = i * 4 + fg;
@@ -1076,6 +1126,8 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
 
 int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
 void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
+int g_attn_klds = 1;    // omchat_op_set_tuning key 12: 0 = batched decode attention loads K fragment-shaped straight to registers (A/B)
+void attn_set_klds(int v) { g_attn_klds = v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
 void attn_set_v2(int v) { g_attn_v2 = v; }
 
@@ -1157,12 +1209,14 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
     if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
-    else if (tpw > 1) hipLaunchKernelGGL(attn_decode_multi_kernel<f16>, grid, dim3(64), 0, s, p);
+    else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, true>), grid, dim3(64), 0, s, p);
+    else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else if (dtype == OMCHAT_BF16) {
     if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
-    else if (tpw > 1) hipLaunchKernelGGL(attn_decode_multi_kernel<bf16>, grid, dim3(64), 0, s, p);
+    else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, true>), grid, dim3(64), 0, s, p);
+    else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }

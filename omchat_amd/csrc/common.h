@@ -58,6 +58,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float e = 0.5f * t * __expf(fmaf(-z, z, p));          // erfc(z) / 2
   return x * (x >= 0.f ? 1.0f - e : e);
 }
+// Two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32): the same formula on a register pair, for the GEMM epilogue where no MFMA of
+// this wave competes for issue slots (the polynomial is 9 of the ~20 VALU of an element; the two transcendentals stay scalar).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 d = __builtin_elementwise_fma((f32x2){0.5f, 0.5f}, z, (f32x2){1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = {0.17087277f, 0.17087277f};
+  p = __builtin_elementwise_fma(p, t, (f32x2){-0.82215223f, -0.82215223f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){1.48851587f, 1.48851587f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-1.13520398f, -1.13520398f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){0.27886807f, 0.27886807f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-0.18628806f, -0.18628806f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){0.09678418f, 0.09678418f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){0.37409196f, 0.37409196f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){1.00002368f, 1.00002368f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-1.26551223f, -1.26551223f});
+  const f32x2 a = __builtin_elementwise_fma(-z, z, p);
+  const f32x2 e = (t * 0.5f) * (f32x2){__expf(a[0]), __expf(a[1])};          // erfc(z) / 2
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 phi = {x[0] >= 0.f ? one[0] - e[0] : e[0], x[1] >= 0.f ? one[1] - e[1] : e[1]};
+  return x * phi;
+}
 // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU): the result is rounded to 16 bit next
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 

@@ -53,15 +53,29 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ---------------------------------------------------------------------------------------------------------
-// Shared epilogue.  acc[i][j][r] = C[rowu + i*16 + 4*fg + r][colu + j*16 + fr]   (rowu / colu: wave-uniform corner of the wave tile)
-// VALU does not overlap MFMA on a SIMD, so epilogue instructions are paid in full: the first version spent, per element, a
-// 64-bit multiply-add for the address, a compare + exec-mask branch for the row bound and a 2-byte flat store (796 VALU + 133
-// branches per thread for the plain epilogue, 1700 with a residual).  Here C and the residual are addressed through buffer
-// resources that start at the wave tile's first row and end after its last valid row: the hardware drops out-of-range rows, the
-// per-element address is one 32-bit add, bias / layer-scale are per column (hoisted), and the rounding points are unchanged.
+// Shared epilogue.  Every kernel below issues its MFMAs with the operands SWAPPED (W fragment first): the two 16x16x32 operands have
+// the same lane layout, so the accumulator then holds the transposed tile,
+//     acc[i][j][r] = C[rowu + i*16 + fr][colu + j*16 + 4*fg + r]        (rowu / colu: wave-uniform corner of the wave tile)
+// i.e. a lane owns FOUR CONSECUTIVE COLUMNS of one row per fragment: one 8-byte store (and one 8-byte residual load) per fragment
+// instead of four 2-byte ones, bias / layer-scale as 8-byte loads per column block.  VALU does not overlap MFMA on a SIMD, so epilogue
+// instructions are paid in full (round 2, row-major accumulators: ~25 VALU + a 2-byte store + a 2-byte load per ELEMENT made a 256^2
+// tile's epilogue ~20 % of a K = 3200 main loop and the whole cost of the K = 512 row-parallel shards of TP = 8: 243 TF).
+// C and the residual are addressed through buffer resources that start at the wave tile's first row and end after its last valid row:
+// the hardware drops out-of-range rows.  Rounding points are unchanged.  N % 4 == 0.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ unsigned short bits16(T v) { return __builtin_bit_cast(unsigned short, v); }
 template <typename T> __device__ __forceinline__ float from_bits16(unsigned short v) { return tof(__builtin_bit_cast(T, v)); }
+template <typename T> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  typename V8<T>::half_type h = {fromf<T>(a), fromf<T>(b), fromf<T>(c), fromf<T>(d)};
+  return __builtin_bit_cast(u32x2, h);
+}
+template <typename T> __device__ __forceinline__ f32x4 unpack4(u32x2 w) {
+  const typename V8<T>::half_type h = __builtin_bit_cast(typename V8<T>::half_type, w);
+  return (f32x4){tof(h[0]), tof(h[1]), tof(h[2]), tof(h[3])};
+}
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
+  return unpack4<T>(*reinterpret_cast<const u32x2*>(p));
+}
 
 template <typename T, int MR, int NR, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int rowu_, int colu_, int fg, int fr) {
@@ -69,35 +83,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
   const int rows_valid = p.M - rowu < MR * 16 ? p.M - rowu : MR * 16;
   if (rows_valid <= 0) return;                                                   // wave-uniform
   if (p.a_scale) {          // fp8 x fp8 operands: the accumulators are sums of unscaled e4m3 products (wave-uniform branch)
-    float sw[NR];
+    float sa[MR];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) { const int col = colu + j * 16 + fr; sw[j] = p.w_scale[col < p.N ? col : p.N - 1]; }
+    for (int i = 0; i < MR; ++i) { const int row = rowu + i * 16 + fr; sa[i] = p.a_scale[row < p.M ? row : p.M - 1]; }
 #pragma unroll
-    for (int i = 0; i < MR; ++i)
+    for (int j = 0; j < NR; ++j) {
+      const int col = colu + j * 16 + 4 * fg;
+      const f32x4 sw = col < p.N ? *reinterpret_cast<const f32x4*>(p.w_scale + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rowu + i * 16 + fg * 4 + r;
-        const float sa = p.a_scale[row < p.M ? row : p.M - 1];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j][r] *= sa * sw[j];
-      }
+      for (int i = 0; i < MR; ++i) acc[i][j] *= sw * sa[i];
+    }
   }
   const T* __restrict__ bias = (const T*)p.bias;
   // byte ranges of the wave tile's rows (< 2^32: at most 128 rows of one matrix row stride each)
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((T*)p.C + (size_t)rowu * p.ldc, 0, rows_valid * p.ldc * 2, 0x00020000);
-  const int c_lane = (fg * 4 * p.ldc + fr) * 2;                                  // lane part of the byte offset inside C's range
+  const int c_lane = (fr * p.ldc + 4 * fg) * 2;                                  // lane part of the byte offset inside C's range
   if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
     for (int j = 0; j < NR; j += 2) {
-      if (colu + j * 16 + 16 + fr < p.N) {                                       // gate column in the fused layout (up = +16)
+      if (colu + j * 16 + 16 + 4 * fg < p.N) {                                   // gate columns in the fused layout (up = +16)
         const int oc = ((colu + j * 16) >> 1) * 2;                               // byte offset of the output column block
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i) {
+          float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float g = rnd<T>(acc[i][j][r]), u = rnd<T>(acc[i][j + 1][r]);
-            __builtin_amdgcn_raw_buffer_store_b16(bits16<T>(fromf<T>(rnd<T>(silu(g)) * u)), crs, c_lane + (i * 16 + r) * p.ldc * 2 + oc, 0, 0);
+            o[r] = rnd<T>(silu(g)) * u;
           }
+          __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(o[0], o[1], o[2], o[3]), crs, c_lane + i * 16 * p.ldc * 2 + oc, 0, 0);
+        }
       }
     }
   } else {
@@ -105,35 +120,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
     const bool has_r = (EPI == EPI_LS_RESID || EPI == EPI_RESID) && p.resid != nullptr;
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(has_r ? (T*)p.resid + (size_t)rowu * p.ldr : (T*)p.C, 0,
                                                                         has_r ? rows_valid * p.ldr * 2 : 0, 0x00020000);
-    const int r_lane = (fg * 4 * p.ldr + fr) * 2;
+    const int r_lane = (fr * p.ldr + 4 * fg) * 2;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      const int col = colu + j * 16 + fr;
+      const int col = colu + j * 16 + 4 * fg;
       if (col < p.N) {
-        const float bv = bias ? tof(bias[col]) : 0.f;
-        float lsv = 1.f;
-        if constexpr (EPI == EPI_LS_RESID) lsv = tof(ls[col]);
+        const f32x4 bv = bias ? load4<T>(bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 lsv = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI == EPI_LS_RESID) lsv = load4<T>(ls + col);
         const int cj = c_lane + (colu + j * 16) * 2, rj = r_lane + (colu + j * 16) * 2;
-        // all residual elements of this column block in flight before the first use (no residual: the resource has zero
+        // all residual fragments of this column block in flight before the first use (no residual: the resource has zero
         // records and the loads return 0 -- no branch either way)
-        unsigned short rb[MR][4];
+        u32x2 rb[MR];
         if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
 #pragma unroll
-          for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rb[i][r] = __builtin_amdgcn_raw_buffer_load_b16(rrs, rj + (i * 16 + r) * p.ldr * 2, 0, 0);
+          for (int i = 0; i < MR; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b64(rrs, rj + i * 16 * p.ldr * 2, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i) {
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) rv = unpack4<T>(rb[i]);
+          float o[4];
+          if constexpr (EPI == EPI_GELU) {
+            const f32x2 g0 = gelu_erf2((f32x2){rnd<T>(acc[i][j][0] + bv[0]), rnd<T>(acc[i][j][1] + bv[1])});
+            const f32x2 g1 = gelu_erf2((f32x2){rnd<T>(acc[i][j][2] + bv[2]), rnd<T>(acc[i][j][3] + bv[3])});
+            o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[i][j][r] + bv;
-            if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
-            if constexpr (EPI == EPI_GELU) v = gelu_erf(v);
-            if constexpr (EPI == EPI_LS_RESID) v = from_bits16<T>(rb[i][r]) + rnd<T>(v * lsv);
-            if constexpr (EPI == EPI_RESID) v = from_bits16<T>(rb[i][r]) + v;
-            __builtin_amdgcn_raw_buffer_store_b16(bits16<T>(fromf<T>(v)), crs, cj + (i * 16 + r) * p.ldc * 2, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[i][j][r] + bv[r];
+              if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
+              if constexpr (EPI == EPI_LS_RESID) v = rv[r] + rnd<T>(v * lsv[r]);
+              if constexpr (EPI == EPI_RESID) v = rv[r] + v;
+              o[r] = v;
+            }
           }
+          __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(o[0], o[1], o[2], o[3]), crs, cj + i * 16 * p.ldc * 2, 0, 0);
+        }
       }
     }
   }
@@ -226,7 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);      // swapped operands: transposed accumulator (see gemm_epilogue)
     }
   }
 
@@ -361,7 +384,7 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   __builtin_amdgcn_s_setprio(1);                                                                                   \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-          acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag<T, F8>(af[i][s], BF[j][s], acc[(MH) * 4 + i][(NH) * 2 + j]);  \
+          acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag<T, F8>(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j]);  \
   __builtin_amdgcn_s_setprio(0);                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_barrier();                                                                                    \
@@ -765,6 +788,8 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
     OM_CHECK(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && a.a_scale && a.w_scale, "fp8 GEMM: K % 128, lda / ldw % 16 bytes, both scale vectors");
     OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.ldc % 2 == 0 && ((uintptr_t)a.C & 3) == 0, "fp8 GEMM: alignment");
     OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
+    OM_CHECK(a.N % 4 == 0 && ((uintptr_t)a.bias & 7) == 0 && ((uintptr_t)a.ls & 7) == 0 && ((uintptr_t)a.w_scale & 15) == 0,
+             "fp8 GEMM: N % 4, bias / layer-scale 8-byte and w_scale 16-byte aligned");
     if (dtype == OMCHAT_F16) return launch_f8_t<f16>(a, stream);
     if (dtype == OMCHAT_BF16) return launch_f8_t<bf16>(a, stream);
     omchat_set_error("launch_gemm: bad dtype");
@@ -777,6 +802,8 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "A/W must be 16-byte aligned");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
   OM_CHECK(a.epi != EPI_LS_RESID || a.ls, "layer-scale epilogue needs ls");
+  OM_CHECK(a.N % 4 == 0 && ((uintptr_t)a.bias & 7) == 0 && ((uintptr_t)a.ls & 7) == 0,
+           "N must be a multiple of 4 and bias / layer-scale 8-byte aligned (the epilogue owns four consecutive columns per lane)");
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16, "bad dtype");
   GemmArgs b = a;
   if (!a.force_tile && g_autotune && a.stream_k <= 0) b.force_tile = tuned_tile(dtype, a, stream);

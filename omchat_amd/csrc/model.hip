@@ -1039,7 +1039,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   void* y = ctx->tw_x2;
   TRY(launch_gather_rows(ctx->dt, tokens, ctx->t_embed, nullptr, x, b, H, s));      // embed_tokens
   // weight-only fp8 replica (omchat_enable_fp8_decode): batch-1 steps stream e4m3 bytes + per-row scales
-  const bool f8 = ctx->fp8_decode && b == 1 && ctx->tp_size == 1;
+  const bool f8 = ctx->fp8_decode && b == 1;      // under tensor parallelism every rank streams the e4m3 replica of its own shard (round 3)
   // batched steps (2 <= b <= 32): the activations that feed a GEMV (tw_xn, tw_ao, tw_act) are produced in the packed x layout
   // (common.h) by their producers, and the weights come from the packed replica when it exists (ensure_packed)
   const int pk = (b > 1 && b <= 32 && H % 64 == 0 && qd % 64 == 0 && It % 64 == 0) ? (b > 16 ? 2 : 1) : 0;

@@ -216,17 +216,19 @@ def test_gemv_packed_operands(gpu_lib, dt, wp, b, N, K, ks):
 @pytest.mark.parametrize("replica", [1, 0])
 def test_batched_decode_packed_path_vs_oracle(gpu_lib, dt, replica):
     """batched decode steps (b = 3 and b = 20) run on the packed path (packed activations; packed weight replica or the row-major
-    weights): logits against single-sequence steps of the same model (b = 1: whole-row kernels on row-major activations, themselves
-    checked against the oracle in test_gpu_model.py)"""
+    weights): logits against the ORACLE (fp32 restatement on the same 16-bit-rounded inputs, two decode steps per checked row) and
+    against single-sequence steps of the same model (b = 1: whole-row kernels on row-major activations)"""
+    import oracle
     cfg = tiny(q_heads=4, kv_heads=2)
     sd = synth.state_dict(cfg, 3)
+    sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
     gpu_lib.omchat_op_set_tuning(6, replica)
     try:
         for b in (3, 20):
             e = Engine(cfg, dtype=dt, max_seq=64, max_batch=b, max_tiles=1, vision=False)
             e.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
             S = 9
-            x = torch.randn(b, S, 256, generator=torch.Generator().manual_seed(b)) * 0.5
+            x = rnd(torch.randn(b, S, 256, generator=torch.Generator().manual_seed(b)) * 0.5, dt)
             lens = [S - (i % 4) for i in range(b)]
             e.prefill(x, lens)
             toks = torch.arange(b) % 300 + 5
@@ -240,6 +242,12 @@ def test_batched_decode_packed_path_vs_oracle(gpu_lib, dt, replica):
                 _, l1 = e1.decode_step(toks[i:i + 1], want_logits=True)
                 _, l2 = e1.decode_step(nxt[i:i + 1], want_logits=True); sync()
                 assert rel(lg[i], l1[0]) < TOL_DEEP[dt] and rel(lg2[i], l2[0]) < TOL_DEEP[dt], (b, i, rel(lg[i], l1[0]), rel(lg2[i], l2[0]))
+                # the oracle leg: prefill row i, then the same two tokens
+                cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+                oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
+                o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+                o2 = oracle.decode_step(nxt[i:i + 1].cpu()[None].long(), sdt, cfg.text, cache)[0, 0]
+                assert rel(lg[i], o1) < TOL_DEEP[dt] and rel(lg2[i], o2) < TOL_DEEP[dt], (b, i, rel(lg[i], o1), rel(lg2[i], o2))
             e.close(); e1.close()
     finally:
         gpu_lib.omchat_op_set_tuning(6, 1)

@@ -209,3 +209,58 @@ def test_shard_context_runs_the_whole_path(gpu_lib, n):
     assert logits.shape[1] == cfg.text["vocab_size"] // n and torch.isfinite(logits).all()
     assert all(0 <= int(t) < cfg.text["vocab_size"] for t in tok)
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched decode attention: K tiles as whole rows through LDS (tuning key 12) vs fragment-shaped register loads
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+def test_decode_attention_k_through_lds_is_bit_identical(gpu_lib, dt):
+    """same keys, same MFMA operands, same order: the K load path (whole 256-byte rows -> LDS image -> ds_read_b128 fragments vs 16 rows x
+    64 B straight to registers) must not change a bit -- op level (ragged lengths, poisoned cache tail) and inside the decode step, where
+    the tile that owns the new position rotates (RoPE) and appends the fresh K row (positions at tile edges)"""
+    b, Hq, Hkv, cap, lens = 3, 8, 2, 1024, [1000, 513, 64]
+    q = rnd(randn((b, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3), dt)
+    for i, n in enumerate(lens):
+        k[i, :, n:] = float("nan"); v[i, :, n:] = float("nan")
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    L = max(lens)
+    wsb = gpu_lib.omchat_op_attn_decode_ws(b, Hq, L)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ref = _attn_ref(q[:, None], torch.nan_to_num(k), torch.nan_to_num(v), 128 ** -0.5, 0, 0, lens)[:, 0]
+    outs = {}
+    try:
+        gpu_lib.omchat_op_set_tuning(10, 4)
+        for klds in (0, 1):
+            gpu_lib.omchat_op_set_tuning(12, klds)
+            out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), 128 ** -0.5, ptr(ws), wsb, None))
+            sync()
+            assert rel(out, ref) < TOL[dt]
+            outs[klds] = out.clone()
+        assert torch.equal(outs[0], outs[1])
+        # inside the model: fused RoPE + append of the fresh row
+        cfg = tiny(q_heads=4, kv_heads=2)
+        sd = {k_: v_ for k_, v_ in synth.state_dict(cfg, 5).items() if not k_.startswith(synth.TOWER) and "mm_projector" not in k_}
+        x = torch.randn(4, 200, 256, generator=torch.Generator().manual_seed(11)) * 0.5
+        lens2 = [200, 127, 129, 64]
+        runs = {}
+        for klds in (0, 1):
+            gpu_lib.omchat_op_set_tuning(12, klds)
+            e = Engine(cfg, dtype=dt, max_seq=256, max_batch=4, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x, lens2)
+            tok = torch.arange(4) % 300 + 7
+            seq = []
+            for _ in range(4):
+                tok, lg = e.decode_step(tok, want_logits=True)
+                seq.append(lg.float().cpu().clone())
+            sync()
+            runs[klds] = seq
+            e.close()
+        for a_, b_ in zip(runs[0], runs[1]):
+            assert torch.isfinite(a_).all() and torch.equal(a_, b_)
+    finally:
+        gpu_lib.omchat_op_set_tuning(10, 0)
+        gpu_lib.omchat_op_set_tuning(12, 1)

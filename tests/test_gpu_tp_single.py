@@ -169,3 +169,47 @@ def test_rccl_bootstrap_single_rank(gpu_lib):
         torch.cuda.synchronize()
         assert torch.equal(x, y)
     gpu_lib.omchat_comm_destroy(comm)
+
+
+def test_tp2_fp8_decode_on_one_gpu(gpu_lib):
+    """weight-only e4m3 decode under tensor parallelism (round 3: every rank quantises and streams its own shard; per-row scales of the
+    row-parallel o_proj / down_proj cover the LOCAL K slice): two rank contexts on one GPU, logits against the oracle on the 16-bit
+    weights with the fp8 tolerance of tests/test_gpu_fp8.py, both ranks agreeing bit for bit on the activations they share"""
+    dt = "bf16"
+    cfg = tiny(q_heads=4, kv_heads=2, heads_v=2)
+    sd = synth.state_dict(cfg, 13)
+    grp = Group(2)
+    engines, hooks = [], []
+    for r in range(2):
+        e = Engine(cfg, dtype=dt, max_seq=128, max_batch=1, max_tiles=2, tp_rank=r, tp_size=2, comm=C.c_void_p(1), vision=False)
+        h = grp.hook_for(r)
+        _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+        e.load_state_dict({k: v for k, v in sd.items() if not k.startswith(synth.TOWER) and "mm_projector" not in k})
+        e.enable_fp8_decode(True)
+        engines.append(e); hooks.append(h)
+    x = torch.randn(1, 11, 256, generator=torch.Generator().manual_seed(3)) * 0.5
+
+    def run(r):
+        e = engines[r]
+        e.prefill(x)
+        outs = []
+        tok = torch.tensor([5])
+        for _ in range(3):
+            tok, lg = e.decode_step(tok, want_logits=True)
+            outs.append(lg.float().cpu())
+        torch.cuda.synchronize()
+        return outs, int(tok[0])
+
+    res = _run_ranks(run, 2)
+    assert res[0][1] == res[1][1]
+    sdt = {k: T32(v) for k, v in sd.items()}
+    cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+    oracle.qwen2_model(x, sdt, cfg.text, cache)
+    tok = 5
+    for s in range(3):
+        ref = oracle.decode_step(torch.tensor([[tok]]), sdt, cfg.text, cache)[0, 0]
+        full = torch.cat([res[0][0][s], res[1][0][s]], dim=-1)[0]
+        assert rel(full, ref) < 0.12, (s, rel(full, ref))           # e4m3 weights vs 16-bit weights (same bound as the TP = 1 fp8 tests)
+        tok = int(torch.argmax(full))
+    for e in engines:
+        e.close()
