@@ -1126,7 +1126,7 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
 
 int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
 void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
-int g_attn_klds = 1;    // omchat_op_set_tuning key 12: 0 = batched decode attention loads K fragment-shaped straight to registers (A/B)
+int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
 void attn_set_klds(int v) { g_attn_klds = v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
 void attn_set_v2(int v) { g_attn_v2 = v; }

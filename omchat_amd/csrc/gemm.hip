@@ -77,12 +77,12 @@ template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
   return unpack4<T>(*reinterpret_cast<const u32x2*>(p));
 }
 
-template <typename T, int MR, int NR, int EPI>
+template <typename T, int MR, int NR, int EPI, bool F8 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int rowu_, int colu_, int fg, int fr) {
   const int rowu = __builtin_amdgcn_readfirstlane(rowu_), colu = __builtin_amdgcn_readfirstlane(colu_);      // SGPRs: scalar offsets, scalar resources
   const int rows_valid = p.M - rowu < MR * 16 ? p.M - rowu : MR * 16;
   if (rows_valid <= 0) return;                                                   // wave-uniform
-  if (p.a_scale) {          // fp8 x fp8 operands: the accumulators are sums of unscaled e4m3 products (wave-uniform branch)
+  if constexpr (F8) {       // fp8 x fp8 operands: the accumulators are sums of unscaled e4m3 products
     float sa[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) { const int row = rowu + i * 16 + fr; sa[i] = p.a_scale[row < p.M ? row : p.M - 1]; }
@@ -121,41 +121,62 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(has_r ? (T*)p.resid + (size_t)rowu * p.ldr : (T*)p.C, 0,
                                                                         has_r ? rows_valid * p.ldr * 2 : 0, 0x00020000);
     const int r_lane = (fr * p.ldr + 4 * fg) * 2;
+    // The loads of the epilogue are issued in large groups BEFORE their first use: bias / layer-scale and the MR residual fragments
+    // (8 bytes each) of JG column blocks at a time.  Measured with tools/bench_gemm_k.py
+    // (K = 64, i.e. the fixed cost of a launch): the per-column-block form -- load, wait, store, four times in a row -- cost a 256^2 tile
+    // 5.6 us alone on the chip and 13.9 us per round with all 256 CUs in their epilogue together: four dependent memory round trips.
+    // JG column blocks per group: all of them (224 VGPRs, no spill on the 256^2 tile); the fp8 kernels, whose scale vectors stay live, take
+    // two groups
+    constexpr int JG = (F8 && MR * NR > 16) ? (NR + 1) / 2 : NR;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int col = colu + j * 16 + 4 * fg;
-      if (col < p.N) {
-        const f32x4 bv = bias ? load4<T>(bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 lsv = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI == EPI_LS_RESID) lsv = load4<T>(ls + col);
-        const int cj = c_lane + (colu + j * 16) * 2, rj = r_lane + (colu + j * 16) * 2;
-        // all residual fragments of this column block in flight before the first use (no residual: the resource has zero
-        // records and the loads return 0 -- no branch either way)
-        u32x2 rb[MR];
-        if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+    for (int j0 = 0; j0 < NR; j0 += JG) {
+      f32x4 bv[JG], lsv[JG];
+      u32x2 rb[MR][JG];
 #pragma unroll
-          for (int i = 0; i < MR; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b64(rrs, rj + i * 16 * p.ldr * 2, 0, 0);
-        }
+      for (int jj = 0; jj < JG; ++jj) {
+        const int j = j0 + jj;
+        if (j < NR) {
+          const int col = colu + j * 16 + 4 * fg;
+          const int cc = col < p.N ? col : 0;                                      // clamped: the value is unused when the block is out of range
+          bv[jj] = bias ? load4<T>(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          lsv[jj] = (f32x4){1.f, 1.f, 1.f, 1.f};
+          if constexpr (EPI == EPI_LS_RESID) lsv[jj] = load4<T>(ls + cc);
+          if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) {
+            const int rj = r_lane + (colu + j * 16) * 2;
+            // (no residual: the resource has zero records and the loads return 0 -- no branch either way; columns beyond N of the last
+            // tile read the next row's first bytes or nothing, and are never stored)
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) rv = unpack4<T>(rb[i]);
-          float o[4];
-          if constexpr (EPI == EPI_GELU) {
-            const f32x2 g0 = gelu_erf2((f32x2){rnd<T>(acc[i][j][0] + bv[0]), rnd<T>(acc[i][j][1] + bv[1])});
-            const f32x2 g1 = gelu_erf2((f32x2){rnd<T>(acc[i][j][2] + bv[2]), rnd<T>(acc[i][j][3] + bv[3])});
-            o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = acc[i][j][r] + bv[r];
-              if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
-              if constexpr (EPI == EPI_LS_RESID) v = rv[r] + rnd<T>(v * lsv[r]);
-              if constexpr (EPI == EPI_RESID) v = rv[r] + v;
-              o[r] = v;
-            }
+            for (int i = 0; i < MR; ++i) rb[i][jj] = __builtin_amdgcn_raw_buffer_load_b64(rrs, rj + i * 16 * p.ldr * 2, 0, 0);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(o[0], o[1], o[2], o[3]), crs, cj + i * 16 * p.ldc * 2, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < JG; ++jj) {
+        const int j = j0 + jj;
+        const int col = colu + j * 16 + 4 * fg;
+        if (j < NR && col < p.N) {
+          const int cj = c_lane + (colu + j * 16) * 2;
+#pragma unroll
+          for (int i = 0; i < MR; ++i) {
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) rv = unpack4<T>(rb[i][jj]);
+            float o[4];
+            if constexpr (EPI == EPI_GELU) {
+              const f32x2 g0 = gelu_erf2((f32x2){rnd<T>(acc[i][j][0] + bv[jj][0]), rnd<T>(acc[i][j][1] + bv[jj][1])});
+              const f32x2 g1 = gelu_erf2((f32x2){rnd<T>(acc[i][j][2] + bv[jj][2]), rnd<T>(acc[i][j][3] + bv[jj][3])});
+              o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + bv[jj][r];
+                if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
+                if constexpr (EPI == EPI_LS_RESID) v = rv[r] + rnd<T>(v * lsv[jj][r]);
+                if constexpr (EPI == EPI_RESID) v = rv[r] + v;
+                o[r] = v;
+              }
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(o[0], o[1], o[2], o[3]), crs, cj + i * 16 * p.ldc * 2, 0, 0);
+          }
         }
       }
     }
@@ -294,8 +315,13 @@ __device__ __forceinline__ f32x4 mma_frag(typename V8<T>::type a, typename V8<T>
   }
 }
 
+// Persistent use (gemm8p_kernel): prologue_issued = the staging loads of this tile's first K-tiles were already issued by the previous call
+// (with has_next), which recomputes the staging sources for tile (next_m0, next_n0) after its own last barrier -- every LDS read of the
+// finished tile is retired there for both wave groups -- and issues that tile's prologue, so that the caller's epilogue (VALU + global
+// stores, no LDS) runs under the next tile's first HBM round trip.
 template <typename T, bool F8 = false>
-__device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, int kt0, int kt1, char* smem, f32x4 (&acc)[8][4]) {
+__device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, int kt0, int kt1, char* smem, f32x4 (&acc)[8][4],
+                                              bool prologue_issued = false, bool has_next = false, int next_m0 = 0, int next_n0 = 0) {
   constexpr int SLOT = 128 * 128;                 // 128 rows x 128 B
   constexpr int STAGE = 4 * SLOT;                 // A_0, A_1, B_0, B_1
   constexpr int ES = F8 ? 1 : 2;                  // bytes per operand element: a 128-byte row holds 128 / ES elements of K
@@ -311,18 +337,21 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   // staging sources (byte pointers): slot piece lin = i*512 + tid -> slot row rho = lin >> 3, physical chunk pc = lin & 7
   const char* a_src[2][2];     // [mh][round]
   const char* b_src[2][2];     // [nh][round]
+  auto set_src = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lin = i * 512 + tid, rho = lin >> 3, pc = lin & 7;
-    const int c = pc ^ ((rho >> 1) & 7);
+    for (int i = 0; i < 2; ++i) {
+      const int lin = i * 512 + tid, rho = lin >> 3, pc = lin & 7;
+      const int c = pc ^ ((rho >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int gr = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63); gr = gr < p.M ? gr : p.M - 1;
-      a_src[h][i] = A + (size_t)gr * p.lda * ES + c * 16;
-      int gc = n0 + (rho >> 5) * 64 + h * 32 + (rho & 31); gc = gc < p.N ? gc : p.N - 1;
-      b_src[h][i] = W + (size_t)gc * p.ldw * ES + c * 16;
+      for (int h = 0; h < 2; ++h) {
+        int gr = tm0 + (rho >> 6) * 128 + h * 64 + (rho & 63); gr = gr < p.M ? gr : p.M - 1;
+        a_src[h][i] = A + (size_t)gr * p.lda * ES + c * 16;
+        int gc = tn0 + (rho >> 5) * 64 + h * 32 + (rho & 31); gc = gc < p.N ? gc : p.N - 1;
+        b_src[h][i] = W + (size_t)gc * p.ldw * ES + c * 16;
+      }
     }
-  }
+  };
+  set_src(m0, n0);
   // slot order inside a stage: 0 = A_0, 1 = A_1, 2 = B_0, 3 = B_1
   auto issue = [&](int buf, int slot, const char* const (&src)[2], int kt) {
     char* base = smem + buf * STAGE + slot * SLOT;
@@ -348,13 +377,15 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
 
   const int nk = kt1 - kt0;
   // prologue: K-tile 0 completely, plus A_0 / B_0 of K-tile 1 (steady state issues them in p3 / p4 of tile t-1)
-  issue(0, 0, a_src[0], 0); issue(0, 2, b_src[0], 0); issue(0, 3, b_src[1], 0); issue(0, 1, a_src[1], 0);
-  if (nk > 1) {
-    issue(1, 0, a_src[0], 1); issue(1, 2, b_src[0], 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  auto issue_prologue = [&]() {
+    issue(0, 0, a_src[0], 0); issue(0, 2, b_src[0], 0); issue(0, 3, b_src[1], 0); issue(0, 1, a_src[1], 0);
+    if (nk > 1) { issue(1, 0, a_src[0], 1); issue(1, 2, b_src[0], 1); }
+  };
+  if (!prologue_issued) issue_prologue();
+  // (persistent use: the epilogue stores of the previous tile were issued after these loads; vmcnt is in order, so the counted wait
+  // retires the loads it is meant for and whatever stores are older than the 4 youngest operations)
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();      // stagger: group 1 runs one barrier behind
 
@@ -410,7 +441,10 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
 #undef OM_SYNC_COMPUTE
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 matches group 1's extra barrier
-
+  if (has_next) {                                  // uniform: both groups are past their last LDS read here
+    set_src(next_m0, next_n0);
+    issue_prologue();
+  }
 }
 
 
@@ -431,7 +465,40 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   gemm8_segment<T, F8>(p, m0, n0, 0, p.K / (F8 ? 128 : 64), smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
-  gemm_epilogue<T, 8, 4, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
+  gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
+}
+
+// Persistent form for multi-round launches (round 3): one workgroup per CU walks tiles w, w + G, w + 2G, ... and issues the NEXT tile's
+// first staging loads before the CURRENT tile's epilogue.  tools/bench_gemm_k.py (K = 64: the fixed cost of a launch) shows what a round
+// costs beyond its K loop with one workgroup per tile: ~15 us (EPI_NONE) to ~29 us (layer-scale + residual) per round on the 3-tile ViT
+// shapes -- workgroup dispatch, the first HBM round trip of the prologue, the epilogue and its store drain, none of it overlapped because
+// all 256 workgroups move in lockstep.  Here the prologue's round trip and the store drain run under the neighbouring tile's work and
+// the per-round dispatch disappears.  Tile order: round r = tiles [r G, r G + G_r) with the XCD remap applied inside the round.
+template <typename T, int EPI, bool F8 = false>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmP p, int tiles) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int G = gridDim.x, w = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
+  auto coords = [&](int L, int& m0, int& n0) {
+    const int r0 = (L / G) * G;
+    const int gr = tiles - r0 < G ? tiles - r0 : G;               // workgroups active in this round
+    tile_coords_id(r0 + xcd_remap(L - r0, gr), p.M, p.N, 256, 256, m0, n0);
+  };
+  const int nk = p.K / (F8 ? 128 : 64);
+  int m0, n0;
+  if (w >= tiles) return;
+  coords(w, m0, n0);
+  bool issued = false;
+  for (int L = w; L < tiles; L += G) {
+    const bool more = L + G < tiles;
+    int m1 = 0, n1 = 0;
+    if (more) coords(L + G, m1, n1);
+    f32x4 acc[8][4];
+    gemm8_segment<T, F8>(p, m0, n0, 0, nk, smem, acc, issued, more, m1, n1);
+    gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
+    issued = more; m0 = m1; n0 = n1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -524,6 +591,7 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(GemmP p, SkP sk) {
   }
 }
 
+int g_gemm_persist = 1;   // omchat_op_set_tuning key 13: 0 = multi-round 256^2 GEMMs launch one workgroup per tile (A/B)
 int g_gemm_skew = 0;      // tuning knob (omchat_op_set_tuning), units of s_sleep(16) ~ 1024 cycles
 constexpr size_t SK_SLAB_BYTES = 65536 * 4;
 constexpr int SK_MAX_WG = 256;
@@ -532,11 +600,13 @@ template <typename T, int EPI>
 int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * 4 * 128 * 128;
   auto kern = gemm8_kernel<T, EPI>;
+  auto kern_p = gemm8p_kernel<T, EPI>;
   auto kern_sk = gemm8_sk_kernel<T, EPI>;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     int dev = 0;
     OM_HIP(hipGetDevice(&dev));
@@ -556,7 +626,8 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   if (a.stream_k > 0 && !use_sk && !have_ws) { omchat_set_error("launch_gemm: stream-K requested without workspace"); return 1; }
   if (!use_sk) R = 0;
   const int n_dp = tiles - R;
-  if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
+  if (n_dp > G && g_gemm_persist && R == 0) hipLaunchKernelGGL(kern_p, dim3(G), dim3(512), LDS, stream, p, n_dp);
+  else if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
   if (R > 0) {
     unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
     OM_HIP(hipMemsetAsync(flags, 0, 4096, stream));
@@ -571,13 +642,21 @@ template <typename T, int EPI>
 int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * 4 * 128 * 128;
   auto kern = gemm8_kernel<T, EPI, true>;
+  auto kern_p = gemm8p_kernel<T, EPI, true>;
   static bool attr_set = false;
+  static int n_cu = 0;
   if (!attr_set) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    int dev = 0;
+    OM_HIP(hipGetDevice(&dev));
+    OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
   GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale};
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 256) * cdiv(a.N, 256)), dim3(512), LDS, stream, p, 0);
+  const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  if (tiles > n_cu && g_gemm_persist) hipLaunchKernelGGL(kern_p, dim3(n_cu), dim3(512), LDS, stream, p, tiles);
+  else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -653,6 +732,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 void gemm_set_skew(int v) { g_gemm_skew = v; }
+void gemm_set_persist(int v) { g_gemm_persist = v; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Tile choice by measurement.  Which kernel wins depends on the shape in ways a fill-the-last-round model does not capture

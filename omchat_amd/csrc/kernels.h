@@ -35,6 +35,7 @@ struct GemmArgs {
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 size_t gemm_sk_ws_bytes();
 void gemm_set_skew(int v);
+void gemm_set_persist(int v);
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM (decode)
 // Y[b,N] = epilogue(X[b,K] @ W[N,K]^T) for b <= 16: weight-streaming, HBM-bound.  K % 64 == 0.

@@ -540,6 +540,16 @@ static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W
                           const void* ls, const void* resid, int epi, hipStream_t s) {
   int nch = M >= 3 * g_ar_min_rows ? 4 : (M >= g_ar_min_rows ? 2 : 1);
   if (!ctx->comm_stream) nch = 1;
+  // A chunk must still fill the GPU: cutting the 3-tile ViT (M = 3075: 169 tiles of 256^2) or the single-sequence prefill (S = 3584: 196
+  // tiles) into 1024-row chunks ran every projection as 3-4 launches on 52-78 of the 256 CUs (bench.py --shard-of 8, profiles/r03_a:
+  // 3 x 34 us for a projection that takes ~40 us in one launch).  The all-reduce of such a message is then exposed, but it is shorter
+  // than the lost GEMM time.  (Tests lower g_ar_min_rows below one tile to force chunking on tiny shapes: the rule is skipped there.)
+  if (g_ar_min_rows >= 256) {
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+    while (nch > 1 && tiles / nch < n_cu) nch >>= 1;
+  }
   if (nch == 1) {
     TRY(gemm(ctx, A, lda, W, ldw, Y, N, M, N, K, bias, ls, resid, N, epi, s));
     return ctx->allreduce(Y, (size_t)M * N, s);

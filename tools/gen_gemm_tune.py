@@ -18,10 +18,14 @@ from omchat_amd.tp import local_dims
 NONE, GELU, LS_RESID, RESID, SWIGLU = 0, 1, 2, 3, 4
 
 
-def chunks(M, tp):
+def chunks(M, tp, N):
+    """row chunks of a row-parallel projection (model.hip: gemm_allreduce): up to 4, while a chunk still holds >= 256 tiles of 256^2"""
     if tp == 1:
         return [M]
     nch = 4 if M >= 3 * 1024 else (2 if M >= 1024 else 1)
+    tiles = -(-M // 256) * -(-N // 256)
+    while nch > 1 and tiles // nch < 256:
+        nch //= 2
     if nch == 1:
         return [M]
     per = -(-(-(-M // nch)) // 256) * 256
@@ -41,9 +45,9 @@ def classes(cfg, tp, tiles, rows):
     out = [(tiles * 1024, C, 640, NONE, C), (M, 3 * Cq, C, NONE, 3 * Cq), (M, I, C, GELU, I),
            (tiles * 1024, H, C, GELU, H), (tiles * 1024, H, H, NONE, H),
            (rows, qkvd, H, NONE, qkvd), (rows, 2 * It, H, SWIGLU, It)]
-    for m in sorted(set(chunks(M, tp))):
+    for m in sorted(set(chunks(M, tp, C))):
         out += [(m, C, Cq, LS_RESID, C), (m, C, I, LS_RESID, C)]
-    for m in sorted(set(chunks(rows, tp))):
+    for m in sorted(set(chunks(rows, tp, H))):
         out += [(m, H, qd, RESID, H), (m, H, It, RESID, H)]
     return out
 

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Projected tensor-parallel scaling of bench.py's workloads from ONE-GPU measurements: per-rank compute time comes
+from `bench.py --shard-of N` lines (rank 0's shard shapes and launch sequence with the exchanges removed), the exchanges are priced
+from their message bytes.  No multi-GPU node was available to the builder: this is arithmetic on measured inputs, not a measurement.
+
+    python tools/tp_projection.py profiles/r03_a_bench_n1.json profiles/r03_a_bench_shard2.json profiles/r03_a_bench_shard4.json profiles/r03_a_bench_shard8.json
+
+Communication model (stated, not measured):
+  * xGMI: 7 links x 153 GB/s per GPU and direction (BASELINE / MI355X guide).  A ring / direct all-reduce of B bytes moves 2 (n-1)/n B per
+    GPU; with all (n-1) links of the fully connected node busy the bound is t = 2 (n-1)/n B / ((n-1) x 153 GB/s) = 2 B / (n x 153 GB/s).
+    RCCL is priced at EFF = 60 % of that bound plus LAT_RCCL = 25 us per call (launch + protocol).
+  * decode-sized messages go through the one-shot peer kernel (csrc/comm.hip) fused with the residual + RMSNorm launch that exists anyway:
+    extra cost LAT_PEER = 4 us per exchange (flag round trip over xGMI + (n-1) remote 16-byte-granule reads), 2 per layer + 1 for the argmax.
+  * prefill / ViT all-reduces run on the communication stream under the next row chunk's GEMM (model.hip: gemm_allreduce): per
+    projection the exposed time is max(sum of chunk all-reduces - GEMM time of the later chunks, last chunk's all-reduce).
+"""
+import json
+import sys
+
+LINK = 153e9
+EFF = 0.60
+LAT_RCCL = 25e-6
+LAT_PEER = 4e-6
+
+
+def allreduce_s(nbytes, n):
+    return LAT_RCCL + 2.0 * nbytes / (n * LINK) / EFF
+
+
+def main():
+    files = sys.argv[1:]
+    base = json.load(open(files[0]))
+    shards = {}
+    for f in files[1:]:
+        d = json.load(open(f))
+        shards[d["shard_of"]] = d
+    print("workload      N   ViT ms  prefill ms  decode ms/step | comm: ViT  prefill  decode/step |  step ms   speed-up   (DP tower: step ms, speed-up)")
+    for wl, key, b, tiles_chunk, n_chunks in (("configs1", None, 1, 3, 1), ("configs2", "configs2", 32, 24, 4)):
+        d1 = base if key is None else base[key]
+        dec1 = d1.get("decode_ms_per_token_p50", d1.get("decode_ms_per_step_p50"))
+        gen = 256
+        t1 = d1["vit_ms_p50"] + d1["prefill_ms_p50"] + (gen - 1) * dec1
+        print(f"{wl:10s}    1  {d1['vit_ms_p50']:7.1f}  {d1['prefill_ms_p50']:9.1f}  {dec1:12.3f} |      -        -         -       | {t1:8.1f}      1.00")
+        for n in sorted(shards):
+            s = shards[n] if key is None else shards[n][key]
+            dec = s.get("decode_ms_per_token_p50", s.get("decode_ms_per_step_p50"))
+            S = 3584
+            # ViT: 45 layers x 2 all-reduces of [tiles x 1025, 3200] 16-bit per tower chunk (+ the [rows, 2] fp32 q/k-norm sums)
+            m_vit = tiles_chunk * 1025 * 3200 * 2
+            ar_vit = 45 * n_chunks * (2 * allreduce_s(m_vit, n) + allreduce_s(tiles_chunk * 1025 * 8, n))
+            # prefill: 28 layers x 2 all-reduces of [b x S, 3584] 16-bit
+            m_pre = b * S * 3584 * 2
+            ar_pre = 28 * 2 * allreduce_s(m_pre, n)
+            # overlap: large (chunked) projections hide all but the last chunk's all-reduce when the GEMM of the later chunks is longer;
+            # here the sums are compared on the whole phase: exposed = max(comm - 0.5 x compute, comm / 4) for chunked shapes, all of it otherwise
+            chunked = b > 1
+            exp_vit = max(ar_vit - 0.5 * s["vit_ms_p50"] / 1e3, ar_vit / 4) if chunked else ar_vit
+            exp_pre = max(ar_pre - 0.5 * s["prefill_ms_p50"] / 1e3, ar_pre / 4) if chunked else ar_pre
+            dec_comm = (28 * 2 + 1) * LAT_PEER
+            vit = s["vit_ms_p50"] + exp_vit * 1e3
+            pre = s["prefill_ms_p50"] + exp_pre * 1e3
+            step = vit + pre + (gen - 1) * (dec + dec_comm * 1e3)
+            # data-parallel tower: tiles / n per GPU at the TP = 1 per-tile rate + one gather of the features
+            tiles = tiles_chunk * n_chunks
+            vit_dp = d1["vit_ms_p50"] * max(1, -(-tiles // n)) / tiles + allreduce_s(tiles * 1024 * 3584 * 2, n) * 1e3
+            step_dp = vit_dp + pre + (gen - 1) * (dec + dec_comm * 1e3)
+            print(f"{wl:10s}  {n:3d}  {s['vit_ms_p50']:7.1f}  {s['prefill_ms_p50']:9.1f}  {dec:12.3f} | {exp_vit*1e3:7.1f}  {exp_pre*1e3:7.1f}  {dec_comm*1e3:9.3f}     | {step:8.1f}  {t1/step:8.2f}     ({step_dp:8.1f}, {t1/step_dp:5.2f})")
+
+
+if __name__ == "__main__":
+    main()
