@@ -183,8 +183,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * slices and the residual + RMSNorm as two launches instead of omchat_peer_resid_rmsnorm; key 10: key tiles (of 64) per wave of the
  * split-KV decode attention, 0 = chosen from the grid size (1 for single sequences, up to 4 for large batches); key 11: 1 = the batched
  * decode GEMV never takes its x-stationary persistent form; key 12: 1 = the batched decode attention loads its K tiles as whole rows
- * through LDS instead of fragment-shaped straight to registers (same bits; measured neutral); key 13: 0 = multi-round 256x256 GEMMs
- * launch one workgroup per tile instead of the persistent one-workgroup-per-CU form that overlaps the next tile's prologue with the epilogue) */
+ * through LDS instead of fragment-shaped straight to registers (same bits; measured neutral); key 13: 1 = multi-round 256x256 GEMMs
+ * take the persistent one-workgroup-per-CU form that overlaps the next tile's prologue with the epilogue (same bits; measured neutral)) */
 int omchat_op_set_tuning(int key, int value);
 /* GEMM tile choices are measured on first use of a (dtype, epilogue, ceil(M/256), N, K) class; load / dump persist them as text
  * (returns the number of entries, -1 when the file cannot be opened); omchat_gemm_tune_runs = measurements done by this process */

@@ -473,27 +473,31 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
 // costs beyond its K loop with one workgroup per tile: ~15 us (EPI_NONE) to ~29 us (layer-scale + residual) per round on the 3-tile ViT
 // shapes -- workgroup dispatch, the first HBM round trip of the prologue, the epilogue and its store drain, none of it overlapped because
 // all 256 workgroups move in lockstep.  Here the prologue's round trip and the store drain run under the neighbouring tile's work and
-// the per-round dispatch disappears.  Tile order: round r = tiles [r G, r G + G_r) with the XCD remap applied inside the round.
+// the per-round dispatch disappears.
 template <typename T, int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmP p, int tiles) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int G = gridDim.x, w = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
-  auto coords = [&](int L, int& m0, int& n0) {
-    const int r0 = (L / G) * G;
-    const int gr = tiles - r0 < G ? tiles - r0 : G;               // workgroups active in this round
-    tile_coords_id(r0 + xcd_remap(L - r0, gr), p.M, p.N, 256, 256, m0, n0);
-  };
+  // Tile order = the one-workgroup-per-tile launch's: XCD x (workgroups w with w % 8 == x, dealt round-robin by the dispatcher) owns the
+  // contiguous logical range xcd_remap gives it and its G / 8 workgroups walk it G / 8 ids per round, so the 32 tiles an XCD runs together
+  // form the same 4 x 8 block and consecutive rounds move along the same A row panels (a per-round remap measured +2.8 % on the 259-round
+  // prefill gate|up: every round met a cold A panel).  G is a multiple of 8.
+  const int xcd = w & 7, per = G >> 3;
+  const int q8 = tiles >> 3, r8 = tiles & 7;
+  const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int count = q8 + (xcd < r8 ? 1 : 0);
   const int nk = p.K / (F8 ? 128 : 64);
+  int idx = w >> 3;
+  if (idx >= count) return;
   int m0, n0;
-  if (w >= tiles) return;
-  coords(w, m0, n0);
+  tile_coords_id(start + idx, p.M, p.N, 256, 256, m0, n0);
   bool issued = false;
-  for (int L = w; L < tiles; L += G) {
-    const bool more = L + G < tiles;
+  for (; idx < count; idx += per) {
+    const bool more = idx + per < count;
     int m1 = 0, n1 = 0;
-    if (more) coords(L + G, m1, n1);
+    if (more) tile_coords_id(start + idx + per, p.M, p.N, 256, 256, m1, n1);
     f32x4 acc[8][4];
     gemm8_segment<T, F8>(p, m0, n0, 0, nk, smem, acc, issued, more, m1, n1);
     gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(GemmP p, SkP sk) {
   }
 }
 
-int g_gemm_persist = 1;   // omchat_op_set_tuning key 13: 0 = multi-round 256^2 GEMMs launch one workgroup per tile (A/B)
+int g_gemm_persist = 0;   // omchat_op_set_tuning key 13: 1 = multi-round 256^2 GEMMs take the persistent form (measured neutral: DESIGN.md section 6)
 int g_gemm_skew = 0;      // tuning knob (omchat_op_set_tuning), units of s_sleep(16) ~ 1024 cycles
 constexpr size_t SK_SLAB_BYTES = 65536 * 4;
 constexpr int SK_MAX_WG = 256;
@@ -626,7 +630,7 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   if (a.stream_k > 0 && !use_sk && !have_ws) { omchat_set_error("launch_gemm: stream-K requested without workspace"); return 1; }
   if (!use_sk) R = 0;
   const int n_dp = tiles - R;
-  if (n_dp > G && g_gemm_persist && R == 0) hipLaunchKernelGGL(kern_p, dim3(G), dim3(512), LDS, stream, p, n_dp);
+  if (n_dp > G && g_gemm_persist && R == 0 && G >= 8) hipLaunchKernelGGL(kern_p, dim3(G & ~7), dim3(512), LDS, stream, p, n_dp);
   else if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
   if (R > 0) {
     unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
@@ -655,7 +659,7 @@ int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
   }
   GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
-  if (tiles > n_cu && g_gemm_persist) hipLaunchKernelGGL(kern_p, dim3(n_cu), dim3(512), LDS, stream, p, tiles);
+  if (tiles > n_cu && g_gemm_persist && n_cu >= 8) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
   else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
   OM_LAUNCH_CHECK();
   return 0;

@@ -298,7 +298,7 @@ def test_gemm_persistent_equals_one_workgroup_per_tile(gpu_lib, dt, M, N, K):
             assert rel(outs[1], ref) < TOL[dt], (epi, rel(outs[1], ref))
             assert torch.equal(outs[0], outs[1]), epi
     finally:
-        gpu_lib.omchat_op_set_tuning(13, 1)
+        gpu_lib.omchat_op_set_tuning(13, 0)
 
 
 def test_gemm_persistent_race_screen(gpu_lib):
@@ -309,6 +309,7 @@ def test_gemm_persistent_race_screen(gpu_lib):
     dA, dW = dev(A, dt), dev(W, dt)
     ref = A @ W.t()
     outs = []
+    gpu_lib.omchat_op_set_tuning(13, 1)
     for it in range(3):
         out = torch.full((M, N), float("nan"), dtype=DT[dt], device="cuda")
         _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), N, M, N, K, None, None, None, 0, _lib.EPI_NONE, 2, None))
@@ -323,4 +324,5 @@ def test_gemm_persistent_race_screen(gpu_lib):
     dx = dev(x, dt)
     _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(dx), N, M, N, K, None, None, ptr(dx), N, _lib.EPI_RESID, 2, None))
     sync()
+    gpu_lib.omchat_op_set_tuning(13, 0)
     assert rel(dx, x + rnd(ref, dt)) < TOL[dt]
