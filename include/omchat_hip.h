@@ -184,7 +184,14 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * split-KV decode attention, 0 = chosen from the grid size (1 for single sequences, up to 4 for large batches); key 11: 1 = the batched
  * decode GEMV never takes its x-stationary persistent form; key 12: 1 = the batched decode attention loads its K tiles as whole rows
  * through LDS instead of fragment-shaped straight to registers (same bits; measured neutral); key 13: 1 = multi-round 256x256 GEMMs
- * take the persistent one-workgroup-per-CU form that overlaps the next tile's prologue with the epilogue (same bits; measured neutral)) */
+ * take the persistent one-workgroup-per-CU form that overlaps the next tile's prologue with the epilogue (same bits; measured neutral);
+ * key 14: 0 = batch-1 decode keeps the post-attention residual + RMSNorm as a launch of its own instead of running the norm in the
+ * registers of the gate|up GEMV) */
+/* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
+ * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
+ * post_attention_layernorm + gate|up) */
+int omchat_op_gemv_norm(int dtype, const void* X, const void* W, int ldw, void* Y, int N, int K, const void* norm_w, float eps,
+                        const void* bias, int epi, int out_f32, void* stream);
 int omchat_op_set_tuning(int key, int value);
 /* GEMM tile choices are measured on first use of a (dtype, epilogue, ceil(M/256), N, K) class; load / dump persist them as text
  * (returns the number of entries, -1 when the file cannot be opened); omchat_gemm_tune_runs = measurements done by this process */

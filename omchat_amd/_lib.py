@@ -51,6 +51,7 @@ _SIGS = {
     "omchat_kv_lengths": (_i, [_vp, _vp, _i]),
     "omchat_set_allreduce_hook": (_i, [_vp, _vp, _vp]),
     "omchat_allreduce_noop": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
+    "omchat_op_gemv_norm": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _vp]),
     "omchat_prof_enable": (_i, [_vp, _i]),
     "omchat_prof_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
     "omchat_mha_fwd": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),

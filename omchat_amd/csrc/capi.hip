@@ -24,6 +24,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 11) { gemv_set_no_xs(value); return 0; }
   if (key == 12) { attn_set_klds(value); return 0; }
   if (key == 13) { gemm_set_persist(value); return 0; }
+  if (key == 14) { model_set_norm_in_gemv(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }
@@ -46,6 +47,15 @@ extern "C" int omchat_op_gemm_sk(int dtype, const void* A, int lda, const void* 
 extern "C" int omchat_op_gemv(int dtype, const void* X, int ldx, const void* W, int ldw, void* Y, int ldy, int b, int N, int K,
                               const void* bias, const void* resid, int ldr, int epi, int out_f32, void* stream) {
   GemvArgs g{X, ldx, W, ldw, Y, ldy, b, N, K, bias, resid, ldr, epi, out_f32};
+  return launch_gemv(dtype, g, S(stream));
+}
+
+// batch-1 GEMV with the preceding RMSNorm in registers: y = epi(W RMSNorm(x; norm_w, eps)), x the RAW row [K] (K <= 4096)
+extern "C" int omchat_op_gemv_norm(int dtype, const void* X, const void* W, int ldw, void* Y, int N, int K, const void* norm_w, float eps,
+                                   const void* bias, int epi, int out_f32, void* stream) {
+  OM_CHECK(X && W && Y && norm_w, "null argument");
+  GemvArgs g{X, K, W, ldw, Y, N, 1, N, K, bias, nullptr, 0, epi, out_f32};
+  g.norm_w = norm_w; g.norm_eps = eps;
   return launch_gemv(dtype, g, S(stream));
 }
 

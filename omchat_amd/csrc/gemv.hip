@@ -10,6 +10,7 @@
 // (8 waves x UNROLL x 2 KiB per workgroup).  The 8 partial 16x16 fp32 tiles are summed through LDS in a fixed order
 // (deterministic, no atomics), and wave 0 applies the epilogue.
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -18,6 +19,7 @@ struct GemvP {
   int ldx, ldw, ldy, ldr, b, N, K, out_f32, ksplit;
   const float* w_scale;
   int y_packed;
+  const void* norm_w; float norm_eps;      // whole-row batch-1 form: X is the RAW hidden row, normalised in registers (gemv_rows_norm_kernel)
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
@@ -640,6 +642,143 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Whole-row GEMV with the RMSNorm that precedes the projection computed in registers (round 3; batch 1, no split-K, K = 512 NCH <= 4096):
+//   y = epi(W xn),  xn = T(w * T(x * rsqrt(mean(x^2) + eps)))      (Qwen2RMSNorm's rounding points, modeling_qwen2.py:247-252)
+// X is the RAW hidden row.  One group of rows per wave; ALL of the group's weight loads are issued first, then the workgroup's four
+// waves normalise the row together through LDS (x and the norm weights are read once per WORKGROUP) while those loads are in flight,
+// the dot products last.  Measured forms that did not pay: the chain in front of the weight loads, every wave for itself (gate|up
+// 41.6 -> 45.8 us: exactly the launch it removes); every wave for itself with half the rows per wave to make room (48.3 us: x and the norm
+// weights were then half as many bytes through the CU as the weights).  All waves use the same sum (fixed order): the same bits.
+// It removes the residual + RMSNorm launch in front of the gate|up GEMV of a batch-1 decode step (o_proj then writes x + attn itself).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, int RR, int NCH, bool F8>
+__global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
+  typedef typename V8<T>::type v8;
+  constexpr int R = EPI == EPI_SWIGLU ? 2 * RR : RR;
+  __shared__ __attribute__((aligned(16))) T xs[NCH * 512];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  const int g = blockIdx.x * 4 + wave;
+  // ---- 1. this wave's weight rows: every load issued now
+  int rows[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if constexpr (EPI == EPI_SWIGLU) {
+      int n = g * RR + (r % RR); n = n < n_out ? n : n_out - 1;
+      rows[r] = 32 * (n >> 4) + (n & 15) + (r / RR) * 16;       // gate rows, then the matching up rows
+    } else {
+      const int n = g * R + r;
+      rows[r] = n < p.N ? n : p.N - 1;
+    }
+  }
+  typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
+  wreg_t w[R][NCH];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int k = c * 512 + lane * 8;
+      k = k < p.K ? k : 0;                      // ragged last chunk: clamp (x is zero there)
+      if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)rows[r] * p.ldw + k));
+      else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)rows[r] * p.ldw + k));
+    }
+  // ---- 2. the norm, shared by the workgroup: wave w owns chunks w, w + 4 (x and the norm weights are read ONCE per workgroup: 2 x 7 KB
+  // instead of 7 KB of xn per wave), partial sums of squares meet in LDS, the normalised row goes to LDS, every wave reads it back.
+  // The plain loads above stay in flight across the two barriers.
+  constexpr int MC = (NCH + 3) / 4;
+  rw_u32x4 xq[MC], nq[MC];
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i, k = c * 512 + lane * 8;
+    const rw_u32x4 z = {0u, 0u, 0u, 0u};
+    const bool ok = c < NCH && k < p.K;
+    xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
+  }
+  __builtin_amdgcn_sched_barrier(0);            // keep every load above the first wait
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const v8 xv = __builtin_bit_cast(v8, xq[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = tof(xv[j]); ss += v * v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) red[wave] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float inv = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)p.K + p.norm_eps);      // fixed order: the same bits in every wave
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i;
+    if (c < NCH) {
+      const v8 xv = __builtin_bit_cast(v8, xq[i]), wv = __builtin_bit_cast(v8, nq[i]);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(tof(xv[j]) * inv));
+      *reinterpret_cast<v8*>(xs + c * 512 + lane * 8) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rw_u32x4 xr[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const rw_u32x4*>(xs + c * 512 + lane * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 3. dot products
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if constexpr (F8) a = rw_dot8_fp8<T>(w[r][c], xr[c], a);
+      else a = rw_dot8<T>(w[r][c], xr[c], a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if constexpr (F8) a *= p.w_scale[rows[r]];
+    acc[r] = a;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int n = g * RR + r;
+      if (n >= n_out) continue;
+      if constexpr (EPI == EPI_SWIGLU) {
+        const float gt = rnd<T>(acc[r]), up = rnd<T>(acc[r + RR]);
+        ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
+      } else {
+        const float y = acc[r] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+        if (p.out_f32) ((float*)p.Y)[n] = y;
+        else ((T*)p.Y)[n] = fromf<T>(y);
+      }
+    }
+  }
+}
+
+template <typename T, int EPI, int RR, bool F8, int NCH>
+void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, RR, NCH, F8>), dim3(cdiv(cdiv(n_out, RR), 4)), dim3(256), 0, s, p);
+}
+template <typename T, int EPI, int RR, bool F8>
+void launch_rows_norm(const GemvP& p, hipStream_t s) {
+  switch (cdiv(p.K, 512)) {
+    case 1: launch_rows_norm_n<T, EPI, RR, F8, 1>(p, s); break;
+    case 2: launch_rows_norm_n<T, EPI, RR, F8, 2>(p, s); break;
+    case 3: launch_rows_norm_n<T, EPI, RR, F8, 3>(p, s); break;
+    case 4: launch_rows_norm_n<T, EPI, RR, F8, 4>(p, s); break;
+    case 5: launch_rows_norm_n<T, EPI, RR, F8, 5>(p, s); break;
+    case 6: launch_rows_norm_n<T, EPI, RR, F8, 6>(p, s); break;
+    case 7: launch_rows_norm_n<T, EPI, RR, F8, 7>(p, s); break;
+    default: launch_rows_norm_n<T, EPI, RR, F8, 8>(p, s); break;
+  }
+}
+
 template <typename T, int EPI, int RR, bool F8>
 void launch_rows_r(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
@@ -653,12 +792,27 @@ void launch_rows_r(const GemvP& p, hipStream_t s) {
 template <typename T, int EPI>
 void launch_rows(const GemvP& p, hipStream_t s) {
   if (p.w_scale) {
-    if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1, true>(p, s);
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
+      if (p.norm_w) {
+        if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 1, true>(p, s);
+        else launch_rows_norm<T, EPI, 4, true>(p, s);
+        return;
+      }
+    }
+    if ((EPI == EPI_NONE || EPI == EPI_RESID) && p.N < 32768) launch_rows_r<T, EPI, 1, true>(p, s);
     else if (EPI == EPI_NONE) launch_rows_r<T, EPI, 8, true>(p, s);      // lm_head: 80.7 vs 82.3 us
     else launch_rows_r<T, EPI, 4, true>(p, s);
     return;
   }
-  if (EPI == EPI_NONE && p.N < 32768) launch_rows_r<T, EPI, 1, false>(p, s);
+  if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
+    if (p.norm_w) {          // the norm shared through LDS; 3 (gate, up) pairs per wave: 6 x 7 chunks of weights + the row fit 256 VGPRs
+      if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 1, false>(p, s);
+      else if (EPI == EPI_SWIGLU) launch_rows_norm<T, EPI, 3, false>(p, s);
+      else launch_rows_norm<T, EPI, 4, false>(p, s);
+      return;
+    }
+  }
+  if ((EPI == EPI_NONE || EPI == EPI_RESID) && p.N < 32768) launch_rows_r<T, EPI, 1, false>(p, s);      // short outputs: one row per wave (latency-bound)
   else launch_rows_r<T, EPI, 4, false>(p, s);
 }
 
@@ -667,7 +821,8 @@ void launch_rows(const GemvP& p, hipStream_t s) {
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed};
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed, a.norm_w, a.norm_eps};
+  if (a.norm_w && a.x_packed) { omchat_set_error("launch_gemv: the in-register RMSNorm is a batch-1 form (row-major x)"); return 1; }
   if (a.x_packed) {
     // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
 #define OM_PK(NT_, EPI_, WV_, UN_)                                                                                                  \
@@ -726,6 +881,10 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     return 0;
   }
   const bool rows_ok = a.b == 1 && cdiv(cdiv(a.K, 512), ks) <= RW_MAXC;
+  if (a.norm_w && !(rows_ok && ks == 1 && !a.force_mfma && !g_gemv_force_mfma && (a.epi == EPI_NONE || a.epi == EPI_SWIGLU))) {
+    omchat_set_error("launch_gemv: the in-register RMSNorm needs the whole-row batch-1 form without split-K (K <= 4096), epilogue NONE / SWIGLU");
+    return 1;
+  }
   if (a.w_scale && !rows_ok) { omchat_set_error("launch_gemv: fp8 weights need b == 1 and <= 8 chunks of 512 per K slice"); return 1; }
   if (rows_ok && (a.w_scale || (!a.force_mfma && !g_gemv_force_mfma))) {       // whole-row streaming form
     switch (a.epi) {

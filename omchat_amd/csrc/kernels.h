@@ -56,6 +56,8 @@ struct GemvArgs {
   int x_packed;             // X is packed with NB = b > 16 ? 2 : 1 (ldx ignored)
   int w_packed;             // W is the packed replica (ldw ignored); needs x_packed
   int y_packed;             // EPI_SWIGLU only: write Y in the packed x layout of the consumer (same NB; ldy ignored)
+  // b == 1, ksplit <= 1, whole-row form: X is the RAW hidden row and y = epi(W RMSNorm(X; norm_w, norm_eps)) -- the norm runs in registers
+  const void* norm_w; float norm_eps;
 };
 // row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
@@ -71,6 +73,7 @@ int gemm_tune_dump(const char* path);
 long gemm_tune_runs();
 void model_set_ar_min_rows(int v);
 void model_set_pack_replica(int v);
+void model_set_norm_in_gemv(int v);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)

@@ -527,6 +527,8 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
+int g_norm_in_gemv = 1;       // omchat_op_set_tuning key 14: 0 = batch-1 decode keeps the post-attention residual + RMSNorm as its own launch (A/B)
+void model_set_norm_in_gemv(int v) { g_norm_in_gemv = v; }
 int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
 void model_set_pack_replica(int v) { g_pack_replica = v; }
 int g_ar_min_rows = 1024;      // rows from which a projection is pipelined in 2 (x3: 4) chunks; tests lower it (omchat_op_set_tuning key 4)
@@ -1127,7 +1129,12 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     }
     a.o_pack_nb = fused ? pk : 0;
     TRY(launch_attn_decode(ctx->dt, a, s));
-    if (fused) {
+    // batch 1, one GPU (round 3): o_proj without split-K writes x + attn itself (EPI_RESID, in place) and the post-attention RMSNorm runs
+    // in the registers of the gate|up GEMV's waves (gemv.hip: norm_w): seven dependent launches per layer instead of eight
+    const bool n2 = g_norm_in_gemv && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096;
+    if (n2) {
+      TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
+    } else if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
       TRY(ctx->reduce_resid_rmsnorm(x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, pk, s));
     } else if (ctx->tp_size == 1) {
@@ -1142,7 +1149,13 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     // per token would themselves slow the measured decode by a few per cent
     const bool mark = allow_prof && i == c.t_layers / 2;
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
+    if (n2) {
+      GemvArgs g = gemv_args(x, H, L.wgu, H, ctx->tw_act, It, 1, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, Q.wgu, Q.sgu, nullptr, false);
+      g.norm_w = L.ln2; g.norm_eps = c.t_eps;
+      TRY(launch_gemv(ctx->dt, g, s));
+    } else {
+      TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
+    }
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (fused) {
       TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd, P.wd));

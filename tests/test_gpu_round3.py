@@ -11,7 +11,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from gpu_util import DT, CODE, TOL, dev, rnd, rel, sync, ptr, randn
+from gpu_util import DT, CODE, TOL, TOL_DEEP, dev, rnd, rel, sync, ptr, randn
 from test_gpu_ops import _attn_ref
 from omchat_amd import synth, _lib
 from omchat_amd.config import omchat8b_21, omchat13b, tiny
@@ -326,3 +326,73 @@ def test_gemm_persistent_race_screen(gpu_lib):
     sync()
     gpu_lib.omchat_op_set_tuning(13, 0)
     assert rel(dx, x + rnd(ref, dt)) < TOL[dt]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batch-1 decode: post-attention RMSNorm in the registers of the gate|up GEMV (tuning key 14), o_proj writing x + attn itself
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,K,epi", [(512, 256, "none"), (37888, 3584, "swiglu"), (4608, 3584, "none"), (96, 4096, "swiglu"), (320, 64, "none")])
+def test_gemv_with_the_norm_in_registers(gpu_lib, dt, N, K, epi):
+    """y = epi(W RMSNorm(x)) against fp32 torch with Qwen2RMSNorm's rounding points (x * rsqrt(mean(x^2) + eps) rounded to T, times w rounded
+    to T: modeling_qwen2.py:247-252), SwiGLU on the 16-row interleaved gate | up layout"""
+    x = rnd(randn((K,), 1), dt); w = rnd(randn((N, K), 2, 0.05), dt); nw = rnd(randn((K,), 3, 0.1) + 1.0, dt)
+    eps = 1e-6
+    xn = rnd(nw * rnd(x * torch.rsqrt((x * x).mean() + eps), dt), dt)
+    y = w @ xn
+    code = _lib.EPI_NONE
+    if epi == "swiglu":
+        code = _lib.EPI_SWIGLU
+        blocks = y.reshape(N // 32, 2, 16)
+        g, u = rnd(blocks[:, 0], dt), rnd(blocks[:, 1], dt)
+        y = (rnd(torch.nn.functional.silu(g), dt) * u).reshape(N // 2)
+    dx, dw, dn = dev(x, dt), dev(w, dt), dev(nw, dt)
+    out = torch.full((y.numel(),), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(dx), ptr(dw), K, ptr(out), N, K, ptr(dn), eps, None, code, 0, None))
+    sync()
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, y) < TOL[dt], rel(out, y)
+    with pytest.raises(ValueError):           # K > 4096 does not fit a wave's registers: refused, never silently un-normalised
+        big = torch.zeros(8192, dtype=DT[dt], device="cuda"); bw = torch.zeros(32, 8192, dtype=DT[dt], device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(big), ptr(bw), 8192, ptr(out), 32, 8192, ptr(big), eps, None, _lib.EPI_NONE, 0, None))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("fp8", [False, True])
+def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8):
+    """the seven-launch layer (key 14 = 1, default) against the eight-launch layer (key 14 = 0) and the oracle: same model, 5 decode steps;
+    the two differ only in the fp32 summation order of the o_proj K sum and of the sum of squares"""
+    cfg = tiny(q_heads=4, kv_heads=2)
+    sd = {k: v for k, v in synth.state_dict(cfg, 9).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    x = rnd(torch.randn(1, 21, 256, generator=torch.Generator().manual_seed(2)) * 0.5, dt)
+    runs = {}
+    try:
+        for key in (1, 0):
+            gpu_lib.omchat_op_set_tuning(14, key)
+            e = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            if fp8:
+                e.enable_fp8_decode(True)
+            e.prefill(x)
+            tok, outs = torch.tensor([11]), []
+            for _ in range(5):
+                _, lg = e.decode_step(tok, want_logits=True)
+                outs.append(lg.float().cpu().clone())
+                tok = torch.tensor([int(torch.argmax(outs[-1][0])) if key == 1 or not runs else runs[1][1][len(outs) - 1]])
+            sync()
+            runs[key] = (outs, [int(torch.argmax(o[0])) for o in outs])
+            e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(14, 1)
+    for a_, b_ in zip(runs[1][0], runs[0][0]):
+        assert rel(a_, b_) < (1.2e-2 if dt == "bf16" else 2.5e-3), rel(a_, b_)
+    if not fp8:
+        import oracle
+        sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items()}
+        cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+        oracle.qwen2_model(x, sdt, cfg.text, cache)
+        tok = 11
+        for s_ in range(5):
+            ref = oracle.decode_step(torch.tensor([[tok]]), sdt, cfg.text, cache)[0, 0]
+            assert rel(runs[1][0][s_][0], ref) < TOL_DEEP[dt], (s_, rel(runs[1][0][s_][0], ref))
+            tok = runs[1][1][s_]

@@ -387,3 +387,27 @@ def test_decode_branch_of_the_splice_mirror_vs_reference_golden():
             assert emb is None and labels is None and past is cache and ids.shape == (2, 1)
             assert mask.dtype == torch.long and np.array_equal(mask.numpy(), g[f"{side}_dec_mask_{k}"])
             assert np.array_equal(pos.numpy(), g[f"{side}_dec_pos_{k}"])
+
+
+def test_bench_parent_never_touches_hip_and_algorithmic_constants():
+    """bench.py: (1) the process that spawns the N ranks counts GPUs from the KFD topology and must not reach torch / HIP (the
+    children are started from it); (2) the algorithmic FLOPs / bytes the roofline fractions are priced with equal SURVEY.md 8(d)'s figures
+    for OmChat-13B and follow the same formulas for OmChat-2.1-8B"""
+    import importlib.util, inspect, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = inspect.getsource(bench.spawn_ranks) + inspect.getsource(bench.count_gpus_without_hip)
+    assert "import torch" not in src and "torch." not in src and "ctypes" not in src and "_lib" not in src
+    n = bench.count_gpus_without_hip()
+    assert isinstance(n, int) and n >= 0
+    from omchat_amd.config import omchat13b, omchat8b_21
+    a = bench.algorithmic(omchat13b())
+    assert abs(a["vit_tile"] / 1e12 - (11.945 + 0.0498)) < 2e-3            # SURVEY 8(d): ViT 11.945 TF + projector 0.0498 TF per tile
+    assert abs(a["prefill"](3584) / 1e12 - 49.36) < 1e-2                    # 46.78 + 2.58 TF at S = 3584
+    assert abs(a["decode_weight_bytes"] / 1e9 - 14.14) < 1e-2 and a["kv_bytes_per_pos"] == 57344.0
+    b = bench.algorithmic(omchat8b_21())
+    per_layer = 2 * 1025 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 4 * 1025 ** 2 * 1024
+    assert abs(b["vit_tile"] - (24 * per_layer + 2 * 1024 * 588 * 1024 + 2 * 1024 * (1024 * 3584 + 3584 ** 2))) < 1.0
+    assert b["decode_weight_bytes"] == a["decode_weight_bytes"]             # same Qwen2-7B decoder

@@ -12,7 +12,8 @@ Communication model (stated, not measured):
   * decode-sized messages go through the one-shot peer kernel (csrc/comm.hip) fused with the residual + RMSNorm launch that exists anyway:
     extra cost LAT_PEER = 4 us per exchange (flag round trip over xGMI + (n-1) remote 16-byte-granule reads), 2 per layer + 1 for the argmax.
   * prefill / ViT all-reduces run on the communication stream under the next row chunk's GEMM (model.hip: gemm_allreduce): per
-    projection the exposed time is max(sum of chunk all-reduces - GEMM time of the later chunks, last chunk's all-reduce).
+    projection the exposed time is max(sum of chunk all-reduces - GEMM time of the later chunks, one chunk's all-reduce); projections
+    too small to be chunked (a chunk must hold >= 256 tiles: the 3-tile sample, the single-sequence prefill) expose all of it.
 """
 import json
 import sys
@@ -21,6 +22,7 @@ LINK = 153e9
 EFF = 0.60
 LAT_RCCL = 25e-6
 LAT_PEER = 4e-6
+F_ROW = 0.41          # share of a phase's per-rank compute spent in the two row-parallel projections (proj + fc2 / o_proj + down_proj)
 
 
 def allreduce_s(nbytes, n):
@@ -47,15 +49,22 @@ def main():
             S = 3584
             # ViT: 45 layers x 2 all-reduces of [tiles x 1025, 3200] 16-bit per tower chunk (+ the [rows, 2] fp32 q/k-norm sums)
             m_vit = tiles_chunk * 1025 * 3200 * 2
-            ar_vit = 45 * n_chunks * (2 * allreduce_s(m_vit, n) + allreduce_s(tiles_chunk * 1025 * 8, n))
             # prefill: 28 layers x 2 all-reduces of [b x S, 3584] 16-bit
             m_pre = b * S * 3584 * 2
-            ar_pre = 28 * 2 * allreduce_s(m_pre, n)
-            # overlap: large (chunked) projections hide all but the last chunk's all-reduce when the GEMM of the later chunks is longer;
-            # here the sums are compared on the whole phase: exposed = max(comm - 0.5 x compute, comm / 4) for chunked shapes, all of it otherwise
+            # overlap (model.hip: gemm_allreduce): a projection whose output holds >= 256 tiles per chunk is cut into 4 row chunks and the
+            # all-reduce of chunk i runs under the GEMM of chunk i + 1, after which the launch stream waits for the last all-reduce:
+            # exposed = max(sum of the chunk all-reduces - 3/4 of that projection's GEMM time, one chunk's all-reduce).  The GEMM time of
+            # the two row-parallel projections is F_ROW of the phase's compute (kernel stats, profiles/r03_a_kernel_stats_shard8_*).
+            def exposed(n_ar, msg_bytes, phase_ms, chunked):
+                one = allreduce_s(msg_bytes, n)
+                if not chunked:
+                    return n_ar * one
+                g = F_ROW * phase_ms / 1e3 / n_ar                      # GEMM seconds of one projection
+                total = 4 * LAT_RCCL + (one - LAT_RCCL)                  # four chunk calls, the same bytes
+                return n_ar * max(total - 0.75 * g, total / 4)
             chunked = b > 1
-            exp_vit = max(ar_vit - 0.5 * s["vit_ms_p50"] / 1e3, ar_vit / 4) if chunked else ar_vit
-            exp_pre = max(ar_pre - 0.5 * s["prefill_ms_p50"] / 1e3, ar_pre / 4) if chunked else ar_pre
+            exp_vit = exposed(45 * n_chunks * 2, m_vit, s["vit_ms_p50"], chunked) + 45 * n_chunks * allreduce_s(tiles_chunk * 1025 * 8, n)
+            exp_pre = exposed(28 * 2, m_pre, s["prefill_ms_p50"], chunked)
             dec_comm = (28 * 2 + 1) * LAT_PEER
             vit = s["vit_ms_p50"] + exp_vit * 1e3
             pre = s["prefill_ms_p50"] + exp_pre * 1e3
