@@ -760,6 +760,108 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Whole-row GEMV for LONG K without split-K (round 3; batch 1: down_proj, K = 18944): y[n] = resid[n] + T(sum_k W[n][k] x[k]), in place.
+// The split-K form leaves fp32 slices that a residual + RMSNorm launch must sum; here a workgroup stages x (37 KB) in LDS once, every
+// wave streams whole rows in passes of 8 chunks of 512 (weights of pass p + 1 in flight under the dot products of pass p) and lane 0
+// adds the residual: x + mlp is complete when the launch ends, and the NEXT projection normalises it in its own registers
+// (gemv_rows_norm_kernel).  Rows are dealt to 2 workgroups per CU, row r of a workgroup to wave r % 4.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool F8>
+__global__ __launch_bounds__(256) void gemv_rows_longk_kernel(GemvP p, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char xs_raw[];
+  T* xs = (T*)xs_raw;
+  constexpr int RPW = 2;                        // rows a wave has in flight (rows_per_wg <= 4 * RPW)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nch = (p.K + 511) >> 9, npass = (nch + 7) >> 3;
+  const int r0 = blockIdx.x * rows_per_wg;
+  int rows[RPW]; bool valid[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int local = wave + 4 * r, n = r0 + local;
+    valid[r] = local < rows_per_wg && n < p.N;
+    rows[r] = valid[r] ? n : (r0 < p.N ? r0 : p.N - 1);
+  }
+  typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
+  auto load_w = [&](wreg_t (&w)[RPW][8], int pass) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        int k = (pass * 8 + c) * 512 + lane * 8;
+        k = k < p.K ? k : 0;                    // beyond K: any valid address (x is zero there)
+        if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)rows[r] * p.ldw + k));
+        else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)rows[r] * p.ldw + k));
+      }
+  };
+  float acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+  auto dots = [&](wreg_t (&w)[RPW][8], int pass) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const rw_u32x4 xr = *reinterpret_cast<const rw_u32x4*>(xs + (pass * 8 + c) * 512 + lane * 8);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if constexpr (F8) acc[r] = rw_dot8_fp8<T>(w[r][c], xr, acc[r]);
+        else acc[r] = rw_dot8<T>(w[r][c], xr, acc[r]);
+      }
+    }
+  };
+  wreg_t wa[RPW][8], wb[RPW][8];
+  load_w(wa, 0);
+  // x -> LDS (zero beyond K up to the last whole pass), once per workgroup, under the first pass's weight loads
+  for (int i = threadIdx.x; i < npass * 8 * 64; i += 256) {
+    const rw_u32x4 z = {0u, 0u, 0u, 0u};
+    const rw_u32x4 v = i * 8 < p.K ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + i * 8) : z;
+    *reinterpret_cast<rw_u32x4*>(xs + i * 8) = v;
+  }
+  __syncthreads();
+  for (int ps = 0; ps < npass; ps += 2) {
+    if (ps + 1 < npass) load_w(wb, ps + 1);
+    dots(wa, ps);
+    if (ps + 1 < npass) {
+      if (ps + 2 < npass) load_w(wa, ps + 2);
+      dots(wb, ps + 1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float a = acc[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if constexpr (F8) a *= p.w_scale[rows[r]];
+    if (lane == 0 && valid[r]) {
+      const int n = rows[r];
+      const float y = rnd<T>(a + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f));
+      ((T*)p.Y)[n] = fromf<T>((p.resid ? tof(((const T*)p.resid)[n]) : 0.f) + y);
+    }
+  }
+}
+
+template <typename T>
+int launch_rows_longk(const GemvP& p, hipStream_t s) {
+  static int n_cu = 0;
+  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+  int rpw = cdiv(p.N, 2 * n_cu);                // two workgroups per CU
+  rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);
+  const int grid = cdiv(p.N, rpw);
+  const int npass = (cdiv(p.K, 512) + 7) / 8;
+  const size_t lds = (size_t)npass * 8 * 512 * 2;
+  if (p.w_scale) {
+    auto k = gemv_rows_longk_kernel<T, true>;
+    static bool set = false;
+    if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p, rpw);
+  } else {
+    auto k = gemv_rows_longk_kernel<T, false>;
+    static bool set = false;
+    if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p, rpw);
+  }
+  return 0;
+}
+
 template <typename T, int EPI, int RR, bool F8, int NCH>
 void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
@@ -794,7 +896,7 @@ void launch_rows(const GemvP& p, hipStream_t s) {
   if (p.w_scale) {
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
       if (p.norm_w) {
-        if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 1, true>(p, s);
+        if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 2, true>(p, s);
         else launch_rows_norm<T, EPI, 4, true>(p, s);
         return;
       }
@@ -806,7 +908,7 @@ void launch_rows(const GemvP& p, hipStream_t s) {
   }
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
     if (p.norm_w) {          // the norm shared through LDS; 3 (gate, up) pairs per wave: 6 x 7 chunks of weights + the row fit 256 VGPRs
-      if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 1, false>(p, s);
+      if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 2, false>(p, s);      // qkv: 8 rows (56 KB) per workgroup against 14 KB of x + norm weights
       else if (EPI == EPI_SWIGLU) launch_rows_norm<T, EPI, 3, false>(p, s);
       else launch_rows_norm<T, EPI, 4, false>(p, s);
       return;
@@ -877,6 +979,13 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     else if (a.N >= 32768) OM_PK(4, EPI_NONE, 4, 4);
     else OM_PK(2, EPI_NONE, 8, 4);
 #undef OM_PK
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (a.b == 1 && !a.x_packed && a.epi == EPI_RESID && ks == 1 && !a.out_f32 && a.K > RW_MAXC * 512 && a.K % 8 == 0 && a.K <= 32768 &&
+      !a.force_mfma && !g_gemv_force_mfma) {
+    const int rc = launch_rows_longk<T>(p, s);      // long K in one piece: x through LDS, the result complete when the launch ends
+    if (rc) return rc;
     OM_LAUNCH_CHECK();
     return 0;
   }

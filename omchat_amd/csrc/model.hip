@@ -527,7 +527,8 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
-int g_norm_in_gemv = 1;       // omchat_op_set_tuning key 14: 0 = batch-1 decode keeps the post-attention residual + RMSNorm as its own launch (A/B)
+int g_norm_in_gemv = 3;       // omchat_op_set_tuning key 14: bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final norm
+                              // inside qkv / lm_head with down_proj un-split (0 = batch-1 decode keeps both residual + RMSNorm launches: A/B)
 void model_set_norm_in_gemv(int v) { g_norm_in_gemv = v; }
 int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
 void model_set_pack_replica(int v) { g_pack_replica = v; }
@@ -1093,7 +1094,13 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // replica is in use; otherwise ~2 workgroups per CU for the MFMA form
   const int ks_o = b == 1 ? ks_rows(qd) : (wpk && qd == 3584 ? 2 : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16))))));
   const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
-  if (fused) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+  // batch 1, one GPU (round 3): the two residual + RMSNorm launches of a layer disappear.  o_proj and down_proj run without split-K and
+  // write x + attn / x + mlp themselves (EPI_RESID, in place; down_proj's K = 18944 through gemv_rows_longk_kernel), and each RMSNorm runs
+  // inside the projection that consumes it (gemv_rows_norm_kernel: qkv, gate|up, lm_head): six dependent launches per layer instead of
+  // eight.  n2 = the post-attention norm (tuning key 14 bit 0), n1 = the input norm of the next layer / the final norm (bit 1).
+  const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096;
+  const bool n1 = n2 && (g_norm_in_gemv & 2) && It <= 32768 && It % 8 == 0;
+  if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     static const omchat_ctx::DecLayer8 none8{};
@@ -1102,7 +1109,13 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
-    TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
+    if (n1) {
+      GemvArgs g = gemv_args(x, H, L.wqkv, H, ctx->tw_qkv, qkvd, 1, qkvd, L.bqkv, nullptr, EPI_NONE, 0, Q.wqkv, Q.sqkv, nullptr, false);
+      g.norm_w = L.ln1; g.norm_eps = c.t_eps;
+      TRY(launch_gemv(ctx->dt, g, s));
+    } else {
+      TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
+    }
     // RoPE + KV append are fused into the attention kernel (q rotated in registers, the split that owns the new
     // position rotates k and appends k / v)
     AttnDecodeArgs a{};
@@ -1131,7 +1144,6 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     TRY(launch_attn_decode(ctx->dt, a, s));
     // batch 1, one GPU (round 3): o_proj without split-K writes x + attn itself (EPI_RESID, in place) and the post-attention RMSNorm runs
     // in the registers of the gate|up GEMV's waves (gemv.hip: norm_w): seven dependent launches per layer instead of eight
-    const bool n2 = g_norm_in_gemv && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096;
     if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
     } else if (fused) {
@@ -1157,7 +1169,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));
     }
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
-    if (fused) {
+    if (n1) {
+      TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID, Q.wd, Q.sd));
+    } else if (fused) {
       TRY(gemv_partial(ctx->tw_act, It, L.wd, It, ks_d, Q.wd, Q.sd, P.wd));
       const void* nw = i + 1 < c.t_layers ? ctx->dl[i + 1].ln1 : ctx->t_norm;      // next layer's input norm, or the final norm
       TRY(ctx->reduce_resid_rmsnorm(x, H, ctx->tw_part, ks_d, nw, ctx->tw_xn, H, b, H, c.t_eps, pk, s));
@@ -1171,7 +1185,14 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   }
   if (!fused)   TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, ctx->tw_xn, H, b, H, c.t_eps, s));
   float* lg = logits ? logits : ctx->tw_logits;
-  TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
+  if (n1) {
+    GemvArgs g{x, H, ctx->t_lm, H, lg, c.t_vocab, 1, c.t_vocab, H, nullptr, nullptr, 0, EPI_NONE, 1};
+    if (f8) { g.W = ctx->t_lm8; g.w_scale = ctx->t_lm8_s; }
+    g.norm_w = ctx->t_norm; g.norm_eps = c.t_eps;
+    TRY(launch_gemv(ctx->dt, g, s));
+  } else {
+    TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
+  }
   if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
   hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
