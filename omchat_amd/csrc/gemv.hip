@@ -768,74 +768,65 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
 // (gemv_rows_norm_kernel).  Rows are dealt to 2 workgroups per CU, row r of a workgroup to wave r % 4.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, bool F8>
-__global__ __launch_bounds__(256) void gemv_rows_longk_kernel(GemvP p, int rows_per_wg) {
+__global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char xs_raw[];
   T* xs = (T*)xs_raw;
-  constexpr int RPW = 2;                        // rows a wave has in flight (rows_per_wg <= 4 * RPW)
+  // one row per wave, rows_per_wg (<= 8) waves per workgroup: every wave of a workgroup streams the same number of bytes (7 rows per
+  // workgroup at N = 3584 on 2 x 256 workgroups; two rows per wave on 4 waves left the fourth wave idle half the time: 26.0 us)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nch = (p.K + 511) >> 9, npass = (nch + 7) >> 3;
-  const int r0 = blockIdx.x * rows_per_wg;
-  int rows[RPW]; bool valid[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int local = wave + 4 * r, n = r0 + local;
-    valid[r] = local < rows_per_wg && n < p.N;
-    rows[r] = valid[r] ? n : (r0 < p.N ? r0 : p.N - 1);
-  }
+  const int n = blockIdx.x * rows_per_wg + wave;
+  const bool valid = n < p.N;
+  const int row = valid ? n : p.N - 1;
   typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
-  auto load_w = [&](wreg_t (&w)[RPW][8], int pass) {
+  auto load_w = [&](wreg_t (&w)[8], int pass) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        int k = (pass * 8 + c) * 512 + lane * 8;
-        k = k < p.K ? k : 0;                    // beyond K: any valid address (x is zero there)
-        if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)rows[r] * p.ldw + k));
-        else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)rows[r] * p.ldw + k));
-      }
+    for (int c = 0; c < 8; ++c) {
+      int k = (pass * 8 + c) * 512 + lane * 8;
+      k = k < p.K ? k : 0;                      // beyond K: any valid address (x is zero there)
+      if constexpr (F8) w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)row * p.ldw + k));
+      else w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)row * p.ldw + k));
+    }
   };
-  float acc[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
-  auto dots = [&](wreg_t (&w)[RPW][8], int pass) {
+  float acc = 0.f;
+  auto dots = [&](wreg_t (&w)[8], int pass) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const rw_u32x4 xr = *reinterpret_cast<const rw_u32x4*>(xs + (pass * 8 + c) * 512 + lane * 8);
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if constexpr (F8) acc[r] = rw_dot8_fp8<T>(w[r][c], xr, acc[r]);
-        else acc[r] = rw_dot8<T>(w[r][c], xr, acc[r]);
-      }
+      if constexpr (F8) acc = rw_dot8_fp8<T>(w[c], xr, acc);
+      else acc = rw_dot8<T>(w[c], xr, acc);
     }
   };
-  wreg_t wa[RPW][8], wb[RPW][8];
+  wreg_t wa[8], wb[8], wc[8];
   load_w(wa, 0);
-  // x -> LDS (zero beyond K up to the last whole pass), once per workgroup, under the first pass's weight loads
-  for (int i = threadIdx.x; i < npass * 8 * 64; i += 256) {
+  if (npass > 1) load_w(wb, 1);
+  // x -> LDS (zero beyond K up to the last whole pass), once per workgroup, under the first passes' weight loads
+  for (int i = threadIdx.x; i < npass * 8 * 64; i += blockDim.x) {
     const rw_u32x4 z = {0u, 0u, 0u, 0u};
     const rw_u32x4 v = i * 8 < p.K ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + i * 8) : z;
     *reinterpret_cast<rw_u32x4*>(xs + i * 8) = v;
   }
   __syncthreads();
-  for (int ps = 0; ps < npass; ps += 2) {
-    if (ps + 1 < npass) load_w(wb, ps + 1);
+  // three register buffers: the weights of passes ps + 1 and ps + 2 are in flight under the dot products of pass ps (24 KB per wave)
+  for (int ps = 0; ps < npass; ps += 3) {
+    if (ps + 2 < npass) load_w(wc, ps + 2);
     dots(wa, ps);
     if (ps + 1 < npass) {
-      if (ps + 2 < npass) load_w(wa, ps + 2);
+      if (ps + 3 < npass) load_w(wa, ps + 3);
       dots(wb, ps + 1);
     }
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    float a = acc[r];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if constexpr (F8) a *= p.w_scale[rows[r]];
-    if (lane == 0 && valid[r]) {
-      const int n = rows[r];
-      const float y = rnd<T>(a + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f));
-      ((T*)p.Y)[n] = fromf<T>((p.resid ? tof(((const T*)p.resid)[n]) : 0.f) + y);
+    if (ps + 2 < npass) {
+      if (ps + 4 < npass) load_w(wb, ps + 4);
+      dots(wc, ps + 2);
     }
+  }
+  float a = acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if constexpr (F8) a *= p.w_scale[row];
+  if (lane == 0 && valid) {
+    const float y = rnd<T>(a + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f));
+    ((T*)p.Y)[n] = fromf<T>((p.resid ? tof(((const T*)p.resid)[n]) : 0.f) + y);
   }
 }
 
@@ -852,12 +843,12 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
     auto k = gemv_rows_longk_kernel<T, true>;
     static bool set = false;
     if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p, rpw);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * rpw), lds, s, p, rpw);
   } else {
     auto k = gemv_rows_longk_kernel<T, false>;
     static bool set = false;
     if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p, rpw);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * rpw), lds, s, p, rpw);
   }
   return 0;
 }

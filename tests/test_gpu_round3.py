@@ -368,7 +368,7 @@ def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8
     runs = {}
     try:
         for key in (1, 0):
-            gpu_lib.omchat_op_set_tuning(14, key)
+            gpu_lib.omchat_op_set_tuning(14, 3 if key else 0)
             e = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=1, vision=False)
             e.load_state_dict(sd)
             if fp8:
@@ -383,7 +383,7 @@ def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8
             runs[key] = (outs, [int(torch.argmax(o[0])) for o in outs])
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(14, 1)
+        gpu_lib.omchat_op_set_tuning(14, 3)
     for a_, b_ in zip(runs[1][0], runs[0][0]):
         assert rel(a_, b_) < (1.2e-2 if dt == "bf16" else 2.5e-3), rel(a_, b_)
     if not fp8:
@@ -396,3 +396,56 @@ def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8
             ref = oracle.decode_step(torch.tensor([[tok]]), sdt, cfg.text, cache)[0, 0]
             assert rel(runs[1][0][s_][0], ref) < TOL_DEEP[dt], (s_, rel(runs[1][0][s_][0], ref))
             tok = runs[1][1][s_]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,K,rows_resid", [(3584, 18944, True), (256, 4608, True), (96, 8256, False), (7, 32768, True), (3000, 12352, True)])
+def test_gemv_long_k_without_split(gpu_lib, dt, N, K, rows_resid):
+    """down_proj of a batch-1 step without split-K (gemv_rows_longk_kernel: x through LDS, weights in passes of 8 x 512): y = resid +
+    T(W x) in place, against fp32 torch; ragged K (not a multiple of 512 / of a pass), N not a multiple of the rows per workgroup"""
+    x = rnd(randn((K,), 1, 0.5), dt); w = rnd(randn((N, K), 2, 0.05), dt); r = rnd(randn((N,), 3), dt)
+    ref = r + rnd(w @ x, dt)
+    dx, dw, dr = dev(x, dt), dev(w, dt), dev(r, dt)
+    # in place (the decode step's form) or with the residual in its own buffer
+    y = dr if rows_resid else torch.full((N,), float("nan"), dtype=DT[dt], device="cuda")
+    _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dx), K, ptr(dw), K, ptr(y), N, 1, N, K, None, ptr(dr), N, _lib.EPI_RESID, 0, None))
+    sync()
+    assert torch.isfinite(y.float()).all()
+    assert rel(y, ref) < TOL[dt], rel(y, ref)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_decode_six_launch_layer_modes_agree(gpu_lib, dt):
+    """tuning key 14 = 3 (default: both norms inside their consumers, o_proj / down_proj un-split), 1 (post-attention norm only), 0 (eight
+    launches): the same model, the same tokens, logits equal to fp32-summation-order noise; mlp width 4608 takes the long-K kernel"""
+    cfg = tiny(q_heads=4, kv_heads=2, mlp_t=4608)
+    sd = {k: v for k, v in synth.state_dict(cfg, 9).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    x = rnd(torch.randn(1, 21, 256, generator=torch.Generator().manual_seed(2)) * 0.5, dt)
+    toks = [11, 3, 250, 17, 99]
+    runs = {}
+    try:
+        for key in (3, 1, 0):
+            gpu_lib.omchat_op_set_tuning(14, key)
+            e = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x)
+            outs = []
+            for t in toks:
+                nxt, lg = e.decode_step(torch.tensor([t]), want_logits=True)
+                outs.append(lg.float().cpu().clone())
+                assert int(nxt[0]) == int(torch.argmax(outs[-1][0]))
+            sync()
+            runs[key] = outs
+            e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(14, 3)
+    for key in (1, 0):
+        for a_, b_ in zip(runs[3], runs[key]):
+            assert torch.isfinite(a_).all() and rel(a_, b_) < (1.2e-2 if dt == "bf16" else 2.5e-3), (key, rel(a_, b_))
+    import oracle
+    sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items()}
+    cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+    oracle.qwen2_model(x, sdt, cfg.text, cache)
+    for s_, t in enumerate(toks):
+        ref = oracle.decode_step(torch.tensor([[t]]), sdt, cfg.text, cache)[0, 0]
+        assert rel(runs[3][s_][0], ref) < TOL_DEEP[dt], (s_, rel(runs[3][s_][0], ref))
