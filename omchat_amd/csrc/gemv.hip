@@ -761,6 +761,127 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Loop form of gemv_rows_norm_kernel (round 3): ONE resident round of workgroups (2 per CU), each owning a contiguous range of outputs
+// and every wave walking its share one output at a time (a row, or a (gate, up) pair) through a ring of three register buffers -- two
+// outputs' weights in flight under the dot products of the third.  Why: the one-shot form deals 12 outputs per workgroup, and gate|up has
+// 18944 = 37 x 512 of them: 1579 workgroups on 512 slots leave a fourth, 8 %-full round whose 43 workgroups finish alone on 43 CUs; here
+// every workgroup gets 37 outputs (waves 10 / 9 / 9 / 9) and the launch ends everywhere at once.  The norm prologue is the same and runs
+// once per workgroup.  Per output the arithmetic and its order are those of the one-shot form: the same bits.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, int NCH, bool F8>
+__global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int per_wg) {
+  typedef typename V8<T>::type v8;
+  constexpr int R = EPI == EPI_SWIGLU ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T xs[NCH * 512];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  const int o0 = blockIdx.x * per_wg, o1 = o0 + per_wg < n_out ? o0 + per_wg : n_out;
+  typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
+  auto row_of = [&](int n, int r) { return EPI == EPI_SWIGLU ? 32 * (n >> 4) + (n & 15) + r * 16 : n; };
+  auto load_w = [&](wreg_t (&w)[R][NCH], int n) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t row = (size_t)row_of(n, r);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int k = c * 512 + lane * 8;
+        k = k < p.K ? k : 0;                    // ragged last chunk: clamp (x is zero there)
+        if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + row * p.ldw + k));
+        else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + row * p.ldw + k));
+      }
+    }
+  };
+  // ---- 1. the first three outputs of this wave: every load issued now
+  wreg_t wa[R][NCH], wb[R][NCH], wc[R][NCH];
+  const int u0 = o0 + wave;
+  if (u0 < o1) load_w(wa, u0);
+  if (u0 + 4 < o1) load_w(wb, u0 + 4);
+  if (u0 + 8 < o1) load_w(wc, u0 + 8);
+  // ---- 2. the norm, shared by the workgroup (gemv_rows_norm_kernel step 2)
+  constexpr int MC = (NCH + 3) / 4;
+  rw_u32x4 xq[MC], nq[MC];
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i, k = c * 512 + lane * 8;
+    const rw_u32x4 z = {0u, 0u, 0u, 0u};
+    const bool ok = c < NCH && k < p.K;
+    xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
+  }
+  __builtin_amdgcn_sched_barrier(0);            // keep every load above the first wait
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const v8 xv = __builtin_bit_cast(v8, xq[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = tof(xv[j]); ss += v * v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) red[wave] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float inv = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)p.K + p.norm_eps);
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i;
+    if (c < NCH) {
+      const v8 xv = __builtin_bit_cast(v8, xq[i]), wv = __builtin_bit_cast(v8, nq[i]);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(tof(xv[j]) * inv));
+      *reinterpret_cast<v8*>(xs + c * 512 + lane * 8) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rw_u32x4 xr[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const rw_u32x4*>(xs + c * 512 + lane * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 3. dot products, one output at a time; the buffer just consumed is refilled with the output three steps ahead
+  auto finish = [&](wreg_t (&w)[R][NCH], int n) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (F8) a = rw_dot8_fp8<T>(w[r][c], xr[c], a);
+        else a = rw_dot8<T>(w[r][c], xr[c], a);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if constexpr (F8) a *= p.w_scale[row_of(n, r)];
+      acc[r] = a;
+    }
+    if (lane == 0) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        const float gt = rnd<T>(acc[0]), up = rnd<T>(acc[R - 1]);
+        ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
+      } else {
+        const float y = acc[0] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+        if (p.out_f32) ((float*)p.Y)[n] = y;
+        else ((T*)p.Y)[n] = fromf<T>(y);
+      }
+    }
+  };
+  for (int u = u0; u < o1; u += 12) {
+    finish(wa, u);
+    if (u + 12 < o1) load_w(wa, u + 12);
+    if (u + 4 < o1) {
+      finish(wb, u + 4);
+      if (u + 16 < o1) load_w(wb, u + 16);
+    }
+    if (u + 8 < o1) {
+      finish(wc, u + 8);
+      if (u + 20 < o1) load_w(wc, u + 20);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Whole-row GEMV for LONG K without split-K (round 3; batch 1: down_proj, K = 18944): y[n] = resid[n] + T(sum_k W[n][k] x[k]), in place.
 // The split-K form leaves fp32 slices that a residual + RMSNorm launch must sum; here a workgroup stages x (37 KB) in LDS once, every
 // wave streams whole rows in passes of 8 chunks of 512 (weights of pass p + 1 in flight under the dot products of pass p) and lane 0
@@ -853,9 +974,22 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
   return 0;
 }
 
+int g_gemv_norm_loop = 1;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
+
 template <typename T, int EPI, int RR, bool F8, int NCH>
 void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  if constexpr (NCH >= 4) {        // the decoder's hidden sizes only (K > 1536): keeps the instantiation count down
+    // measured (profiles/r03_p): gate|up 44.3 -> 42.8 us (2.778 -> 2.738 ms per token); qkv 9.2 us either way; e4m3 gate|up 0.6 % slower
+    const bool want = EPI == EPI_SWIGLU ? (g_gemv_norm_loop & (F8 ? 4 : 1)) : (p.N < 32768 ? (g_gemv_norm_loop & 2) : (g_gemv_norm_loop & 8));
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    if (want && n_out >= 8 * n_cu) {
+      const int per = cdiv(n_out, 2 * n_cu);
+      hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, RR, NCH, F8>), dim3(cdiv(cdiv(n_out, RR), 4)), dim3(256), 0, s, p);
 }
 template <typename T, int EPI, int RR, bool F8>
@@ -1028,6 +1162,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
+void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
 
 namespace {
 // one wave per row: absmax, then e4m3 (round to nearest even) of w / scale, 8 weights per lane per step

@@ -18,6 +18,7 @@ from omchat_amd.config import omchat8b_21, omchat13b, tiny
 from omchat_amd.engine import Engine
 from omchat_amd.image_processing import HipImageProcessor
 
+DEFAULT_KEY16 = 1      # gemv.hip: g_gemv_norm_loop
 DTS = ["bf16", "f16"]
 CONSIST_TOL = {"bf16": 6e-2, "f16": 1e-2}
 
@@ -355,6 +356,29 @@ def test_gemv_with_the_norm_in_registers(gpu_lib, dt, N, K, epi):
     with pytest.raises(ValueError):           # K > 4096 does not fit a wave's registers: refused, never silently un-normalised
         big = torch.zeros(8192, dtype=DT[dt], device="cuda"); bw = torch.zeros(32, 8192, dtype=DT[dt], device="cuda")
         _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(big), ptr(bw), 8192, ptr(out), 32, 8192, ptr(big), eps, None, _lib.EPI_NONE, 0, None))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,K,epi", [(37888, 3584, "swiglu"), (4608, 3584, "none"), (8192 + 64, 2048, "swiglu"), (5000, 4096, "none"), (4100, 3000 + 8, "none")])
+def test_gemv_norm_loop_form_is_bit_identical(gpu_lib, dt, N, K, epi):
+    """gemv_rows_norm_loop_kernel (tuning key 16: one resident round of workgroups, each wave walking its outputs through a three-buffer
+    register ring) against the one-shot form: the same bits; ragged K (not a multiple of 512), output counts that do not divide by the grid"""
+    x = rnd(randn((K,), 1), dt); w = rnd(randn((N, K), 2, 0.05), dt); nw = rnd(randn((K,), 3, 0.1) + 1.0, dt); bias = rnd(randn((N,), 4), dt)
+    code = _lib.EPI_SWIGLU if epi == "swiglu" else _lib.EPI_NONE
+    dx, dw, dn, db = dev(x, dt), dev(w, dt), dev(nw, dt), dev(bias, dt)
+    n_y = N // 2 if epi == "swiglu" else N
+    outs = []
+    try:
+        for key in (0, 15):
+            gpu_lib.omchat_op_set_tuning(16, key)
+            out = torch.full((n_y,), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(dx), ptr(dw), K, ptr(out), N, K, ptr(dn), 1e-6, None if epi == "swiglu" else ptr(db), code, 0, None))
+            sync()
+            outs.append(out)
+    finally:
+        gpu_lib.omchat_op_set_tuning(16, DEFAULT_KEY16)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("dt", DTS)
