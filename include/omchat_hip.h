@@ -188,7 +188,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 14: batch-1 decode, bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final RMSNorm inside the
  * qkv / lm_head GEMV with down_proj un-split (default 3; 0 = both residual + RMSNorm launches stay);
  * key 16: which of those norm-in-GEMV launches take the loop form (one resident round of workgroups, three register buffers per wave):
- * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 1; every form gives the same bits)) */
+ * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 1; every form gives the same bits);
+ * key 17: 1 (default) = batch-1 o_proj / qkv launches whose rows deal evenly to two workgroups per CU use N / (2 CUs) waves per workgroup) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

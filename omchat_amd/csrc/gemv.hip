@@ -652,15 +652,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
 // weights were then half as many bytes through the CU as the weights).  All waves use the same sum (fixed order): the same bits.
 // It removes the residual + RMSNorm launch in front of the gate|up GEMV of a batch-1 decode step (o_proj then writes x + attn itself).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, int RR, int NCH, bool F8>
-__global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
+template <typename T, int EPI, int RR, int NCH, bool F8, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   typedef typename V8<T>::type v8;
   constexpr int R = EPI == EPI_SWIGLU ? 2 * RR : RR;
   __shared__ __attribute__((aligned(16))) T xs[NCH * 512];
-  __shared__ float red[4];
+  __shared__ float red[WAVES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
-  const int g = blockIdx.x * 4 + wave;
+  const int g = blockIdx.x * WAVES + wave;
   // ---- 1. this wave's weight rows: every load issued now
   int rows[R];
 #pragma unroll
@@ -687,11 +687,11 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
   // ---- 2. the norm, shared by the workgroup: wave w owns chunks w, w + 4 (x and the norm weights are read ONCE per workgroup: 2 x 7 KB
   // instead of 7 KB of xn per wave), partial sums of squares meet in LDS, the normalised row goes to LDS, every wave reads it back.
   // The plain loads above stay in flight across the two barriers.
-  constexpr int MC = (NCH + 3) / 4;
+  constexpr int MC = (NCH + WAVES - 1) / WAVES;
   rw_u32x4 xq[MC], nq[MC];
 #pragma unroll
   for (int i = 0; i < MC; ++i) {
-    const int c = wave + 4 * i, k = c * 512 + lane * 8;
+    const int c = wave + WAVES * i, k = c * 512 + lane * 8;
     const rw_u32x4 z = {0u, 0u, 0u, 0u};
     const bool ok = c < NCH && k < p.K;
     xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
@@ -710,10 +710,13 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_kernel(GemvP p) {
   if (lane == 0) red[wave] = ss;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  const float inv = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)p.K + p.norm_eps);      // fixed order: the same bits in every wave
+  float tot = red[0];                           // fixed order: the same bits in every wave
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) tot += red[w];
+  const float inv = rsqrtf(tot / (float)p.K + p.norm_eps);
 #pragma unroll
   for (int i = 0; i < MC; ++i) {
-    const int c = wave + 4 * i;
+    const int c = wave + WAVES * i;
     if (c < NCH) {
       const v8 xv = __builtin_bit_cast(v8, xq[i]), wv = __builtin_bit_cast(v8, nq[i]);
       v8 o;
@@ -974,6 +977,7 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
   return 0;
 }
 
+int g_gemv_rows_balance = 1;   // omchat_op_set_tuning key 17: 1 = one-row-per-wave launches whose rows deal evenly to 2 workgroups per CU take N / (2 CUs) waves per workgroup (o_proj 7, qkv 9)
 int g_gemv_norm_loop = 1;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
 
 template <typename T, int EPI, int RR, bool F8, int NCH>
@@ -987,6 +991,16 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
       hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per);
+      return;
+    }
+  }
+  if constexpr (NCH >= 4 && EPI == EPI_NONE && RR <= 2) {
+    // qkv of a batch-1 step: 4608 rows = 9 x 512: one row per wave, nine waves per workgroup, 2 workgroups per CU (every CU streams 18 rows)
+    // instead of 576 workgroups of 8 rows on 4 waves (2.25 per CU)
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    if (g_gemv_rows_balance && n_out == 9 * 2 * n_cu) {
+      hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, 1, NCH, F8, 9>), dim3(2 * n_cu), dim3(576), 0, s, p);
       return;
     }
   }
@@ -1009,6 +1023,16 @@ void launch_rows_norm(const GemvP& p, hipStream_t s) {
 template <typename T, int EPI, int RR, bool F8>
 void launch_rows_r(const GemvP& p, hipStream_t s) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  if constexpr (RR == 1 && EPI == EPI_RESID) {
+    // o_proj of a batch-1 step: 3584 rows as 896 four-wave workgroups are 3.5 per CU (one CU in two streams a fourth workgroup); as
+    // 512 seven-wave workgroups every CU streams the same 14 rows (profiles/r03_r)
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    if (g_gemv_rows_balance && p.ksplit == 1 && n_out == 7 * 2 * n_cu) {
+      hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, 1, 7, F8>), dim3(2 * n_cu, 1), dim3(448), 0, s, p);
+      return;
+    }
+  }
   int grid = cdiv(cdiv(n_out, RR), 4);
   grid = grid > 2048 ? 2048 : grid;
   hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
@@ -1163,6 +1187,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
+void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }
 
 namespace {
 // one wave per row: absmax, then e4m3 (round to nearest even) of w / scale, 8 weights per lane per step

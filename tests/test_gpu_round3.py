@@ -382,6 +382,37 @@ def test_gemv_norm_loop_form_is_bit_identical(gpu_lib, dt, N, K, epi):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_gemv_balanced_workgroups_for_o_proj_and_qkv(gpu_lib, dt):
+    """tuning key 17 (default 1): rows that deal evenly to two workgroups per CU take N / (2 CUs) waves per workgroup -- o_proj (3584 rows,
+    residual epilogue: 7 waves, the same bits as the four-wave launch) and qkv with the norm in registers (4608 rows: 9 waves, the sum of
+    squares meets in a different order: fp32 rounding of one sum); both against fp32 torch"""
+    K = 3584
+    x = rnd(randn((K,), 1), dt); nw = rnd(randn((K,), 3, 0.1) + 1.0, dt)
+    wo = rnd(randn((3584, K), 2, 0.05), dt); r = rnd(randn((3584,), 5), dt)
+    wq = rnd(randn((4608, K), 6, 0.05), dt); bq = rnd(randn((4608,), 7), dt)
+    ref_o = r + rnd(wo @ x, dt)
+    xn = rnd(nw * rnd(x * torch.rsqrt((x * x).mean() + 1e-6), dt), dt)
+    ref_q = wq @ xn + bq
+    dx, dn, dwo, dr, dwq, dbq = dev(x, dt), dev(nw, dt), dev(wo, dt), dev(r, dt), dev(wq, dt), dev(bq, dt)
+    got = {}
+    try:
+        for key in (0, 1):
+            gpu_lib.omchat_op_set_tuning(17, key)
+            yo = torch.full((3584,), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dx), K, ptr(dwo), K, ptr(yo), 3584, 1, 3584, K, None, ptr(dr), 3584, _lib.EPI_RESID, 0, None))
+            yq = torch.full((4608,), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(dx), ptr(dwq), K, ptr(yq), 4608, K, ptr(dn), 1e-6, ptr(dbq), _lib.EPI_NONE, 0, None))
+            sync()
+            got[key] = (yo, yq)
+    finally:
+        gpu_lib.omchat_op_set_tuning(17, 1)
+    for key in (0, 1):
+        assert rel(got[key][0], ref_o) < TOL[dt] and rel(got[key][1], ref_q) < TOL[dt]
+    assert torch.equal(got[0][0], got[1][0])
+    assert rel(got[0][1], got[1][1].float().cpu()) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("fp8", [False, True])
 def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8):
     """the seven-launch layer (key 14 = 1, default) against the eight-launch layer (key 14 = 0) and the oracle: same model, 5 decode steps;
