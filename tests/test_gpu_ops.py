@@ -306,7 +306,11 @@ def test_mha_fwd_packed_qkv(gpu_lib, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("b,Hq,Hkv,cap,lens", [(1, 7, 1, 64, [1]), (1, 28, 4, 800, [700]), (3, 4, 2, 256, [63, 64, 65]), (2, 7, 1, 4096, [3585, 17])])
+@pytest.mark.parametrize("b,Hq,Hkv,cap,lens", [(1, 7, 1, 64, [1]), (1, 28, 4, 800, [700]), (3, 4, 2, 256, [63, 64, 65]), (2, 7, 1, 4096, [3585, 17]),
+                                                  (1, 28, 4, 8832, [8801]),            # 138 splits: the merge's 65..256-split path (configs[3] context)
+                                                  (2, 7, 1, 16384, [16384, 4161]),     # 256 splits exactly, and 66 in the same launch
+                                                  (1, 7, 1, 33280, [33280]),           # 520 splits (configs[4] context): the 1024-thread form, two batches
+                                                  (2, 4, 2, 66000, [65537, 300])])     # 1025 splits: the general path; 5 in the same launch
 def test_attn_decode(gpu_lib, dt, b, Hq, Hkv, cap, lens):
     q = rnd(randn((b, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3), dt)
     for i, n in enumerate(lens):                      # poison the unused tail: must never leak
