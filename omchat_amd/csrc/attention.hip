@@ -1182,6 +1182,8 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
 
 int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
 void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
+int g_merge_mid_min = 64;   // omchat_op_set_tuning key 19: split-KV merges with more partials per head than this take the 512-thread form
+void attn_set_merge_mid_min(int v) { g_merge_mid_min = v < 1 ? 1 : v; }
 int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
 void attn_set_klds(int v) { g_attn_klds = v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
@@ -1268,7 +1270,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
-    if (nsplit > 64 && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    if (nsplit > g_merge_mid_min && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
     else if (nsplit > 256 && nsplit <= 1024) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
     else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else if (dtype == OMCHAT_BF16) {
@@ -1276,7 +1278,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
-    if (nsplit > 64 && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    if (nsplit > g_merge_mid_min && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
     else if (nsplit > 256 && nsplit <= 1024) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
     else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
