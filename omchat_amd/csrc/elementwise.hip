@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* logits,
     pi[blockIdx.y * ARG_CHUNKS + blockIdx.x] = besti;
   }
 }
-__global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* pv, const int* pi, int* out) {
+__global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* pv, const int* pi, int* out, int* adv_pos, int* adv_len) {
+  if (adv_pos && threadIdx.x == 0) { adv_pos[blockIdx.x] += 1; adv_len[blockIdx.x] += 1; }
   float best = pv[blockIdx.x * ARG_CHUNKS + threadIdx.x];
   int besti = pi[blockIdx.x * ARG_CHUNKS + threadIdx.x];
 #pragma unroll
@@ -603,13 +604,13 @@ int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int6
 
 size_t argmax_scratch_bytes(int b) { return (size_t)b * ARG_CHUNKS * 8; }
 
-int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scratch, hipStream_t s) {
+int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scratch, hipStream_t s, int* adv_pos, int* adv_len) {
   if (b == 0) return 0;
   OM_CHECK(scratch, "argmax scratch missing");
   float* pv = (float*)scratch;
   int* pi = (int*)((char*)scratch + (size_t)b * ARG_CHUNKS * 4);
   hipLaunchKernelGGL(argmax_stage1_kernel, dim3(ARG_CHUNKS, b), dim3(256), 0, s, logits, ld, V, pv, pi);
-  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(b), dim3(64), 0, s, pv, pi, out);
+  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(b), dim3(64), 0, s, pv, pi, out, adv_pos, adv_len ? adv_len : adv_pos);
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -176,7 +176,8 @@ int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int6
                      int group, int skip, hipStream_t s);   // src row = (r / group) * (group + skip) + skip + r % group
 // argmax over fp32 logits [b, V] -> int32 [b] (first index wins ties)
 size_t argmax_scratch_bytes(int b);
-int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scratch, hipStream_t s);   // scratch: argmax_scratch_bytes(b)
+// adv_pos / adv_len (optional, device [b]): incremented by one in the second stage -- the decode step's position bookkeeping without a launch of its own
+int launch_argmax(const float* logits, int ld, int b, int V, int* out, void* scratch, hipStream_t s, int* adv_pos = nullptr, int* adv_len = nullptr);   // scratch: argmax_scratch_bytes(b)
 // deterministic synthetic fill (bit-identical to omchat_amd/synth.py::uniform)
 int launch_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, hipStream_t s);
 int launch_cast_f32(int dtype, const void* src, float* dst, int64_t n, hipStream_t s);

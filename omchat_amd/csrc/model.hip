@@ -854,9 +854,9 @@ extern "C" int omchat_enable_fp8_prefill(omchat_ctx* ctx, int on) {
 }
 
 // greedy argmax over (rank-local) logits; under tensor parallelism the (max, index) pairs are exchanged
-static int greedy_pick(omchat_ctx* ctx, const float* lg, int b, int32_t* next_tokens, hipStream_t s) {
+static int greedy_pick(omchat_ctx* ctx, const float* lg, int b, int32_t* next_tokens, hipStream_t s, bool advance = false) {
   const omchat_config& c = ctx->c;
-  TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, ctx->arg_scratch, s));
+  TRY(launch_argmax(lg, c.t_vocab, b, c.t_vocab, next_tokens, ctx->arg_scratch, s, advance ? ctx->d_pos : nullptr, advance ? ctx->d_len : nullptr));
   if (ctx->tp_size > 1) {
     const size_t n = (size_t)ctx->tp_size * b * 2;
     OM_HIP(hipMemsetAsync(ctx->tp_table, 0, n * 4, s));
@@ -1193,8 +1193,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   } else {
     TRY(lm_head_rows(ctx, ctx->tw_xn, b, lg, s, f8, fused && pk));
   }
-  if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s));
-  hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
+  // the position bookkeeping (pos += 1, len += 1) rides in the argmax's second stage when the step picks a token (one launch less per token)
+  if (next_tokens) TRY(greedy_pick(ctx, lg, b, next_tokens, s, true));
+  else hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, s, ctx->d_pos, ctx->d_len, b);
   OM_LAUNCH_CHECK();
   return 0;
 }
