@@ -139,4 +139,15 @@ void omchat_set_error(const std::string& s);
 #define OM_LAUNCH_CHECK() OM_HIP(hipGetLastError())
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// compute units of the current device (one process drives one GPU: looked up once; 256 if the query fails)
+static inline int device_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -956,8 +956,7 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
 
 template <typename T>
 int launch_rows_longk(const GemvP& p, hipStream_t s) {
-  static int n_cu = 0;
-  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+  const int n_cu = device_cus();
   int rpw = cdiv(p.N, 2 * n_cu);                // two workgroups per CU
   rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);
   const int grid = cdiv(p.N, rpw);
@@ -986,8 +985,7 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
   if constexpr (NCH >= 4) {        // the decoder's hidden sizes only (K > 1536): keeps the instantiation count down
     // measured (profiles/r03_p): gate|up 44.3 -> 42.8 us (2.778 -> 2.738 ms per token); qkv 9.2 us either way; e4m3 gate|up 0.6 % slower
     const bool want = EPI == EPI_SWIGLU ? (g_gemv_norm_loop & (F8 ? 4 : 1)) : (p.N < 32768 ? (g_gemv_norm_loop & 2) : (g_gemv_norm_loop & 8));
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = device_cus();
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
       hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per);
@@ -997,8 +995,7 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
   if constexpr (NCH >= 4 && EPI == EPI_NONE && RR <= 2) {
     // qkv of a batch-1 step: 4608 rows = 9 x 512: one row per wave, nine waves per workgroup, 2 workgroups per CU (every CU streams 18 rows)
     // instead of 576 workgroups of 8 rows on 4 waves (2.25 per CU)
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = device_cus();
     if (g_gemv_rows_balance && n_out == 9 * 2 * n_cu) {
       hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, 1, NCH, F8, 9>), dim3(2 * n_cu), dim3(576), 0, s, p);
       return;
@@ -1026,8 +1023,7 @@ void launch_rows_r(const GemvP& p, hipStream_t s) {
   if constexpr (RR == 1 && EPI == EPI_RESID) {
     // o_proj of a batch-1 step: 3584 rows as 896 four-wave workgroups are 3.5 per CU (one CU in two streams a fourth workgroup); as
     // 512 seven-wave workgroups every CU streams the same 14 rows (profiles/r03_r)
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = device_cus();
     if (g_gemv_rows_balance && p.ksplit == 1 && n_out == 7 * 2 * n_cu) {
       hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, 1, 7, F8>), dim3(2 * n_cu, 1), dim3(448), 0, s, p);
       return;
@@ -1085,8 +1081,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
            else hipLaunchKernelGGL((gemv_pk_kernel<T, NT_, EPI_, WV_, UN_, 1, false>), grid, dim3(WV_ * 64), 0, s, p); }                     \
   } while (0)
     // long launches with K = 64 * 8 * 7 (= 3584: gate|up, lm_head): x-stationary persistent form, one workgroup per CU, >= 4 units each
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = device_cus();
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
         ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu))) {
@@ -1109,8 +1104,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       // q = 5 * a5 + 2 * a2 with a5 + a2 == ks
       int a5 = -1;
       for (int t = 0; t <= ks; ++t) if (5 * t + 2 * (ks - t) == q) a5 = t;
-      static int n_cu2 = 0;
-      if (!n_cu2) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu2 <= 0) n_cu2 = 256; }
+      const int n_cu2 = device_cus();
       int gx = std::max(1, n_cu2 / ks);
       const int tiles = a.N / 16;
       // short launches (o_proj: 224 tiles x 2 slices): two tiles per workgroup instead of >= 4 units on every CU (as for qkv)

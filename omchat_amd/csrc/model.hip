@@ -548,8 +548,7 @@ static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W
   // 3 x 34 us for a projection that takes ~40 us in one launch).  The all-reduce of such a message is then exposed, but it is shorter
   // than the lost GEMM time.  (Tests lower g_ar_min_rows below one tile to force chunking on tiny shapes: the rule is skipped there.)
   if (g_ar_min_rows >= 256) {
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = device_cus();
     const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
     while (nch > 1 && tiles / nch < n_cu) nch >>= 1;
   }
