@@ -411,3 +411,21 @@ def test_bench_parent_never_touches_hip_and_algorithmic_constants():
     per_layer = 2 * 1025 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 4 * 1025 ** 2 * 1024
     assert abs(b["vit_tile"] - (24 * per_layer + 2 * 1024 * 588 * 1024 + 2 * 1024 * (1024 * 3584 + 3584 ** 2))) < 1.0
     assert b["decode_weight_bytes"] == a["decode_weight_bytes"]             # same Qwen2-7B decoder
+
+
+def test_tp_projection_tool_reproduces_the_committed_curve():
+    """tools/tp_projection.py on the committed shard lines: pure arithmetic on measured one-GPU inputs -- the table in
+    DESIGN.md must be what the tool prints for the committed files (speed-ups of the closing code: configs1 2.04 x, configs2 2.85 x / 3.53 x
+    with the data-parallel tower at N = 8)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "profiles", f"r03_y_bench_{n}.json") for n in ("n1", "shard2", "shard4", "shard8")]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tp_projection.py")] + files, capture_output=True, text=True, check=True).stdout
+    committed = open(os.path.join(root, "profiles", "r03_y_tp_projection.txt")).read()
+    assert out.strip() == committed.strip()
+    rows = {(l.split()[0], int(l.split()[1])): l for l in out.splitlines() if l.startswith("configs")}
+    c1, c2 = rows[("configs1", 8)], rows[("configs2", 8)]
+    assert abs(float(c1.split("|")[2].split()[1]) - 2.04) < 0.01
+    assert abs(float(c2.split("|")[2].split()[1]) - 2.85) < 0.01 and "3.53" in c2
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    assert "| 1 | 1.18 | 1.61 | **2.04** | 2.08 |" in design and "| 1 | 1.17 | 1.93 | **2.85** | **3.53** |" in design
