@@ -191,7 +191,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 1; every form gives the same bits);
  * key 17: 1 (default) = batch-1 o_proj / qkv launches whose rows deal evenly to two workgroups per CU use N / (2 CUs) waves per workgroup;
  * key 19: split-KV merges with more partials per head than this take the 512-thread form (default 64: at 57 partials the 128-thread
- * one-batch form is faster, 4.9 vs 5.9 us)) */
+ * one-batch form is faster, 4.9 vs 5.9 us);
+ * key 21: column groups per head in the split-KV merge: 1 (default) = four workgroups per head beyond 256 partials (33 k keys: 21 -> ~7 us
+ * per launch), 2 = also two workgroups per head for 65..256 partials (neutral), 0 = one workgroup per head) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -1088,20 +1088,22 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
 // thread + one (max, sum) pair; two batches beyond 64 NG splits): one or two memory round trips like the <= 64 path above, where the
 // general path needs ~ns / 8 + 2 dependent ones (8.8 k keys, BASELINE configs[3]: 8.4 -> 6.7 us per launch, 2.94 -> 2.88 ms per token).
 // Fixed summation order: inside a group by split, then the groups left to right.
-template <typename T, int NG>
+template <typename T, int NG, int DG>
 __global__ __launch_bounds__(128 * NG) void attn_merge_mid_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
                                                                   T* O, int64_t o_sb, int64_t o_sh, int pack_nb, int split_keys) {
-  constexpr int NWV = 2 * NG;                        // waves
+  // DG > 1: blockIdx.z takes 128 / DG of the head's columns and the 128 NG threads form NG DG split groups instead of NG -- DG times the
+  // workgroups for the launches whose bytes matter (33 k keys, configs[4]: 520 partials per head = 7.6 MB read by 28 workgroups took 21 us)
+  constexpr int NWV = 2 * NG, COLS = 128 / DG, NGRP = NG * DG;
   __shared__ float fw[128 * NG];
   __shared__ float red[2 * NWV];
-  __shared__ float part[NG][128];
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, d = tid & 127, g = tid >> 7;
+  __shared__ float part[NGRP][COLS];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, dl = tid % COLS, d = blockIdx.z * COLS + dl, g = tid / COLS;
   const int len = kv_len ? kv_len[b] : L;
   int ns = (len + split_keys - 1) / split_keys;
   ns = ns < nsplit ? ns : nsplit;
   ns = ns < 128 * NG ? ns : 128 * NG;                // (the launcher only comes here when nsplit <= 128 NG)
   const float* w = ws + (size_t)(b * q_heads + h) * nsplit * WS_STRIDE;
-  const int q = (ns + NG - 1) / NG, s_lo = g * q;    // this thread's splits: s_lo .. min(s_lo + q, ns) - 1, q <= 128
+  const int q = (ns + NGRP - 1) / NGRP, s_lo = g * q;     // this thread's splits: s_lo .. min(s_lo + q, ns) - 1, q <= 128
   float v[64];
 #pragma unroll
   for (int i = 0; i < 64; ++i) v[i] = w[(size_t)(i < q && s_lo + i < ns ? s_lo + i : 0) * WS_STRIDE + d];
@@ -1127,14 +1129,14 @@ __global__ __launch_bounds__(128 * NG) void attn_merge_mid_kernel(const float* w
 #pragma unroll
     for (int i = 0; i < 64; ++i) a += (64 + i < q && s_lo + 64 + i < ns ? fw[s_lo + 64 + i] : 0.f) * v[i];
   }
-  part[g][d] = a;
+  part[g][dl] = a;
   __syncthreads();
   if (g == 0) {
-    float ltot = red[NWV], tot = part[0][d];
+    float ltot = red[NWV], tot = part[0][dl];
 #pragma unroll
     for (int i = 1; i < NWV; ++i) ltot += red[NWV + i];
 #pragma unroll
-    for (int i = 1; i < NG; ++i) tot += part[i][d];
+    for (int i = 1; i < NGRP; ++i) tot += part[i][dl];
     O[pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d)] = fromf<T>(tot / ltot);
   }
 }
@@ -1182,6 +1184,8 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
 
 int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
 void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
+int g_merge_dg = 1;       // omchat_op_set_tuning key 21: split-KV merge, column groups per head: 0 = none, 1 = 4 groups beyond 256 partials (default), 2 = also 2 groups for 65..256
+void attn_set_merge_dg(int v) { g_merge_dg = v; }
 int g_merge_mid_min = 64;   // omchat_op_set_tuning key 19: split-KV merges with more partials per head than this take the 512-thread form
 void attn_set_merge_mid_min(int v) { g_merge_mid_min = v < 1 ? 1 : v; }
 int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
@@ -1270,16 +1274,26 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
-    if (nsplit > g_merge_mid_min && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-    else if (nsplit > 256 && nsplit <= 1024) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    if (nsplit > g_merge_mid_min && nsplit <= 256) {
+      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    } else if (nsplit > 256 && nsplit <= 1024) {
+      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    }
     else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else if (dtype == OMCHAT_BF16) {
     if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
-    if (nsplit > g_merge_mid_min && nsplit <= 256) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-    else if (nsplit > 256 && nsplit <= 1024) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    if (nsplit > g_merge_mid_min && nsplit <= 256) {
+      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    } else if (nsplit > 256 && nsplit <= 1024) {
+      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    }
     else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();

@@ -26,6 +26,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 16) { gemv_set_norm_loop(value); return 0; }
   if (key == 17) { gemv_set_rows_balance(value); return 0; }
   if (key == 19) { attn_set_merge_mid_min(value); return 0; }
+  if (key == 21) { attn_set_merge_dg(value); return 0; }
   if (key == 13) { gemm_set_persist(value); return 0; }
   if (key == 14) { model_set_norm_in_gemv(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");

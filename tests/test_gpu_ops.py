@@ -324,8 +324,14 @@ def test_attn_decode(gpu_lib, dt, b, Hq, Hkv, cap, lens):
     scale = 128 ** -0.5
     kk = torch.nan_to_num(k); vv = torch.nan_to_num(v)
     ref = _attn_ref(q[:, None], kk, vv, scale, 0, 0, lens)[:, 0]
+    done_auto = 0
     try:
-        for tpw in (0, 1, 2, 4):                      # key tiles per wave: automatic, then each forced split size (running max / sum inside a wave)
+        for tpw in (0, 1, 2, 4, 0, 0):                # key tiles per wave: automatic, then each forced split size (running max / sum inside a wave);
+            # the last two passes: the split-KV merge with 2 column groups below 256 partials / without column groups (tuning key 21)
+            gpu_lib.omchat_op_set_tuning(21, 1)
+            if tpw == 0 and done_auto:
+                gpu_lib.omchat_op_set_tuning(21, 2 if done_auto == 1 else 0)
+            done_auto += tpw == 0
             gpu_lib.omchat_op_set_tuning(10, tpw)
             out.fill_(float("nan")); ws.fill_(float("nan"))
             _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), scale, ptr(ws), wsb, None))
@@ -334,6 +340,7 @@ def test_attn_decode(gpu_lib, dt, b, Hq, Hkv, cap, lens):
             assert rel(out, ref) < TOL[dt], (tpw, rel(out, ref))
     finally:
         gpu_lib.omchat_op_set_tuning(10, 0)
+        gpu_lib.omchat_op_set_tuning(21, 1)
 
 
 @pytest.mark.parametrize("dt", DTS)
