@@ -251,6 +251,11 @@ int omchat_op_attn_decode(int dtype, const void* q, const void* k, const void* v
 /* qkv [rows, (Hq+2Hkv)*128]; rows = b*S; positions pos0 + s; caches [b,Hkv,cap,128]; theta: rope base */
 int omchat_op_rope_kv(int dtype, void* qkv, int b, int S, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache,
                       int cap, void* stream);
+/* the same with the appended rows ALSO quantised into an e4m3 KV cache (k8 / v8 [b, Hkv, cap, 128] bytes, ks / vs [b, Hkv, cap] fp32: per row
+ * s = absmax / 448 (1 for a zero row), bytes = e4m3_rne(x / s) of the 16-bit values stored in kcache / vcache) -- the decode step of the fp8
+ * KV cache mode (BASELINE configs[4]) */
+int omchat_op_rope_kv_q8(int dtype, void* qkv, int b, int S, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
+                         void* k8, void* v8, float* ks, float* vs, void* stream);
 int omchat_op_argmax(const float* logits, int b, int V, int32_t* out, void* stream);
 int omchat_op_fill_uniform(int dtype, void* dst, int64_t n, uint64_t key, float scale, float offset, void* stream);
 

@@ -137,8 +137,21 @@ extern "C" int omchat_op_attn_decode(int dtype, const void* q, const void* k, co
   return launch_attn_decode(dtype, a, S(stream));
 }
 
+static int op_rope_kv_impl(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
+                           void* k8, void* v8, float* ks, float* vs, void* stream);
 extern "C" int omchat_op_rope_kv(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
                                  void* stream) {
+  return op_rope_kv_impl(dtype, qkv, b, Sq, Hq, Hkv, pos0, theta, kcache, vcache, cap, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// the same with the appended rows also quantised to the e4m3 cache (k8 / v8 [b, Hkv, cap, 128] bytes, ks / vs [b, Hkv, cap] fp32 scales):
+// what a decode step with the fp8 KV cache launches (round 3; before: RoPE + append, then a quantiser launch over the new rows)
+extern "C" int omchat_op_rope_kv_q8(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
+                                    void* k8, void* v8, float* ks, float* vs, void* stream) {
+  OM_CHECK(k8 && v8 && ks && vs, "null fp8 cache argument");
+  return op_rope_kv_impl(dtype, qkv, b, Sq, Hq, Hkv, pos0, theta, kcache, vcache, cap, k8, v8, ks, vs, stream);
+}
+static int op_rope_kv_impl(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
+                           void* k8, void* v8, float* ks, float* vs, void* stream) {
   OM_CHECK(pos0 + Sq <= cap, "positions exceed cache capacity");
   const int max_pos = pos0 + Sq;
   std::vector<float> tab((size_t)max_pos * 128);
@@ -154,6 +167,7 @@ extern "C" int omchat_op_rope_kv(int dtype, void* qkv, int b, int Sq, int Hq, in
   OM_HIP(hipMalloc(&d, tab.size() * 4));
   OM_HIP(hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   RopeArgs r{qkv, (Hq + 2 * Hkv) * 128, b * Sq, Sq, Hq, Hkv, nullptr, pos0, d, max_pos, kcache, vcache, (int64_t)Hkv * cap * 128, (int64_t)cap * 128};
+  r.k8 = k8; r.v8 = v8; r.ks = ks; r.vs = vs; r.s_sb = (int64_t)Hkv * cap; r.s_sh = cap;
   int rc = launch_rope_kv(dtype, r, S(stream));
   hipStreamSynchronize(S(stream));
   hipFree(d);

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, int S, int nq, int nkv, const int* pos, int pos0,
-                                                      const float* cos_sin, int max_pos, T* kc, T* vc, int64_t c_sb, int64_t c_sh) {
+                                                      const float* cos_sin, int max_pos, T* kc, T* vc, int64_t c_sb, int64_t c_sh,
+                                                      unsigned char* kq8, unsigned char* vq8, float* ks, float* vs, int64_t s_sb, int64_t s_sh) {
   typedef typename V8<T>::type v8;
   const int nh = nq + 2 * nkv;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -328,9 +329,31 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, 
   const int bi = row / S;
   int pp = pos ? pos[row] : pos0 + (row % S);
   T* src = qkv + (size_t)row * ld + h * 128;
+  // fp8 KV cache: the 16-lane group holds the whole 128-element row: s = absmax / 448 (1 for a zero row), bytes = e4m3_rne(x / s) --
+  // attention.hip: kv_quant_kernel's arithmetic on the 16-bit values just stored, so the same bytes
+  auto quant_row = [&](const v8& r, unsigned char* dst8, float* sc_out) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(tof(r[j])));
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float sc = m > 0.f ? m / 448.0f : 1.0f;
+    typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+    u32x2q w;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(tof(r[4 * k]) / sc, tof(r[4 * k + 1]) / sc, 0, false);
+      const int hi = __builtin_amdgcn_cvt_pk_fp8_f32(tof(r[4 * k + 2]) / sc, tof(r[4 * k + 3]) / sc, 0, false);
+      w[k] = (unsigned)(lo & 0xFFFF) | ((unsigned)(hi & 0xFFFF) << 16);
+    }
+    *reinterpret_cast<u32x2q*>(dst8 + c * 8) = w;
+    if (c == 0) *sc_out = sc;
+  };
   if (h >= nq + nkv) {                              // v: plain copy into the cache
     const int kvh = h - nq - nkv;
-    st8<T>(vc + bi * c_sb + kvh * c_sh + (int64_t)pp * 128 + c * 8, ld8<T>(src + c * 8));
+    const v8 vv = ld8<T>(src + c * 8);
+    st8<T>(vc + bi * c_sb + kvh * c_sh + (int64_t)pp * 128 + c * 8, vv);
+    if (vq8) quant_row(vv, vq8 + bi * c_sb + kvh * c_sh + (int64_t)pp * 128, vs + bi * s_sb + kvh * s_sh + pp);
     return;
   }
   const int pt = pp < max_pos ? pp : max_pos - 1;
@@ -352,6 +375,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, 
   } else {
     const int kvh = h - nq;
     st8<T>(kc + bi * c_sb + kvh * c_sh + (int64_t)pp * 128 + c * 8, r);
+    if (kq8) quant_row(r, kq8 + bi * c_sb + kvh * c_sh + (int64_t)pp * 128, ks + bi * s_sb + kvh * s_sh + pp);
   }
 }
 
@@ -557,10 +581,12 @@ int launch_vit_qk_sumsq(int dtype, const void* qkv, int ld, int rows, int C, flo
 
 int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s) {
   OM_CHECK(a.ld % 8 == 0 && a.cos_sin && a.kcache && a.vcache, "bad args");
+  OM_CHECK(!a.k8 || (a.v8 && a.ks && a.vs), "fp8 KV append: k8, v8 and both scale arrays");
   if (a.rows == 0) return 0;
   const long items = (long)a.rows * (a.nq + 2 * a.nkv) * 16;
   DISPATCH(dtype, hipLaunchKernelGGL(rope_kv_kernel<T>, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, s, (T*)a.qkv, a.ld, a.rows, a.S,
-                                     a.nq, a.nkv, a.pos, a.pos0, a.cos_sin, a.max_pos, (T*)a.kcache, (T*)a.vcache, a.c_sb, a.c_sh));
+                                     a.nq, a.nkv, a.pos, a.pos0, a.cos_sin, a.max_pos, (T*)a.kcache, (T*)a.vcache, a.c_sb, a.c_sh,
+                                     (unsigned char*)a.k8, (unsigned char*)a.v8, a.ks, a.vs, a.s_sb, a.s_sh));
   OM_LAUNCH_CHECK();
   return 0;
 }

@@ -162,6 +162,10 @@ struct RopeArgs {
   int max_pos;
   void* kcache; void* vcache;  // [b, nkv, cap, 128]
   int64_t c_sb, c_sh;          // cache strides (elements); row stride 128
+  // optional (fp8 KV cache, decode): the appended k / v rows are ALSO quantised here (what launch_kv_quant would do to them in a launch
+  // of its own): e4m3 bytes into k8 / v8 (same [b, nkv, cap, 128] layout, strides in elements = bytes), one fp32 scale per row into
+  // ks / vs [b][nkv][s_sh]
+  void* k8 = nullptr; void* v8 = nullptr; float* ks = nullptr; float* vs = nullptr; int64_t s_sb = 0, s_sh = 0;
 };
 int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s);
 

@@ -1130,11 +1130,12 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (ctx->fp8_kv && ctx->kv8_valid) {
       // fp8 KV cache: rotate q / k and append to the 16-bit cache with the prefill's kernel, quantise the new row, then attend over e4m3
       // keys and values (two small launches more per layer than the fused 16-bit path; this mode is for long contexts)
-      RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
-      TRY(launch_rope_kv(ctx->dt, r, s));
+      // (round 3: the new row is quantised inside the RoPE + append launch -- one launch less per layer than rope_kv + kv_quant)
       const size_t off = (size_t)i * ctx->cache_layer_stride(), so = (size_t)i * ctx->scale_layer_stride();
-      TRY(launch_kv_quant(ctx->dt, kc, vc, (char*)ctx->k8cache + off, (char*)ctx->v8cache + off, ctx->ks8 + so, ctx->vs8 + so, b, c.t_kv_heads,
-                          ctx->cache_sb(), ctx->cache_sh(), (int64_t)c.t_kv_heads * c.max_seq, c.max_seq, ctx->d_pos, 0, nullptr, 1, s));
+      RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
+      r.k8 = (char*)ctx->k8cache + off; r.v8 = (char*)ctx->v8cache + off; r.ks = ctx->ks8 + so; r.vs = ctx->vs8 + so;
+      r.s_sb = (int64_t)c.t_kv_heads * c.max_seq; r.s_sh = c.max_seq;
+      TRY(launch_rope_kv(ctx->dt, r, s));
       a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
       a.K = (char*)ctx->k8cache + off; a.V = (char*)ctx->v8cache + off;
       a.k_scale = ctx->ks8 + so; a.v_scale = ctx->vs8 + so; a.scale_sb = (int64_t)c.t_kv_heads * c.max_seq; a.scale_sh = c.max_seq;

@@ -271,6 +271,33 @@ def test_fp8_kv_cache_and_fp8_prefill_on_the_tiny_decoder(gpu_lib, dt):
     assert all(torch.isfinite(t).all() for t in both)
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_rope_append_with_the_fp8_rows_quantised_in_the_same_launch(gpu_lib, dt):
+    """decode step of the fp8 KV cache mode: RoPE + append + e4m3 quantisation of the appended rows in ONE launch (round 3).  The 16-bit
+    cache rows equal the plain launch's bit for bit; the e4m3 bytes and scales equal the reference quantiser (absmax / 448, RNE) applied to
+    those 16-bit rows bit for bit; rows that were not appended stay untouched; a zero row gets scale 1"""
+    b, S, Hq, Hkv, cap, pos0 = 3, 1, 4, 2, 40, 17
+    qkv = rnd(randn((b * S, (Hq + 2 * Hkv) * 128), 1, 2.0), dt)
+    qkv[1, (Hq + Hkv) * 128:(Hq + Hkv + 1) * 128] = 0.0            # sequence 1, v head 0: a zero row
+    d0, d1 = dev(qkv, dt), dev(qkv, dt)
+    kc0 = torch.zeros(b, Hkv, cap, 128, dtype=DT[dt], device="cuda"); vc0 = torch.zeros_like(kc0)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    k8 = torch.full((b, Hkv, cap, 128), 0x55, dtype=torch.uint8, device="cuda"); v8 = k8.clone()
+    ks = torch.full((b, Hkv, cap), -7.0, dtype=torch.float32, device="cuda"); vs = ks.clone()
+    _lib.check(gpu_lib.omchat_op_rope_kv(CODE[dt], ptr(d0), b, S, Hq, Hkv, pos0, 1e6, ptr(kc0), ptr(vc0), cap, None))
+    _lib.check(gpu_lib.omchat_op_rope_kv_q8(CODE[dt], ptr(d1), b, S, Hq, Hkv, pos0, 1e6, ptr(kc1), ptr(vc1), cap, ptr(k8), ptr(v8), ptr(ks), ptr(vs), None))
+    sync()
+    assert torch.equal(d0, d1) and torch.equal(kc0, kc1) and torch.equal(vc0, vc1)
+    for c16, c8, sc in ((kc1, k8, ks), (vc1, v8, vs)):
+        rows = c16[:, :, pos0].float().cpu().reshape(-1, 128)
+        q, s_ref = quant_ref(rows)
+        assert torch.equal(c8[:, :, pos0].cpu().reshape(-1, 128), q.view(torch.uint8))
+        assert torch.equal(sc[:, :, pos0].cpu().reshape(-1), s_ref)
+        keep = torch.ones(cap, dtype=torch.bool); keep[pos0] = False
+        assert bool((c8[:, :, keep] == 0x55).all()) and bool((sc[:, :, keep] == -7.0).all())
+    assert float(vs[1, 0, pos0]) == 1.0
+
+
 def test_fp8_kv_decode_one_full_width_layer_16k_context(gpu_lib):
     """BASELINE configs[4] shape on one Qwen2-7B-width layer: 16 k tokens of context, fp8 weights for the decode GEMVs AND the fp8 KV
     cache, against the oracle run on the de-quantised weights and the de-quantised cache (per (head, position) absmax / 448 scales)"""
