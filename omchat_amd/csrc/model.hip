@@ -1135,6 +1135,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
       r.k8 = (char*)ctx->k8cache + off; r.v8 = (char*)ctx->v8cache + off; r.ks = ctx->ks8 + so; r.vs = ctx->vs8 + so;
       r.s_sb = (int64_t)c.t_kv_heads * c.max_seq; r.s_sh = c.max_seq;
+      if (exact_len) { r.pos = nullptr; r.pos0 = Lmax - 1; }      // the position by value: one dependent load less in front of the table read
       TRY(launch_rope_kv(ctx->dt, r, s));
       a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
       a.K = (char*)ctx->k8cache + off; a.V = (char*)ctx->v8cache + off;
