@@ -205,18 +205,42 @@ def cpu_baseline(cfg, S, gen, n_tiles):
             "decode_tokens_per_sec": 1.0 / (t["num_hidden_layers"] * t_dec + t_lm)}
 
 
-def pmc_traffic(substrings, pattern="*pmc_traffic.json"):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_traffic*.json; counters cannot be
-    collected together with the timed run).  Picks the kernel whose mangled name contains all `substrings`."""
+def _profile_key(path):
+    """profiles/rNN_<tag>_... -> (round, len(tag), tag): 'r03_ai' sorts after 'r03_s' (a plain lexicographic sort put it before)."""
+    import re
+    m = re.match(r"r(\d+)_([a-z]+)_", os.path.basename(path))
+    return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, os.path.basename(path))
+
+
+def pmc_traffic(substrings, which="pmc_traffic", profiles_dir=None, quiet=False):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (counters cannot be collected together with the timed run).
+    The file is the one profiles/MANIFEST.json names under `which` ("pmc_traffic" = configs1, "pmc_traffic_configs2"), written by
+    tools/collect_profiles.sh together with the file itself; without a manifest entry: the newest by (round, tag) order.  Picks the
+    kernel whose mangled name contains all `substrings`; when the file holds no such kernel (the kernels were renamed after the
+    counters were taken) the traffic is None and the source says so -- old counters are never attached to new kernels."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
-    if not files:
-        return None, None
-    ks = json.load(open(files[-1]))["kernels"]
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    path = None
+    man = os.path.join(d, "MANIFEST.json")
+    if os.path.exists(man):
+        name = json.load(open(man)).get(which)
+        if name:
+            path = os.path.join(d, name)
+            if not os.path.exists(path):
+                print(f"bench.py: profiles/MANIFEST.json names {name} for {which}, which does not exist", file=sys.stderr)
+                return None, f"profiles/{name}: named by MANIFEST.json but missing"
+    if path is None:
+        files = sorted(glob.glob(os.path.join(d, "r*_" + which + ".json")), key=_profile_key)
+        if not files:
+            return None, None
+        path = files[-1]
+    ks = json.load(open(path))["kernels"]
     for name, v in ks.items():
         if all(x in name for x in substrings):
-            return v["traffic_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
-    return None, None
+            return v["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
+    if not quiet:
+        print(f"bench.py: no kernel matching {substrings} in profiles/{os.path.basename(path)}: PMC traffic not reported", file=sys.stderr)
+    return None, f"profiles/{os.path.basename(path)}: no kernel matching {'+'.join(substrings)}"
 
 
 def algorithmic(cfg):
@@ -539,12 +563,13 @@ def main():
             tr, src = (None, None)
             if plain and not f8:
                 if b == 1:      # the launch that streams gate|up in the default configuration first, then the forms behind tuning keys 16 / 14
-                    for sub in (["gemv_rows_norm_loop_kernelI", "Li4ELi7ELb0E"], ["gemv_rows_norm_kernelI", "Li4ELi3ELi7ELb0E"], ["gemv_rows_kernelI", "Li4ELi4ELi4E"]):
-                        tr, src = pmc_traffic(sub)
+                    subs = (["gemv_rows_norm_loop_kernelI", "Li4ELi7ELb0E"], ["gemv_rows_norm_kernelI", "Li4ELi3ELi7ELb0E"], ["gemv_rows_kernelI", "Li4ELi4ELi4E"])
+                    for i, sub in enumerate(subs):
+                        tr, src = pmc_traffic(sub, quiet=i + 1 < len(subs))
                         if tr is not None:
                             break
                 else:
-                    tr, src = pmc_traffic(["gemv_xs_kernelI", f"Li4ELi{2 if b > 16 else 1}E"], "*pmc_traffic_configs2.json")
+                    tr, src = pmc_traffic(["gemv_xs_kernelI", f"Li4ELi{2 if b > 16 else 1}E"], "pmc_traffic_configs2")
             roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
                     "launches": n, "bytes_per_launch": gu_bytes}
@@ -685,6 +710,35 @@ def main():
                              "hbm_frac": ((al4["decode_weight_bytes"] / 2 + al4["kv_bytes_per_pos"] * S) / (min(t8) / 1e3) / 1e9 / HBM_PEAK_GBS) if full else None,
                              "note": "decoder GEMV weights as OCP e4m3 + per-row fp32 scale (7.07 GB/step instead of 14.14); "
                                      "prefill, KV cache and activations stay 16-bit; NOT part of `value`"}
+    # the drop-in entry (single_inference.py:53-62): model.generate(input_ids, images=...) on the same sample -- tower, splice, prefill and
+    # the greedy loop with the host looking at every token (EOS / streamer), next to the engine-level loop of `value`
+    if world == 1 and not shard and do1 and not do3 and not do4:
+        from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+        model = OmChatQwen2ForCausalLM(cfg.clone(), eng)
+        px, ids = make_inputs(1)
+        model.generate(ids, images=px, max_new_tokens=8, eos_token_id=None)      # warm
+        tg, t1 = [], []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.generate(ids, images=px, max_new_tokens=1, eos_token_id=None)
+            torch.cuda.synchronize(); t1.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            out_ids = model.generate(ids, images=px, max_new_tokens=a.gen, eos_token_id=None)
+            torch.cuda.synchronize(); tg.append(time.perf_counter() - t0)
+        assert out_ids.shape[1] == ids.shape[1] + a.gen
+        whole, first = sorted(tg)[1], sorted(t1)[1]
+        res["generate"] = {"tokens_per_sec": a.gen / whole, "ms_per_call": whole * 1e3, "first_token_ms": first * 1e3,
+                           "decode_tokens_per_sec": (a.gen - 1) / (whole - first) if a.gen > 1 else None,
+                           "vs_engine_loop": (a.gen / whole) / hs["tokens_per_sec"],
+                           "note": "OmChatQwen2ForCausalLM.generate(input_ids, images=...) wall time per call (host-side splice plan, one pinned "
+                                   "token copy + event wait per generated token, step k + 1 enqueued before token k is read); NOT `value`"}
+        res["generate_tokens_per_sec"] = a.gen / whole
+    if world == 1 and not shard:
+        n_f, bits = eng.fused_status()
+        res["fused_decode"] = {"launches": n_f, "timeout_bits": bits,
+                               "note": "attention + merge + o_proj of a batch-1 decode step as one launch with in-launch hand-offs (csrc/fused_decode.hip)"}
+        if bits:
+            raise SystemExit(f"bench.py: a hand-off of the fused decode launch timed out (bits {bits:#x}): results invalid")
     rgb = pins = None
     if world == 1 and not shard and not do3:
         # image front-end (row f-1), outside the timed region: raw RGB bytes on the host -> normalised tiles in HBM

@@ -107,20 +107,38 @@ int omchat_prefill(omchat_ctx* ctx, const void* embeds, int b, int S, const int3
                    void* hidden_out, void* stream);
 /* Prefill of a LEFT-padded batch (config.tokenizer_padding_side == "left", omchat_arch.py:176-184): row i holds its lengths[i] tokens at
  * [S - lengths[i], S).  As in the reference, position_ids are dropped (:206-207) so RoPE runs on arange(S) for every row, the padded
- * keys are masked, and logits_last is the position S - 1 of every row (what generate reads).  Decode steps after it are refused
- * (the reference positions them with sum(mask) - 1, :61-70, which contradicts the prefill: DESIGN.md section 7). */
+ * keys are masked, and logits_last is the position S - 1 of every row (what generate reads).  A padded query row sees no key; its
+ * attention output is the uniform average of the sequence's V rows, as the reference's eager CPU attention computes it (every score at
+ * finfo.min).  Decode steps after it go through omchat_decode_step_masked (omchat_decode_step would place the rows per sequence and is
+ * refused). */
 int omchat_prefill_left(omchat_ctx* ctx, const void* embeds, int b, int S, const int32_t* lengths, float* logits_last,
                         void* hidden_out, void* stream);
 /* Decode step >= 1 (omchat_qwen2.py:92-111, omchat_arch.py:61-70): one token per sequence, appended at kv_len.
  * tokens device int32 [b]; logits device fp32 [b, t_vocab] or NULL; next_tokens device int32 [b] (greedy argmax,
  * first index wins) or NULL. */
 int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream);
+/* Decode step of a PADDED batch exactly as the reference computes it (omchat_arch.py:61-70 as HF generate drives it, `images` passed on
+ * every step): the new token of EVERY row is appended at the common cache length (S of the padded prefill + the masked steps so far), is
+ * rotated to positions[i] (host int32 [b]; the reference's sum(attention_mask) - 1) and attends the cache slots j <= slots with
+ * key_mask[i * mask_ld + j] != 0 (host bytes [b][mask_ld], mask_ld >= slots + 1: the token-level mask padded with ones -- it hides real
+ * prompt slots and exposes padded ones once images expanded the rows differently).  Valid after omchat_prefill (right padding) and
+ * omchat_prefill_left, for all b rows of that prefill, on one GPU with the 16-bit KV cache; omchat_decode_step and this entry cannot be
+ * mixed after one prefill (they place the cache rows differently).  Synchronises the stream. */
+int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld,
+                              float* logits, int32_t* next_tokens, void* stream);
+/* Batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch with in-launch hand-offs (csrc/fused_decode.hip; tuning
+ * key 22 = 0 turns it off; same bits either way).  launches: how many such launches this context has issued; timeout_bits: sticky bits of
+ * hand-offs that gave up after their wall-clock budget (0 = none; otherwise the affected steps' results are wrong).  Synchronises. */
+int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits);
 /* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
 /* greedy pick (HF generate with do_sample=False: argmax of the last position, first index wins): logits fp32
  * [b, t_vocab] (rank-local slice under tensor parallelism; the (max, index) pairs are exchanged) -> int32 [b] */
 int omchat_greedy(omchat_ctx* ctx, const float* logits, int b, int32_t* next_tokens, void* stream);
 int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b);      /* host copy of the current KV lengths */
+/* take back the last n decode steps of sequences 0..b-1 (generate() enqueues step k + 1 before it has read token k on the host, as the
+ * reference's HF loop cannot; when token k ends the generation -- EOS, a stopping criterion -- that step is forgotten).  Synchronises. */
+int omchat_kv_rewind(omchat_ctx* ctx, int b, int n, void* stream);
 
 /* ---- decode step as a hipGraph ------------------------------------------------------------------------------------ */
 /* With on != 0, omchat_decode_step on a TP = 1 context (b <= 32) replays one captured graph per step instead of issuing its
@@ -171,6 +189,9 @@ int omchat_mha_fwd_varlen(const void* qkv, int B, int S, int H, int D, const int
                           void* out, int dtype, void* stream);
 
 /* ---- op-level entry points (unit parity tests, benches) --------------------------------------------------------- */
+/* C[M, N] = epi(A[M, K] W[N, K]^T) on MFMA, fp32 accumulate.  Contract (checked, an error otherwise): K % 64 == 0; lda, ldw % 8 == 0 and
+ * A, W 16-byte aligned; N % 4 == 0 (the epilogue owns four consecutive columns per lane); C and resid 8-byte aligned with ldc, ldr % 4 == 0
+ * (8-byte epilogue accesses); bias and ls 8-byte aligned; EPI_SWIGLU: N % 32 == 0 and C is [M, N / 2]. */
 int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                    const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream);
 /* same with the stream-K tail enabled: ws from omchat_op_gemm_sk_ws() bytes of device memory; stream_k 0 = auto, 1 = required */
@@ -193,7 +214,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 19: split-KV merges with more partials per head than this take the 512-thread form (default 64: at 57 partials the 128-thread
  * one-batch form is faster, 4.9 vs 5.9 us);
  * key 21: column groups per head in the split-KV merge: 1 (default) = four workgroups per head beyond 256 partials (33 k keys: 21 -> ~7 us
- * per launch), 2 = also two workgroups per head for 65..256 partials (neutral), 0 = one workgroup per head) */
+ * per launch), 2 = also two workgroups per head for 65..256 partials (neutral), 0 = one workgroup per head;
+ * key 22: 1 (default) = a batch-1 decode step on one GPU (16-bit weights and cache, <= 4096 keys) runs attention + merge + o_proj as one
+ * launch (fused_decode.hip), 0 = as three launches (same bits)) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

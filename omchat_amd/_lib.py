@@ -49,6 +49,9 @@ _SIGS = {
     "omchat_lm_head": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_greedy": (_i, [_vp, _vp, _i, _vp, _vp]),
     "omchat_kv_lengths": (_i, [_vp, _vp, _i]),
+    "omchat_kv_rewind": (_i, [_vp, _i, _i, _vp]),
+    "omchat_decode_step_masked": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "omchat_fused_status": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_uint)]),
     "omchat_set_allreduce_hook": (_i, [_vp, _vp, _vp]),
     "omchat_allreduce_noop": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
     "omchat_op_gemv_norm": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _vp]),

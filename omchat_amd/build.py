@@ -6,7 +6,7 @@ SRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomchat_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip", "fused_decode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -34,7 +34,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
         return obj
 
-    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(cc, SOURCES))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)

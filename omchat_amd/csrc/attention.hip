@@ -20,90 +20,9 @@
 // partial (m, l, O) go to a workspace and a merge kernel normalises.
 #include "kernels.h"
 
+#include "attn_common.h"
+
 namespace {
-
-struct AttnP {
-  const void* Q; const void* K; const void* V; void* O;
-  int64_t q_sb, q_sh, q_sr, k_sb, k_sh, k_sr, v_sb, v_sh, v_sr, o_sb, o_sh, o_sr;
-  const int* kv_len;
-  const int* kv_start;
-  int q_heads, kv_heads, Sq, Skv, causal, q_pos0, nsplit;
-  float c;      // scale * log2(e)
-  float* ws;
-  // decode with fused RoPE + KV append (one new token per sequence): raw q/k/v of the new token live in the qkv buffer
-  const float* rope;      // [max_pos][64][2] or null
-  const int* pos;         // [batch] position of the new token (= kv_len - 1)
-  const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v rows, batch stride (elements); head stride 128
-  void* k_cache_w; void* v_cache_w;                          // writable views of K / V (same strides as K / V)
-  int rope_max;
-  const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;      // fp8 KV cache (decode only)
-  int tpw;                // decode: key tiles per wave (attn_decode_multi_kernel): a split is tpw x KV_TILE keys
-};
-
-// 8 e4m3 bytes -> 8 T (exact widening)
-template <typename T> __device__ __forceinline__ typename V8<T>::type widen8(u32x2 w);
-template <> __device__ __forceinline__ bf16x8 widen8<bf16>(u32x2 w) {
-  typedef bf16 v2 __attribute__((ext_vector_type(2)));
-  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, true);
-  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, true);
-  return (bf16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
-}
-template <> __device__ __forceinline__ f16x8 widen8<f16>(u32x2 w) {
-  typedef f16 v2 __attribute__((ext_vector_type(2)));
-  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, true);
-  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, true);
-  return (f16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
-}
-
-// RoPE of one 8-element chunk (rotate-half, modeling_qwen2.py:105-135) with the reference's rounding (N11):
-// x = own chunk, o = partner chunk 64 elements away, first half gets -partner*sin, second half +partner*sin
-template <typename T>
-__device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type x, typename V8<T>::type o, const float* cs, bool second_half) {
-  typename V8<T>::type r;
-  const float sgn = second_half ? 1.f : -1.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
-    r[j] = fromf<T>(rnd<T>(tof(x[j]) * co) + rnd<T>(sgn * tof(o[j]) * si));
-  }
-  return r;
-}
-
-constexpr int KV_TILE = 64;
-constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
-constexpr float NEG_BIG = -1e30f;      // a masked score
-constexpr float M_FLOOR = -1e20f;      // initial running-max reference: far below any real score, far above NEG_BIG, so that a row whose
-                                       // keys are ALL masked (padded query rows of a left-padded batch) gets p = exp2(-huge) = 0, l = 0 and an
-                                       // output of exactly 0 -- never inf - inf.  Its V rows feed later layers as masked keys: 0 * finite.
-constexpr float RESCALE_LOG2 = 8.f;   // prefill: running-max reference moves only on a > 2^8 overshoot
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-__device__ __forceinline__ s16x4 tr_read(const char* lds_addr) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
-}
-
-// lane ^ 32 / lane ^ 16 reductions on the VALU (v_permlane32_swap / v_permlane16_swap): swapping a value with itself gives
-// {own, partner}; no LDS round trip (ds_bpermute) on the softmax critical path
-__device__ __forceinline__ float max_xor32(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float max_xor16(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float sum_xor32(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float sum_xor16(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Prefill kernel.  K/V tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write): the LDS
 // destination is lane-linear (wave instruction i of wave w fills rows 4*(NW*i + w) .. +3), so the bank swizzles are
@@ -618,171 +537,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 // rotates q in registers and, in the split that owns the new position, rotates k and appends k / v to the cache
 // (replaces the separate RoPE + KV-append launch for S = 1).
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, bool KV8 = false>
+template <typename T, bool KV8 = false, bool MASKED = false>
 __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
-  typedef typename V8<T>::type frag_t;
   __shared__ __attribute__((aligned(256))) char Vs[KV_TILE * 256];
   const int lane = threadIdx.x, fc = lane & 15, fg = lane >> 4;
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
   const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
-  const int key0 = split * KV_TILE;
   float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
-  if (key0 >= kv_len) {                       // empty split (uniform): neutral partial
+  if (split * KV_TILE >= kv_len) {            // empty split (uniform): neutral partial
     if (fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
     return;
   }
-  const bool fuse = p.rope != nullptr;
-  const int pp = kv_len - 1;                  // position of the token being appended (fuse)
-  const int pt = pp < p.rope_max ? pp : p.rope_max - 1;
-  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
-  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
-  const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
-  const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
-
-  // ---- issue every load of the tile
-  frag_t kf[4][4];                            // A operand of S^T: key = key0 + 16*kt + fc, d = 32*ds + 8*fg + j
-  bool kfresh[4];
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int key = key0 + kt * 16 + fc;
-    kfresh[kt] = fuse && key >= pp;           // not in the cache yet (or clamped onto it)
-    if constexpr (KV8) {                      // e4m3 cache bytes, widened exactly; the per-key scale multiplies the score below
-      const unsigned char* src = (const unsigned char*)p.K + b * p.k_sb + kvh * p.k_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = widen8<T>(*reinterpret_cast<const u32x2*>(src + ds * 32 + fg * 8));
-    } else {
-      const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
-    }
-  }
-  frag_t vreg[16];                            // V^T image source: chunk idx = i*64 + lane -> row = 4*i + fg, ch = fc
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int key = key0 + i * 4 + fg;
-    const bool fresh = fuse && key >= pp;
-    if constexpr (KV8) {
-      const unsigned char* src = (const unsigned char*)p.V + b * p.v_sb + kvh * p.v_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
-      vreg[i] = widen8<T>(*reinterpret_cast<const u32x2*>(src + fc * 8));
-    } else {
-      const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
-      vreg[i] = ld8<T>(src + fc * 8);
-    }
-  }
-  // fp8 cache: scales of the keys this lane's score registers hold (key0 + 16 kt + 4 fg + r), clamped like the rows
-  f32x4 ksc[4], vsc[4];
-  if constexpr (KV8) {
-    const float* ksp = p.k_scale + b * p.scale_sb + kvh * p.scale_sh;
-    const float* vsp = p.v_scale + b * p.scale_sb + kvh * p.scale_sh;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kt * 16 + 4 * fg + r, kc = key < kv_len ? key : kv_len - 1;
-        ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
-      }
-  }
-  frag_t qf[4];
-  {
-    const int hh = fc < n_rep ? fc : n_rep - 1;
-    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
-  }
-  if (fuse) {
-    // rotate-half partner of d = 32*ds + 8*fg + j is fragment ds ^ 2 of the same lane (q and fresh k alike)
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
-      const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
-      const frag_t lo = qf[ds], hi = qf[ds + 2];
-      qf[ds] = rope_chunk<T>(lo, hi, cs, false);
-      qf[ds + 2] = rope_chunk<T>(hi, lo, cs, true);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kfresh[kt]) {
-          const frag_t kl = kf[kt][ds], kh = kf[kt][ds + 2];
-          kf[kt][ds] = rope_chunk<T>(kl, kh, cs, false);
-          kf[kt][ds + 2] = rope_chunk<T>(kh, kl, cs, true);
-        }
-    }
-    // append (N14): the lanes that hold the real row pp write it (4 lanes x 4 chunks for k, 16 lanes x 1 chunk for v)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-      if (key0 + kt * 16 + fc == pp) {
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds)
-          st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ds * 32 + fg * 8, kf[kt][ds]);
-      }
-  }
-
-  // ---- S^T = K Q^T from registers
-  f32x4 s[4];
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kf[kt][ds], qf[ds], s[kt]);
-  }
-  // ---- softmax over this split (keys >= kv_len masked)
-  float mx = NEG_BIG;
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float sv = s[kt][r];
-      if constexpr (KV8) sv *= ksc[kt][r];
-      const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? sv : NEG_BIG;
-      s[kt][r] = v;
-      mx = fmaxf(mx, v);
-    }
-  mx = max_xor32(max_xor16(mx));
-  const float mc = mx * p.c;
-  float psum = 0.f;
-  frag_t pf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    f32x8 e;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
-      psum += e[j];
-      if constexpr (KV8) e[j] *= vsc[2 * ks + (j >> 2)][j & 3];      // V = scale * e4m3: fold the per-key scale into P
-    }
-    pf[ks] = __builtin_convertvector(e, frag_t);
-  }
-  const float l = sum_xor32(sum_xor16(psum));
-
-  // ---- V -> LDS transpose image (chunk' = chunk ^ ((row & 7) << 1)), append the fresh v row
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = i * 4 + fg;
-    *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ ((row & 7) << 1)) << 4)) = vreg[i];
-    if (fuse && key0 + row == pp)
-      st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + fc * 8, vreg[i]);
-  }
-  __syncthreads();
-
-  // ---- O^T = V^T P^T
-  const int tq = fc >> 2, tp = fc & 3;
-  const int vrow_lo = 4 * fg + tq;
-  const int vswz = ((vrow_lo & 7) << 1);
   f32x4 o[8];
-#pragma unroll
-  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int dn = 0; dn < 8; ++dn) {
-      const int ch = (2 * dn + (tp >> 1)) ^ vswz;
-      const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
-      const s16x4 lo = tr_read(a0);
-      const s16x4 hi = tr_read(a0 + 16 * 256);
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
-    }
+  float mx, l;
+  attn_decode_tile<T, KV8, false, MASKED>(p, split, kvh, b, kv_len, Vs, lane, o, mx, l);
   if (fc < n_rep) {
 #pragma unroll
     for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
@@ -1193,13 +962,44 @@ void attn_set_klds(int v) { g_attn_klds = v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
 void attn_set_v2(int v) { g_attn_v2 = v; }
 
+namespace {
+// one workgroup per (head, sequence), thread = output column: the uniform average of the sequence's V rows, written to every padded query row
+template <typename T>
+__global__ __launch_bounds__(128) void attn_uniform_rows_kernel(AttnP p) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int start = p.kv_start[b];
+  if (start <= 0) return;
+  const int kvh = h / (p.q_heads / p.kv_heads);
+  const T* V = (const T*)p.V + b * p.v_sb + kvh * p.v_sh + d;
+  const float w = rnd<T>(1.0f / (float)p.Skv);          // softmax in fp32, cast to the activation dtype (modeling_qwen2.py:166-167)
+  float acc = 0.f;
+  for (int j = 0; j < p.Skv; ++j) acc += w * tof(V[(int64_t)j * p.v_sr]);
+  const T o = fromf<T>(acc);
+  T* O = (T*)p.O + b * p.o_sb + h * p.o_sh + d;
+  for (int i = 0; i < start && i < p.Sq; ++i) O[(int64_t)i * p.o_sr] = o;
+}
+}  // namespace
+
+int launch_attn_uniform_rows(int dtype, const AttnArgs& a, hipStream_t s) {
+  OM_CHECK(a.kv_start && (a.head_dim == 0 || a.head_dim == 128), "uniform rows: left-padded batch (kv_start), head dim 128");
+  AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
+          a.kv_len, a.kv_start, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
+          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, 0};
+  const dim3 grid(a.q_heads, a.batch);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(attn_uniform_rows_kernel<f16>, grid, dim3(128), 0, s, p);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(attn_uniform_rows_kernel<bf16>, grid, dim3(128), 0, s, p);
+  else { omchat_set_error("launch_attn_uniform_rows: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   OM_CHECK(a.q_heads % a.kv_heads == 0, "q_heads must be a multiple of kv_heads");
   OM_CHECK(a.Sq > 0 && a.Skv > 0 && a.batch > 0, "empty attention");
   OM_CHECK(a.q_sr % 8 == 0 && a.k_sr % 8 == 0 && a.v_sr % 8 == 0 && a.o_sr % 4 == 0, "row strides must keep 16-B alignment");
   AttnP p{a.Q, a.K, a.V, a.O, a.q_sb, a.q_sh, a.q_sr, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, a.o_sb, a.o_sh, a.o_sr,
           a.kv_len, a.kv_start, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
-          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+          nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
@@ -1259,18 +1059,23 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   const long waves1 = (long)cdiv(a.L, KV_TILE) * a.kv_heads * a.batch;
   int tpw = kv8 ? 1 : (waves1 >= 6144 ? 4 : (waves1 >= 3072 ? 2 : 1));
   if (g_attn_tpw > 0 && !kv8) tpw = g_attn_tpw;
+  if (a.key_mask) tpw = 1;      // the masked form exists for the one-tile kernel only (a rare mode)
   const int nsplit = cdiv(a.L, KV_TILE * tpw);
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
-          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh, tpw};
+          a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh, tpw,
+          a.key_mask, a.mask_sb};
+  OM_CHECK(!a.key_mask || (!kv8 && a.rope && a.pos && !a.kv_len && a.mask_sb % 64 == 0 && a.mask_sb >= a.L),
+           "masked decode: 16-bit cache, fused RoPE with explicit positions, uniform length, mask rows padded to a multiple of 64");
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
   OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
-    if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
+    if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
+    else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
@@ -1283,7 +1088,8 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     }
     else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
   } else if (dtype == OMCHAT_BF16) {
-    if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
+    if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
+    else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);

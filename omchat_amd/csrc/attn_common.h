@@ -1,0 +1,292 @@
+// Shared device helpers of the attention kernels (attention.hip) and the fused decode launch (fused_decode.hip): the kernel parameter block,
+// e4m3 widening, RoPE of one fragment chunk, lane-exchange reductions, the transposed LDS read -- and the body of the one-tile decode
+// attention (attn_decode_tile), which both the stand-alone split-KV launch and the fused attention + merge + o_proj launch execute, so that
+// the two give the same bits.  Everything lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "kernels.h"
+
+namespace {
+
+
+struct AttnP {
+  const void* Q; const void* K; const void* V; void* O;
+  int64_t q_sb, q_sh, q_sr, k_sb, k_sh, k_sr, v_sb, v_sh, v_sr, o_sb, o_sh, o_sr;
+  const int* kv_len;
+  const int* kv_start;
+  int q_heads, kv_heads, Sq, Skv, causal, q_pos0, nsplit;
+  float c;      // scale * log2(e)
+  float* ws;
+  // decode with fused RoPE + KV append (one new token per sequence): raw q/k/v of the new token live in the qkv buffer
+  const float* rope;      // [max_pos][64][2] or null
+  const int* pos;         // [batch] position of the new token (= kv_len - 1)
+  const void* k_new; const void* v_new; int64_t new_sb;   // raw k / v rows, batch stride (elements); head stride 128
+  void* k_cache_w; void* v_cache_w;                          // writable views of K / V (same strides as K / V)
+  int rope_max;
+  const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;      // fp8 KV cache (decode only)
+  int tpw;                // decode: key tiles per wave (attn_decode_multi_kernel): a split is tpw x KV_TILE keys
+  // decode of a padded batch as the reference computes it (omchat_decode_step_masked): key j of sequence b is visible iff
+  // key_mask[b * mask_sb + j] != 0 (rows zero-padded to mask_sb, a multiple of 64), and the new token is rotated to pos[b] -- not to the
+  // slot it is appended at (kv_len - 1)
+  const unsigned char* key_mask; int64_t mask_sb;
+};
+
+// 8 e4m3 bytes -> 8 T (exact widening)
+template <typename T> __device__ __forceinline__ typename V8<T>::type widen8(u32x2 w);
+template <> __device__ __forceinline__ bf16x8 widen8<bf16>(u32x2 w) {
+  typedef bf16 v2 __attribute__((ext_vector_type(2)));
+  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.x, 1.0f, true);
+  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w.y, 1.0f, true);
+  return (bf16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+template <> __device__ __forceinline__ f16x8 widen8<f16>(u32x2 w) {
+  typedef f16 v2 __attribute__((ext_vector_type(2)));
+  const v2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, true);
+  const v2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, true);
+  return (f16x8){a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+
+// RoPE of one 8-element chunk (rotate-half, modeling_qwen2.py:105-135) with the reference's rounding (N11):
+// x = own chunk, o = partner chunk 64 elements away, first half gets -partner*sin, second half +partner*sin
+template <typename T>
+__device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type x, typename V8<T>::type o, const float* cs, bool second_half) {
+  typename V8<T>::type r;
+  const float sgn = second_half ? 1.f : -1.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
+    r[j] = fromf<T>(rnd<T>(tof(x[j]) * co) + rnd<T>(sgn * tof(o[j]) * si));
+  }
+  return r;
+}
+
+constexpr int KV_TILE = 64;
+constexpr int WS_STRIDE = 132;   // 128 O values + m + l (+2 pad, keeps 16-B alignment)
+constexpr float NEG_BIG = -1e30f;      // a masked score
+constexpr float M_FLOOR = -1e20f;      // initial running-max reference: far below any real score, far above NEG_BIG, so that a row whose
+                                       // keys are ALL masked (padded query rows of a left-padded batch) gets p = exp2(-huge) = 0, l = 0 and an
+                                       // output of exactly 0 -- never inf - inf.  Its V rows feed later layers as masked keys: 0 * finite.
+constexpr float RESCALE_LOG2 = 8.f;   // prefill: running-max reference moves only on a > 2^8 overshoot
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
+}
+
+// lane ^ 32 / lane ^ 16 reductions on the VALU (v_permlane32_swap / v_permlane16_swap): swapping a value with itself gives
+// {own, partner}; no LDS round trip (ds_bpermute) on the softmax critical path
+__device__ __forceinline__ float max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---------------------------------------------------------------------------------------------------------
+// One 64-key tile of the decode attention for the n_rep query heads of one kv head (the body of attn_decode_kernel): ALL global loads of
+// the tile (K as MFMA A fragments straight to registers, V for the LDS transpose image, Q, RoPE table row) are issued at once -- one HBM
+// round trip -- then S^T from registers, softmax, V -> LDS, PV through ds_read_b64_tr_b16.  With `rope` set it also rotates q in registers
+// and, in the split that owns the new position, rotates k and appends k / v to the cache.  Results stay in registers: lane (fc = lane & 15
+// = head in the group, fg = lane >> 4) holds O[d = 16 dn + 4 fg + r] in o[dn][r], the tile's score maximum and exponential sum.
+// WAVE_ONLY: the caller is ONE wave of a larger workgroup (fused_decode.hip): LDS hand-over inside the wave instead of a workgroup
+// barrier, and one raw workgroup barrier right after the loads are issued (the other waves of the workgroup start THEIR loads behind it,
+// so that this tile's K / V are first in the CU's in-order memory pipe).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool KV8, bool WAVE_ONLY, bool MASKED = false>
+__device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int kvh, int b, int kv_len, char* Vs, int lane, f32x4 (&o)[8], float& mx_out,
+                                                 float& l_out) {
+  typedef typename V8<T>::type frag_t;
+  const int fc = lane & 15, fg = lane >> 4;
+  const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
+  const int key0 = split * KV_TILE;
+  const bool fuse = WAVE_ONLY ? true : p.rope != nullptr;      // the fused launch always rotates and appends (its launcher checks)
+  const int pp = kv_len - 1;                  // position of the token being appended (fuse)
+  const int pr = MASKED ? p.pos[b] : pp;      // RoPE position of the new token (MASKED: given, omchat_arch.py:70 sum(mask) - 1)
+  const int pt = pr < p.rope_max ? (pr > 0 ? pr : 0) : p.rope_max - 1;
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
+  const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
+
+  // ---- issue every load of the tile
+  frag_t kf[4][4];                            // A operand of S^T: key = key0 + 16*kt + fc, d = 32*ds + 8*fg + j
+  bool kfresh[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = key0 + kt * 16 + fc;
+    kfresh[kt] = fuse && key >= pp;           // not in the cache yet (or clamped onto it)
+    if constexpr (KV8) {                      // e4m3 cache bytes, widened exactly; the per-key scale multiplies the score below
+      const unsigned char* src = (const unsigned char*)p.K + b * p.k_sb + kvh * p.k_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = widen8<T>(*reinterpret_cast<const u32x2*>(src + ds * 32 + fg * 8));
+    } else {
+      const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
+    }
+  }
+  frag_t vreg[16];                            // V^T image source: chunk idx = i*64 + lane -> row = 4*i + fg, ch = fc
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int key = key0 + i * 4 + fg;
+    const bool fresh = fuse && key >= pp;
+    if constexpr (KV8) {
+      const unsigned char* src = (const unsigned char*)p.V + b * p.v_sb + kvh * p.v_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+      vreg[i] = widen8<T>(*reinterpret_cast<const u32x2*>(src + fc * 8));
+    } else {
+      const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
+      vreg[i] = ld8<T>(src + fc * 8);
+    }
+  }
+  // fp8 cache: scales of the keys this lane's score registers hold (key0 + 16 kt + 4 fg + r), clamped like the rows
+  f32x4 ksc[4], vsc[4];
+  if constexpr (KV8) {
+    const float* ksp = p.k_scale + b * p.scale_sb + kvh * p.scale_sh;
+    const float* vsp = p.v_scale + b * p.scale_sb + kvh * p.scale_sh;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + 4 * fg + r, kc = key < kv_len ? key : kv_len - 1;
+        ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
+      }
+  }
+  frag_t qf[4];
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
+  }
+  // WAVE_ONLY: the RoPE table row of the new position is loaded with the tile, ahead of the barrier (no runtime branch around the loads:
+  // a conditional block would end in a wait for them, and the barrier would then stand behind the whole memory round trip)
+  float csv[2][16];
+  if constexpr (WAVE_ONLY) {
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) csv[ds][j] = cs[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();               // raw: the loads above stay in flight; the workgroup's other waves issue theirs behind them
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (fuse) {
+    // rotate-half partner of d = 32*ds + 8*fg + j is fragment ds ^ 2 of the same lane (q and fresh k alike)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const float* cs = WAVE_ONLY ? csv[ds] : p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
+      const frag_t lo = qf[ds], hi = qf[ds + 2];
+      qf[ds] = rope_chunk<T>(lo, hi, cs, false);
+      qf[ds + 2] = rope_chunk<T>(hi, lo, cs, true);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kfresh[kt]) {
+          const frag_t kl = kf[kt][ds], kh = kf[kt][ds + 2];
+          kf[kt][ds] = rope_chunk<T>(kl, kh, cs, false);
+          kf[kt][ds + 2] = rope_chunk<T>(kh, kl, cs, true);
+        }
+    }
+    // append (N14): the lanes that hold the real row pp write it (4 lanes x 4 chunks for k, 16 lanes x 1 chunk for v)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (key0 + kt * 16 + fc == pp) {
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+          st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + ds * 32 + fg * 8, kf[kt][ds]);
+      }
+  }
+
+  // ---- S^T = K Q^T from registers
+  f32x4 s[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kf[kt][ds], qf[ds], s[kt]);
+  }
+  // ---- softmax over this split (keys >= kv_len masked; MASKED: also the keys the sequence's mask hides)
+  unsigned vis[4];
+  if constexpr (MASKED) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) vis[kt] = *reinterpret_cast<const unsigned*>(p.key_mask + b * p.mask_sb + key0 + kt * 16 + 4 * fg);
+  }
+  float mx = NEG_BIG;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv = s[kt][r];
+      if constexpr (KV8) sv *= ksc[kt][r];
+      bool seen = key0 + kt * 16 + 4 * fg + r < kv_len;
+      if constexpr (MASKED) seen = seen && ((vis[kt] >> (8 * r)) & 0xffu) != 0u;
+      const float v = seen ? sv : NEG_BIG;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = max_xor32(max_xor16(mx));
+  const float mc = mx * p.c;
+  float psum = 0.f;
+  frag_t pf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
+      psum += e[j];
+      if constexpr (KV8) e[j] *= vsc[2 * ks + (j >> 2)][j & 3];      // V = scale * e4m3: fold the per-key scale into P
+    }
+    pf[ks] = __builtin_convertvector(e, frag_t);
+  }
+  const float l = sum_xor32(sum_xor16(psum));
+
+  // ---- V -> LDS transpose image (chunk' = chunk ^ ((row & 7) << 1)), append the fresh v row
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = i * 4 + fg;
+    *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ ((row & 7) << 1)) << 4)) = vreg[i];
+    if (fuse && key0 + row == pp)
+      st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + fc * 8, vreg[i]);
+  }
+  if constexpr (WAVE_ONLY) { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+
+  // ---- O^T = V^T P^T
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;
+  const int vswz = ((vrow_lo & 7) << 1);
+#pragma unroll
+  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) {
+      const int ch = (2 * dn + (tp >> 1)) ^ vswz;
+      const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+      const s16x4 lo = tr_read(a0);
+      const s16x4 hi = tr_read(a0 + 16 * 256);
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
+    }
+  mx_out = mx;
+  l_out = l;
+}
+
+}  // namespace

@@ -782,14 +782,23 @@ int gemm_tune_dump(const char* path) {
 }
 long gemm_tune_runs() { return g_tune_runs; }
 
+// choices that were NOT measured (the cost model's answer for a launch-bound shape, a neighbouring class's winner): remembered for the
+// life of the process, never written to the tune file -- g_tuned holds measurements (made here or loaded) only
+static std::map<std::array<int, 5>, int> g_guess;
+
 static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   const std::array<int, 5> key{dtype * 8 + a.epi, cdiv(a.M, 256), a.N, a.K, a.ldc};
   std::lock_guard<std::mutex> lock(g_tune_mu);
   auto it = g_tuned.find(key);
   if (it != g_tuned.end()) return it->second;
+  it = g_guess.find(key);
+  if (it != g_guess.end()) return it->second;
+  const int heuristic = pick_tile(a.M, a.N, a.epi);
+  if ((double)a.M * a.N * a.K < 4e9) return g_guess[key] = heuristic;            // < 8 GFLOP: launch-bound, nothing to choose
   {
-    // a measured class of the same (dtype, epilogue, N, K, ldc) whose row-tile count is within one tile or 1/8: prompts come in every
-    // length, and a live request must not pay 5 candidates x 4 launches because its S rounds to a row-tile count nobody has seen
+    // a MEASURED class of the same (dtype, epilogue, N, K, ldc) whose row-tile count is within one tile or 1/8: prompts come in every
+    // length, and a live request must not pay 5 candidates x 4 launches because its S rounds to a row-tile count nobody has seen.
+    // Ties go to the smaller row-tile count (std::map order), so the answer does not depend on the order in which shapes were seen.
     int best_d = INT_MAX, best_t = 0;
     for (auto& kv : g_tuned) {
       const auto& k = kv.first;
@@ -797,16 +806,14 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
       const int d = k[1] > key[1] ? k[1] - key[1] : key[1] - k[1];
       if (d < best_d) { best_d = d; best_t = kv.second; }
     }
-    if (best_t && best_d <= std::max(1, key[1] / 8)) return best_t;          // not cached under the new key: the file stays what was measured
+    if (best_t && best_d <= std::max(1, key[1] / 8)) return g_guess[key] = best_t;
   }
-  const int heuristic = pick_tile(a.M, a.N, a.epi);
-  if ((double)a.M * a.N * a.K < 4e9) return g_tuned[key] = heuristic;            // < 8 GFLOP: launch-bound, nothing to choose
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return heuristic;      // cannot time inside a capture
   GemmArgs t = a;
   t.M = a.M < 8192 ? a.M : 8192;                                                 // enough rounds to rank the kernels, bounded scratch
   void* scratch = nullptr;
-  if (hipMalloc(&scratch, (size_t)t.M * a.ldc * 2) != hipSuccess) { (void)hipGetLastError(); return g_tuned[key] = heuristic; }
+  if (hipMalloc(&scratch, (size_t)t.M * a.ldc * 2) != hipSuccess) { (void)hipGetLastError(); return g_guess[key] = heuristic; }
   t.C = scratch;
   // In the model every GEMM meets its weights cold (27 GB stream through a 256 MB Infinity Cache between two uses), while
   // back-to-back timing runs would find them cached and rank the kernels differently (o_proj: 102 us warm, 120 us in place).
@@ -870,7 +877,8 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   OM_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "empty problem");
   if (a.f8) {
     OM_CHECK(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && a.a_scale && a.w_scale, "fp8 GEMM: K % 128, lda / ldw % 16 bytes, both scale vectors");
-    OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.ldc % 2 == 0 && ((uintptr_t)a.C & 3) == 0, "fp8 GEMM: alignment");
+    OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.C & 7) == 0 &&
+             (!a.resid || (a.ldr % 4 == 0 && ((uintptr_t)a.resid & 7) == 0)), "fp8 GEMM: A / W 16-byte, C / residual 8-byte aligned with row strides % 4");
     OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
     OM_CHECK(a.N % 4 == 0 && ((uintptr_t)a.bias & 7) == 0 && ((uintptr_t)a.ls & 7) == 0 && ((uintptr_t)a.w_scale & 15) == 0,
              "fp8 GEMM: N % 4, bias / layer-scale 8-byte and w_scale 16-byte aligned");
@@ -881,8 +889,9 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
   }
   OM_CHECK(a.K % 64 == 0, "K must be a multiple of 64");
   OM_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, "lda/ldw must be multiples of 8 elements (16-byte rows)");
-  OM_CHECK(a.ldc % 2 == 0 && (!a.resid || a.ldr % 2 == 0) && ((uintptr_t)a.C & 3) == 0 && ((uintptr_t)a.resid & 3) == 0,
-           "C / residual rows must start on 4-byte boundaries (the epilogue addresses them through buffer resources)");
+  // the epilogue owns four consecutive columns of a row per lane: 8-byte stores to C and 8-byte loads of the residual
+  OM_CHECK(a.ldc % 4 == 0 && (!a.resid || a.ldr % 4 == 0) && ((uintptr_t)a.C & 7) == 0 && ((uintptr_t)a.resid & 7) == 0,
+           "C / residual: 8-byte aligned base, row stride a multiple of 4 elements (8-byte epilogue accesses)");
   OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "A/W must be 16-byte aligned");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
   OM_CHECK(a.epi != EPI_LS_RESID || a.ls, "layer-scale epilogue needs ls");

@@ -10,6 +10,7 @@
 // (8 waves x UNROLL x 2 KiB per workgroup).  The 8 partial 16x16 fp32 tiles are summed through LDS in a fixed order
 // (deterministic, no atomics), and wave 0 applies the epilogue.
 #include "kernels.h"
+#include "rowdot.h"
 #include <type_traits>
 
 namespace {
@@ -470,31 +471,9 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 // epilogue.  Split-K slices are chunk ranges of 512 elements, <= RW_MAXC chunks each.
 // ---------------------------------------------------------------------------------------------------------
 int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
+int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 int g_gemv_no_xs = 0;          // tuning knob (key 11): 1 = batched decode never takes the x-stationary persistent kernel (A/B)
 constexpr int RW_MAXC = 8;
-typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> __device__ __forceinline__ float rw_dot8(rw_u32x4 w, rw_u32x4 x, float acc);
-template <> __device__ __forceinline__ float rw_dot8<bf16>(rw_u32x4 w, rw_u32x4 x, float acc) {
-  typedef bf16 v2 __attribute__((ext_vector_type(2)));
-  // explicit components: bit_cast of a loop-indexed vector element was observed to read element 0 four times
-  const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w0), __builtin_bit_cast(v2, x0), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w1), __builtin_bit_cast(v2, x1), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w2), __builtin_bit_cast(v2, x2), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w3), __builtin_bit_cast(v2, x3), acc, false);
-  return acc;
-}
-template <> __device__ __forceinline__ float rw_dot8<f16>(rw_u32x4 w, rw_u32x4 x, float acc) {
-  typedef f16 v2 __attribute__((ext_vector_type(2)));
-  const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w0), __builtin_bit_cast(v2, x0), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w1), __builtin_bit_cast(v2, x1), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w2), __builtin_bit_cast(v2, x2), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, w3), __builtin_bit_cast(v2, x3), acc, false);
-  return acc;
-}
-
 // weight-only fp8 (OCP e4m3): 8 weights of a lane = 8 bytes.  gfx950's v_cvt_scalef32_pk_{bf16,f16}_fp8 widens two e4m3
 // values to a packed 16-bit pair in one instruction (exact: 3 mantissa bits), which then feeds the same v_dot2 as the
 // 16-bit kernel with x still packed in registers: 4 converts + 4 dot2 per 8 weights.
@@ -684,11 +663,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
       if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)rows[r] * p.ldw + k));
       else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)rows[r] * p.ldw + k));
     }
-  // ---- 2. the norm, shared by the workgroup: wave w owns chunks w, w + 4 (x and the norm weights are read ONCE per workgroup: 2 x 7 KB
-  // instead of 7 KB of xn per wave), partial sums of squares meet in LDS, the normalised row goes to LDS, every wave reads it back.
-  // The plain loads above stay in flight across the two barriers.
+  // ---- 2. the norm, shared by the workgroup: wave w normalises chunks w, w + WAVES, ... (x and the norm weights are read ONCE per
+  // workgroup: 2 x 7 KB instead of 7 KB of xn per wave), the normalised row goes to LDS, every wave reads it back.  The plain loads above
+  // stay in flight across the two barriers.
+  // The sum of squares is ALWAYS taken in the four-wave order -- waves 0..3 own chunks w and w + 4, per-lane accumulation over the two
+  // chunks, butterfly, ((r0 + r1) + r2) + r3 -- whatever WAVES is, so that every launch form of a projection (4, 7 or 9 waves, the loop
+  // form) gives the same bits on every device (the nine-wave form used to sum its nine per-chunk partials: ADVICE r03).
+  static_assert(WAVES >= 4 && NCH <= 8, "sum-of-squares order: four owner waves, up to two chunks each");
   constexpr int MC = (NCH + WAVES - 1) / WAVES;
-  rw_u32x4 xq[MC], nq[MC];
+  constexpr int SC = (NCH + 3) / 4;
+  rw_u32x4 xq[MC], nq[MC], sq[SC];
 #pragma unroll
   for (int i = 0; i < MC; ++i) {
     const int c = wave + WAVES * i, k = c * 512 + lane * 8;
@@ -697,22 +681,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
     xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
     nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
   }
+#pragma unroll
+  for (int i = 0; i < SC; ++i) {
+    if constexpr (WAVES == 4) {
+      sq[i] = xq[i];
+    } else {
+      const int c = wave + 4 * i, k = c * 512 + lane * 8;
+      const rw_u32x4 z = {0u, 0u, 0u, 0u};
+      sq[i] = (wave < 4 && c < NCH && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);            // keep every load above the first wait
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MC; ++i) {
-    const v8 xv = __builtin_bit_cast(v8, xq[i]);
+  for (int i = 0; i < SC; ++i) {
+    const v8 xv = __builtin_bit_cast(v8, sq[i]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float v = tof(xv[j]); ss += v * v; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  if (lane == 0) red[wave] = ss;
+  if (lane == 0 && wave < 4) red[wave] = ss;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  float tot = red[0];                           // fixed order: the same bits in every wave
+  float tot = red[0];                           // fixed order: the same bits in every wave and in every launch form
 #pragma unroll
-  for (int w = 1; w < WAVES; ++w) tot += red[w];
+  for (int w = 1; w < 4; ++w) tot += red[w];
   const float inv = rsqrtf(tot / (float)p.K + p.norm_eps);
 #pragma unroll
   for (int i = 0; i < MC; ++i) {

@@ -67,6 +67,7 @@ int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
 // W8[n][k] = e4m3_rne(W[n][k] / scale[n])
 int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t stream);
 void gemv_set_force_mfma(int v);
+int gemv_get_force_mfma();
 void gemm_set_autotune(int v);
 int gemm_tune_load(const char* path);
 int gemm_tune_dump(const char* path);
@@ -110,6 +111,9 @@ struct AttnArgs {
   int head_dim;             // 128 (0 = 128) or 64 (InternViT-300M)
 };
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s);
+// query rows i < kv_start[b] of a left-padded batch (no visible key): O = sum_j T(1 / Skv) * V[j] over ALL Skv keys, the reference's eager
+// attention on a fully masked row (modeling_qwen2.py:150-172 with every score at finfo.min); needs a.kv_start
+int launch_attn_uniform_rows(int dtype, const AttnArgs& a, hipStream_t s);
 void attn_set_v2(int v);
 void model_set_fuse_peer_norm(int v);
 void attn_set_tpw(int v);
@@ -141,6 +145,9 @@ struct AttnDecodeArgs {
   // with one fp32 scale per (sequence, kv head, key): k_scale / v_scale [b][kv_heads][scale_cap]; rope must be null (the new token is
   // rotated, appended and quantised before the call)
   const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;
+  // padded batch as the reference decodes it (omchat_decode_step_masked): key j of sequence b is visible iff key_mask[b * mask_sb + j] != 0
+  // (device bytes, rows zero-padded to mask_sb % 64 == 0); `pos` then holds the RoPE positions (not kv_len - 1); kv_len must be null
+  const unsigned char* key_mask; int64_t mask_sb;
 };
 // quantise rows [pos0, pos1) of every (sequence < b, kv head) of a 16-bit cache [b_cap, kv_heads, cap, 128] into the fp8 cache + scales
 // (pos1 = null-terminated per sequence: rows >= len[b] are skipped when len != null)
@@ -148,6 +155,22 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
                     int64_t s_sb, int64_t s_sh, const int* pos_lo, int pos0, const int* len, int max_rows, hipStream_t s);
 size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len);
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s);
+
+// batch-1 decode on one GPU (fused_decode.hip, round 4): launch_attn_decode + the o_proj GEMV with EPI_RESID as ONE launch, same bits.
+// x [H] is the residual stream (read, x + o_proj(attn) written in place), Wo [H][qd] row-major; ws = fused_decode_ws_bytes(q_heads) bytes
+// of zero-initialised device memory owned by the caller and used by no other launch at the same time; epoch: a value that no earlier launch
+// on the same ws has used (monotonic counter, never 0); err: device word that collects time-out bits (0 = every hand-off completed).
+struct FusedDecodeArgs {
+  const void* Wo; int ldw;
+  void* x; int H, qd;
+  void* ws; unsigned epoch;
+  unsigned* err; int timeout_ms;
+  void* dbg = nullptr;      // diagnostic build of tools/tune_fused.hip only: phase stamps [CUs][16]; the library never sets it
+};
+size_t fused_decode_ws_bytes(int q_heads);
+bool attn_oproj_fused_ok(const AttnDecodeArgs& a, int H, int qd);
+int launch_attn_oproj_fused(int dtype, const AttnDecodeArgs& a, const FusedDecodeArgs& f, hipStream_t s);
+void model_set_fuse_attn_oproj(int v);
 
 // ------------------------------------------------------------------------------------------------ RoPE + KV append
 // qkv [rows, (nq + 2 nkv) * 128] post-bias; rotate q in place, write rotated k and raw v into the caches at

@@ -69,6 +69,8 @@ struct Route {
 
 }  // namespace
 
+int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
+void model_set_fuse_attn_oproj(int v) { g_fuse_attn_oproj = v; }
 int g_fuse_peer_norm = 1;      // omchat_op_set_tuning key 9: 0 = tensor-parallel decode keeps the all-reduce and the residual + RMSNorm as two launches (A/B)
 void model_set_fuse_peer_norm(int v) { g_fuse_peer_norm = v; }
 
@@ -137,8 +139,18 @@ struct omchat_ctx {
   float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
   float* tw_attn_ws = nullptr;
   size_t tw_attn_ws_bytes = 0;
+  // fused attention + merge + o_proj launch of the batch-1 decode step (fused_decode.hip): granule buffers, sticky time-out word, and the
+  // launch counter that tags the granules of one launch
+  void* fd_ws = nullptr;
+  unsigned* fd_err = nullptr;
+  unsigned fd_epoch = 0;
+  long n_fused_launches = 0;
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_start = nullptr;
   bool left_padded = false;
+  // decode of a padded batch as the reference computes it (omchat_decode_step_masked): every row's cache holds pre_S + masked_steps slots;
+  // dec_mode: 0 = no decode step since the prefill, 1 = omchat_decode_step (per-sequence lengths), 2 = omchat_decode_step_masked
+  int pre_S = 0, pre_b = 0, masked_steps = 0, dec_mode = 0;
+  unsigned char* d_mask = nullptr; int64_t mask_sb = 0;
   void *kcache = nullptr, *vcache = nullptr;   // [layers][max_batch][kv_heads][max_seq][128]
   std::vector<int> h_len;
   // optional per-kernel-class HIP-event timing (bench.py roofline): category -> event pairs recorded on the launch stream
@@ -357,6 +369,13 @@ int build(omchat_ctx* ctx) {
     ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
     TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
     TRY(ctx->alloc((void**)&ctx->tw_part, (size_t)DEC_KS_MAX * c.max_batch * H * 4));
+    if (ctx->tp_size == 1) {
+      const size_t fb = fused_decode_ws_bytes(c.t_heads);
+      TRY(ctx->alloc(&ctx->fd_ws, fb));
+      TRY(ctx->alloc((void**)&ctx->fd_err, 64));
+      OM_HIP(hipMemset(ctx->fd_ws, 0, fb));
+      OM_HIP(hipMemset(ctx->fd_err, 0, 64));
+    }
     TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
     TRY(ctx->alloc((void**)&ctx->d_pos, (size_t)c.max_batch * 4));
@@ -900,6 +919,7 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     klen[i] = left ? S : lengths[i]; kstart[i] = left ? S - lengths[i] : 0;
   }
   ctx->left_padded = left;
+  ctx->pre_S = S; ctx->pre_b = b; ctx->masked_steps = 0; ctx->dec_mode = 0;
   // d_len holds the valid key range end during prefill; switched to (len + 1, pos = len) for the decode steps at the end
   OM_HIP(hipMemcpyAsync(ctx->d_len, klen.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
   if (left) OM_HIP(hipMemcpyAsync(ctx->d_start, kstart.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
@@ -937,6 +957,10 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     a.kv_start = left ? ctx->d_start : nullptr;
     a.scale = 0.08838834764831845f;
     TRY(launch_attn_prefill(ctx->dt, a, s));
+    // left-padded batch: a padded query row sees no key at all; the reference's eager attention (the CPU path) then attends EVERY key of
+    // the sequence with weight 1 / S (all scores are finfo.min -> softmax uniform, future keys included), and these rows' K / V in the
+    // next layers are what a masked decode step exposes (omchat_arch.py:61-70).  The flash kernel leaves exactly 0 there; fill them.
+    if (left && ctx->tp_size == 1) TRY(launch_attn_uniform_rows(ctx->dt, a, s));
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, x, H, rows, H, qd, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
@@ -1043,7 +1067,7 @@ static int ensure_packed(omchat_ctx* ctx) {
 // exact_len: every sequence holds exactly Lmax keys after this step (eager launches only): the attention launches then take the length
 // as a kernel argument instead of loading d_len first -- one dependent memory round trip less in two latency-bound launches per layer.
 static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, float* logits, int32_t* next_tokens, hipStream_t s, bool allow_prof,
-                       bool exact_len = false) {
+                       bool exact_len = false, bool masked = false) {
   const omchat_config& c = ctx->c;
   const int H = c.t_hidden, It = c.t_mlp, qkvd = ctx->t_qkvdim, qd = ctx->t_qdim;
   const bool lead = ctx->tp_rank == 0;
@@ -1097,7 +1121,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // write x + attn / x + mlp themselves (EPI_RESID, in place; down_proj's K = 18944 through gemv_rows_longk_kernel), and each RMSNorm runs
   // inside the projection that consumes it (gemv_rows_norm_kernel: qkv, gate|up, lm_head): six dependent launches per layer instead of
   // eight.  n2 = the post-attention norm (tuning key 14 bit 0), n1 = the input norm of the next layer / the final norm (bit 1).
-  const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096;
+  // (only while the whole-row GEMV form is in use: with tuning key 1 -- force the MFMA form -- the norm has no registers to live in and
+  // the step keeps its residual + RMSNorm launches)
+  const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096 && !gemv_get_force_mfma();
   const bool n1 = n2 && (g_norm_in_gemv & 2) && It <= 32768 && It % 8 == 0;
   if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
@@ -1127,6 +1153,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     a.rope = ctx->rope; a.rope_max = c.max_seq; a.pos = ctx->d_pos;
     a.k_new = (const char*)ctx->tw_qkv + (size_t)qd * 2; a.v_new = (const char*)ctx->tw_qkv + (size_t)(qd + ctx->t_kvdim) * 2; a.new_sb = qkvd;
     if (exact_len) a.kv_len = nullptr;
+    if (masked) { a.key_mask = ctx->d_mask; a.mask_sb = ctx->mask_sb; }      // d_pos holds the given RoPE positions, every row has Lmax keys
     if (ctx->fp8_kv && ctx->kv8_valid) {
       // fp8 KV cache: rotate q / k and append to the 16-bit cache with the prefill's kernel, quantise the new row, then attend over e4m3
       // keys and values (two small launches more per layer than the fused 16-bit path; this mode is for long contexts)
@@ -1142,10 +1169,21 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       a.k_scale = ctx->ks8 + so; a.v_scale = ctx->vs8 + so; a.scale_sb = (int64_t)c.t_kv_heads * c.max_seq; a.scale_sh = c.max_seq;
     }
     a.o_pack_nb = fused ? pk : 0;
-    TRY(launch_attn_decode(ctx->dt, a, s));
+    // batch 1, one GPU (round 4): attention + merge + o_proj (+ residual) as ONE launch with in-launch hand-offs (fused_decode.hip; the same
+    // bits as the three launches).  Eager steps only: the launch is tagged with a per-launch counter, which a captured graph would freeze.
+    const bool fuse_ao = g_fuse_attn_oproj && n2 && exact_len && !f8 && a.rope && ctx->fd_ws && attn_oproj_fused_ok(a, H, qd);
+    if (fuse_ao) {
+      FusedDecodeArgs fa{L.wo, qd, x, H, qd, ctx->fd_ws, ++ctx->fd_epoch, ctx->fd_err, 2000};
+      TRY(launch_attn_oproj_fused(ctx->dt, a, fa, s));
+      ++ctx->n_fused_launches;
+    } else {
+      TRY(launch_attn_decode(ctx->dt, a, s));
+    }
     // batch 1, one GPU (round 3): o_proj without split-K writes x + attn itself (EPI_RESID, in place) and the post-attention RMSNorm runs
     // in the registers of the gate|up GEMV's waves (gemv.hip: norm_w): seven dependent launches per layer instead of eight
-    if (n2) {
+    if (fuse_ao) {
+      // x + attn is already in place
+    } else if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
     } else if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
@@ -1235,8 +1273,9 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
   OM_CHECK(c.t_layers > 0, "context has no decoder");
   OM_CHECK(b >= 1 && b <= c.max_batch, "batch exceeds max_batch");
   int Lmax = 0;
-  OM_CHECK(!ctx->left_padded, "decode after a left-padded prefill is refused: the reference positions such a batch inconsistently "
-                              "between prefill (arange(S)) and decode (sum(mask) - 1); pad on the right (DESIGN.md section 7)");
+  OM_CHECK(!ctx->left_padded, "per-sequence decode after a left-padded prefill: use omchat_decode_step_masked (the reference positions such a "
+                              "batch with sum(mask) - 1 and a per-row key mask, omchat_arch.py:61-70; DESIGN.md section 7)");
+  OM_CHECK(ctx->dec_mode != 2, "omchat_decode_step after omchat_decode_step_masked on the same prefill: the two place the cache rows differently");
   bool same_len = true;
   for (int i = 0; i < b; ++i) {
     OM_CHECK(ctx->h_len[i] >= 1, "decode before prefill");
@@ -1284,6 +1323,48 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
     OM_HIP(hipStreamWaitEvent(s, ctx->graph_ev_out, 0));
   }
   for (int i = 0; i < b; ++i) ctx->h_len[i] += 1;
+  ctx->dec_mode = 1;
+  return 0;
+}
+
+// Decode step of a PADDED batch exactly as the reference computes it (omchat_arch.py:61-70 as HF generate drives it with `images` passed
+// on every step): the new token of EVERY row is appended at the common cache length (S of the padded prefill + the steps so far), rotated
+// to positions[i] = sum(mask_i) - 1, and attends the cache slots whose mask byte is non-zero -- the token-level mask padded with ones,
+// which hides real prompt slots and exposes padded ones once images expanded the rows differently.  After a right-padded prefill the
+// padded slots hold the K / V of causally un-masked padded query rows (what every backend of the reference computes); after a
+// left-padded one those of fully masked rows, which the prefill filled as the reference's eager (CPU) attention does.
+extern "C" int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask,
+                                         int mask_ld, float* logits, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && tokens && positions && key_mask, "null argument");
+  const omchat_config& c = ctx->c;
+  OM_CHECK(c.t_layers > 0, "context has no decoder");
+  OM_CHECK(ctx->pre_S >= 1 && b == ctx->pre_b, "masked decode: the batch of the last prefill, all rows");
+  OM_CHECK(ctx->dec_mode != 1, "omchat_decode_step_masked after omchat_decode_step on the same prefill: the two place the cache rows differently");
+  OM_CHECK(ctx->tp_size == 1 && !(ctx->fp8_kv && ctx->kv8_valid), "masked decode: one GPU, 16-bit KV cache");
+  const int Lc = ctx->pre_S + ctx->masked_steps;          // slots every row holds; the new token goes to slot Lc
+  OM_CHECK(Lc + 1 <= c.max_seq, "KV cache full (max_seq)");
+  OM_CHECK(mask_ld >= Lc + 1, "key_mask rows must cover the cache and the new token (slots + 1 columns)");
+  hipStream_t s = (hipStream_t)stream;
+  if (!ctx->d_mask) {
+    ctx->mask_sb = (int64_t)cdiv(c.max_seq, 64) * 64;
+    TRY(ctx->alloc((void**)&ctx->d_mask, (size_t)c.max_batch * ctx->mask_sb));
+  }
+  std::vector<int> pos(b);
+  for (int i = 0; i < b; ++i) {
+    OM_CHECK(positions[i] >= 0 && positions[i] < c.max_seq, "position outside the RoPE table");
+    OM_CHECK(key_mask[(size_t)i * mask_ld + Lc] != 0, "the new token must see itself");
+    pos[i] = positions[i];
+  }
+  OM_HIP(hipMemsetAsync(ctx->d_mask, 0, (size_t)b * ctx->mask_sb, s));
+  OM_HIP(hipMemcpy2DAsync(ctx->d_mask, (size_t)ctx->mask_sb, key_mask, (size_t)mask_ld, (size_t)Lc + 1, (size_t)b, hipMemcpyHostToDevice, s));
+  OM_HIP(hipMemcpyAsync(ctx->d_pos, pos.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  if (b > 1 && b <= 32) TRY(ensure_packed(ctx));
+  if (ctx->fp8_decode && ctx->fp8_stale) TRY(ensure_fp8_weights(ctx));
+  const int rc = decode_body(ctx, tokens, b, Lc + 1, logits, next_tokens, s, false, true, true);
+  OM_HIP(hipStreamSynchronize(s));     // pos is a stack vector; the caller's mask may be reused
+  if (rc) return rc;
+  ctx->masked_steps += 1;
+  ctx->dec_mode = 2;
   return 0;
 }
 
@@ -1337,9 +1418,46 @@ extern "C" int omchat_prof_read(omchat_ctx* ctx, int cat, double* total_ms, long
   return 0;
 }
 
+// Fused decode launches (fused_decode.hip): how many ran, and the sticky time-out bits of their in-launch hand-offs (0 = every hand-off
+// completed; bit 0 = a merge sweep, bit 1 = a row sweep gave up after its wall-clock budget -- the step's results are then wrong and the
+// caller must not use them).  Synchronises the device.
+extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits) {
+  OM_CHECK(ctx, "null ctx");
+  if (launches) *launches = ctx->n_fused_launches;
+  if (timeout_bits) {
+    *timeout_bits = 0;
+    if (ctx->fd_err) OM_HIP(hipMemcpy(timeout_bits, ctx->fd_err, 4, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// Forget the last n decode steps of sequences 0..b-1 (their cache rows stay in memory and are overwritten by the next steps): the drop-in
+// generate() enqueues step k + 1 before it has looked at token k on the host, and takes the step back when token k ends the generation.
+extern "C" int omchat_kv_rewind(omchat_ctx* ctx, int b, int n, void* stream) {
+  OM_CHECK(ctx && b >= 1 && b <= (int)ctx->h_len.size() && n >= 0, "bad argument");
+  if (n == 0) return 0;
+  if (ctx->dec_mode == 2) {
+    OM_CHECK(n <= ctx->masked_steps, "rewind beyond the prefill");
+    ctx->masked_steps -= n;
+    return 0;
+  }
+  std::vector<int> pos(b), len1(b);
+  for (int i = 0; i < b; ++i) {
+    OM_CHECK(ctx->h_len[i] - n >= 1, "rewind beyond the prefill");
+    ctx->h_len[i] -= n;
+    pos[i] = ctx->h_len[i]; len1[i] = ctx->h_len[i] + 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  OM_HIP(hipMemcpyAsync(ctx->d_pos, pos.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  OM_HIP(hipMemcpyAsync(ctx->d_len, len1.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
+  OM_HIP(hipStreamSynchronize(s));     // stack vectors
+  return 0;
+}
+
 extern "C" int omchat_kv_lengths(omchat_ctx* ctx, int32_t* out, int b) {
   OM_CHECK(ctx && out && b <= (int)ctx->h_len.size(), "bad argument");
-  for (int i = 0; i < b; ++i) out[i] = ctx->h_len[i];
+  // after a left-padded prefill, and once a masked decode step ran, every row holds the same number of cache slots
+  for (int i = 0; i < b; ++i) out[i] = (ctx->left_padded || ctx->dec_mode == 2) ? ctx->pre_S + ctx->masked_steps : ctx->h_len[i];
   return 0;
 }
 

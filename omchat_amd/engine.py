@@ -263,6 +263,28 @@ class Engine:
         check(self.lib.omchat_decode_step(self.h, ptr(tk), b, ptr(logits), ptr(nxt), cur_stream()))
         return nxt, logits
 
+    def decode_step_masked(self, tokens, position_ids, attention_mask, want_logits=False):
+        """Decode step of a padded batch as the reference computes it (omchat_arch.py:61-70): `position_ids` [b] or [b, 1] and
+        `attention_mask` [b, slots + 1] are what the decode branch of prepare_inputs_labels_for_multimodal returns (the token-level
+        mask padded with ones, sum(mask) - 1).  The new token of every row goes to the common cache slot; see include/omchat_hip.h."""
+        torch = _torch()
+        tk = tokens.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+        b = tk.shape[0]
+        pos = position_ids.detach().to("cpu", torch.int32).contiguous().view(-1)
+        m = attention_mask.detach().to("cpu").ne(0).to(torch.uint8).contiguous()
+        if pos.shape[0] != b or m.dim() != 2 or m.shape[0] != b:
+            raise ValueError("decode_step_masked: position_ids [b], attention_mask [b, slots + 1]")
+        logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        nxt = torch.empty(b, dtype=torch.int32, device=self.device)
+        check(self.lib.omchat_decode_step_masked(self.h, ptr(tk), b, ptr(pos), ptr(m), m.shape[1], ptr(logits), ptr(nxt), cur_stream()))
+        return nxt, logits
+
+    def fused_status(self):
+        """(launches, timeout_bits) of the fused attention + o_proj decode launches; timeout_bits != 0 means a hand-off gave up."""
+        n, bits = C.c_long(0), C.c_uint(0)
+        check(self.lib.omchat_fused_status(self.h, C.byref(n), C.byref(bits)))
+        return n.value, bits.value
+
     def lm_head(self, hidden):
         torch = _torch()
         h = hidden.to(device=self.device, dtype=self.torch_dtype).contiguous()
@@ -291,6 +313,10 @@ class Engine:
         out = torch.zeros(b, dtype=torch.int32)
         check(self.lib.omchat_kv_lengths(self.h, ptr(out), b))
         return [int(x) for x in out]
+
+    def kv_rewind(self, b, n=1):
+        """forget the last n decode steps of sequences 0..b-1 (see include/omchat_hip.h: omchat_kv_rewind)"""
+        check(self.lib.omchat_kv_rewind(self.h, b, n, cur_stream()))
 
     def argmax(self, logits):
         torch = _torch()

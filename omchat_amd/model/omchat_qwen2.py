@@ -143,6 +143,9 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
                 # engine because the reference positions them inconsistently
                 side = "right" if right else "left"
             self._last_lengths = None
+            # a batch whose rows differ in (spliced) length, or any left-padded one, is decoded as the reference does it: common cache
+            # slot, position_ids = sum(mask) - 1 and the padded token-level mask as the key mask (omchat_arch.py:61-70)
+            self._padded_batch = b > 1 and (side == "left" and min(lengths) < S or len(set(lengths)) > 1)
             logits_last, hidden = self.engine.prefill(inputs_embeds, lengths, want_hidden=bool(output_hidden_states), padding_side=side)
             logits_last = self.engine.full_logits(logits_last)        # vocab-parallel lm_head: gather the rank-local shards
             out = CausalLMOutputWithPast(logits_last.unsqueeze(1), KVHandle(self.engine, b))
@@ -151,7 +154,18 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             return out
         if input_ids.shape[1] != 1:
             raise ValueError("decode steps take exactly one token per sequence")
-        nxt, logits = self.engine.decode_step(input_ids[:, 0], want_logits=True)
+        if getattr(self, "_padded_batch", False):
+            if attention_mask is None:
+                raise ValueError("decode step of a padded batch: pass the token-level attention_mask (one more 1 per generated token) as HF "
+                                 "generate does, so that omchat_arch.py:61-70 can position the rows")
+            if position_ids is None:
+                # text-only call (no `images`): the reference leaves position_ids to Qwen2Model, which takes cache_position -- the common
+                # cache length -- for every row (modeling_qwen2.py:368-373), and the mask is the token-level one as passed
+                L = past_key_values.get_seq_length() if past_key_values is not None else max(self.engine.kv_lengths(input_ids.shape[0]))
+                position_ids = torch.full((input_ids.shape[0], 1), L, dtype=torch.long)
+            nxt, logits = self.engine.decode_step_masked(input_ids[:, 0], position_ids, attention_mask, want_logits=True)
+        else:
+            nxt, logits = self.engine.decode_step(input_ids[:, 0], want_logits=True)
         out = CausalLMOutputWithPast(self.engine.full_logits(logits).unsqueeze(1), past_key_values)
         out.next_tokens = nxt
         return out
@@ -183,14 +197,6 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
         pad = pad_token_id if pad_token_id is not None else self.generation_config.pad_token_id
         b = input_ids.shape[0]
-        if (max_new_tokens > 1 and attention_mask is not None and getattr(self.config, "tokenizer_padding_side", "right") == "left"
-                and bool(attention_mask.eq(0).any())):
-            # before any work is done: a left-padded batch can be prefilled (one token) but not decoded.  The reference pads the TOKEN-level
-            # mask with ones to the SPLICED cache length and sets position_ids = sum(mask) - 1 (omchat_arch.py:61-70): the padded rows are
-            # rotated to positions before their own prompt and attend to padded cache slots whose contents depend on the attention backend
-            # (tests/golden/leftpad_decode.npz: positions [40, 34] after a prefill that ended at 39)
-            raise NotImplementedError("generate() on a left-padded batch with max_new_tokens > 1: the reference positions these decode steps "
-                                      "inconsistently (omchat_arch.py:61-70); pad on the right (tokenizer_padding_side='right')")
         if streamer is not None:
             streamer.put(input_ids.cpu())
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True)
@@ -200,7 +206,8 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             # gathered [b, V] logits: first index wins an exact tie, the rule Engine.argmax / omchat_greedy implement (torch.argmax
             # does not promise it)
             lg = out.logits[:, 0]
-            tok = (lg == lg.max(dim=-1, keepdim=True).values).to(torch.int32).argmax(dim=-1).to(torch.int32)
+            idx = torch.arange(lg.shape[-1], device=lg.device)
+            tok = torch.where(lg == lg.max(dim=-1, keepdim=True).values, idx, lg.shape[-1]).min(dim=-1).values.to(torch.int32)
         # The KV cache is context-owned with a fixed capacity (the reference's DynamicCache grows without bound): generate as
         # many tokens as fit and stop cleanly, returning what was produced, instead of failing mid-stream with 'KV cache full'.
         room = self.engine.c.max_seq - max(self.engine.kv_lengths(b)) + 1
@@ -210,21 +217,46 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             max_new_tokens = max(room, 1)
         new = []
         done = torch.zeros(b, dtype=torch.bool)
+        # padded batch (rows of different spliced length, or left padding): every step goes through forward() with the token-level mask
+        # grown by one 1 per generated token and `images` passed -- exactly the calls HF generate makes on the reference, so that the
+        # decode branch of prepare_inputs_labels_for_multimodal (omchat_arch.py:61-70) positions and masks the rows
+        padded = getattr(self, "_padded_batch", False)
+        tok_mask = None
+        if padded:
+            tok_mask = (attention_mask if attention_mask is not None else torch.ones_like(input_ids)).to("cpu", torch.long)
+        # The host looks at every token (EOS, streamer, stopping criteria) as the reference's HF loop does -- but not with the GPU idle:
+        # token k is copied to pinned host memory behind an event, step k + 1 is enqueued, and only then the host waits for the event.
+        # When token k ends the generation the step that was already enqueued is taken back (omchat_kv_rewind).
+        stage = torch.empty((max_new_tokens, b), dtype=torch.int32).pin_memory()
         for step in range(max_new_tokens):
-            t_cpu = tok.cpu().to(torch.int64)                          # one host sync per token, like the reference's streamer/EOS check
+            last = step == max_new_tokens - 1
+            stage[step].copy_(tok.to(torch.int32), non_blocking=True)
+            evt = torch.cuda.Event(); evt.record()
+            ahead = None
+            if not last and not padded:
+                ahead, _ = self.engine.decode_step(tok)               # runs while the host handles token `step`
+            evt.synchronize()
+            t_cpu = stage[step].to(torch.int64)
             if pad is not None:
                 t_cpu = torch.where(done, torch.full_like(t_cpu, pad), t_cpu)
             new.append(t_cpu)
             if streamer is not None:
                 streamer.put(t_cpu)
             done = done | torch.tensor([int(x) in eos for x in t_cpu])
-            if bool(done.all()) or step == max_new_tokens - 1:
-                break
-            if stopping_criteria:                                     # HF StoppingCriteriaList semantics: any criterion stops the batch
+            stop = bool(done.all()) or last
+            if not stop and stopping_criteria:                        # HF StoppingCriteriaList semantics: any criterion stops the batch
                 so_far = torch.cat([input_ids.cpu(), torch.stack(new, dim=1)], dim=1)
-                if any(bool(c(so_far, None)) for c in stopping_criteria):
-                    break
-            tok, _ = self.engine.decode_step(tok)
+                stop = any(bool(c(so_far, None)) for c in stopping_criteria)
+            if stop:
+                if ahead is not None:
+                    self.engine.kv_rewind(b, 1)
+                break
+            if padded:
+                tok_mask = torch.cat([tok_mask, torch.ones(b, 1, dtype=torch.long)], dim=1)
+                o = self.forward(input_ids=t_cpu[:, None], attention_mask=tok_mask, past_key_values=out.past_key_values, images=images, use_cache=True)
+                tok = o.next_tokens
+            else:
+                tok = ahead
         if streamer is not None:
             streamer.end()
         return torch.cat([input_ids.cpu(), torch.stack(new, dim=1)], dim=1)

@@ -1,0 +1,165 @@
+"""Round-4 GPU tests (all through the C ABI):
+  * the fused attention + merge + o_proj launch of the batch-1 decode step (csrc/fused_decode.hip) gives the BITS of the three launches it
+    replaces, at the tiny geometries (ragged K chunk, one row per workgroup) and at the full Qwen2-7B width (28 / 4 heads, 3584 wide, two
+    rows per wave), across a key-tile boundary and at 3 k keys; no hand-off timed out
+  * padded batches decode as the REFERENCE computes them (omchat_arch.py:61-70): logits of the three steps after the right-
+    AND the left-padded prefill of tests/golden/leftpad_decode.npz (captured from the reference, eager CPU attention), through
+    omchat_decode_step_masked and through the drop-in generate()
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from conftest import golden
+from gpu_util import DT, TOL_DEEP, rnd, rel, sync
+from omchat_amd import synth, _lib
+from omchat_amd.config import tiny
+from omchat_amd.engine import Engine
+
+DTS = ["bf16", "f16"]
+T32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+def _decoder_sd(cfg, seed):
+    return {k: v for k, v in synth.state_dict(cfg, seed).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+
+
+GEOMS = {
+    # name: (config kwargs, prefill length, decode steps, max_seq)
+    "tiny_q4kv2": (dict(q_heads=4, kv_heads=2), 21, 6, 64),                       # K = 512: one chunk, one o_proj row per workgroup
+    "tiny_q7kv1_tile_edge": (dict(q_heads=7, kv_heads=1), 61, 8, 128),              # K = 896: ragged second chunk; the steps cross key 64
+    "qwen2_7b_width": (dict(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2), 3000, 5, 3072),   # 14 rows per workgroup, 47 splits
+    "qwen2_7b_width_short": (dict(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2), 70, 4, 128),
+}
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("geom", list(GEOMS))
+def test_fused_attn_oproj_gives_the_bits_of_the_three_launches(gpu_lib, dt, geom):
+    kw, S, steps, max_seq = GEOMS[geom]
+    cfg = tiny(**kw)
+    sd = _decoder_sd(cfg, 5)
+    H = cfg.text["hidden_size"]
+    x = rnd(torch.randn(1, S, H, generator=torch.Generator().manual_seed(3)) * 0.5, dt)
+    runs = {}
+    try:
+        for key in (1, 0):
+            _lib.check(gpu_lib.omchat_op_set_tuning(22, key))
+            e = Engine(cfg, dtype=dt, max_seq=max_seq, max_batch=1, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x)
+            tok, outs = torch.tensor([11]), []
+            for _ in range(steps):
+                nxt, lg = e.decode_step(tok, want_logits=True)
+                outs.append(lg.float().cpu().clone())
+                tok = nxt.cpu()
+            sync()
+            n, bits = e.fused_status()
+            assert bits == 0, f"a hand-off of the fused launch timed out: {bits:#x}"
+            assert n == (steps * cfg.text["num_hidden_layers"] if key else 0), (key, n)
+            runs[key] = outs
+            e.close()
+    finally:
+        _lib.check(gpu_lib.omchat_op_set_tuning(22, 1))
+    for s_, (a_, b_) in enumerate(zip(runs[1], runs[0])):
+        assert torch.isfinite(a_).all()
+        assert torch.equal(a_, b_), (geom, s_, rel(a_, b_))
+
+
+def test_fused_launch_is_repeatable_and_race_screened(gpu_lib):
+    """the same 40 decode steps twice at the full width: every step's logits bit-identical between the runs (a hand-off that let a
+    stale granule through, or a read before its sweep, would show up as a difference sooner or later), no time-out bit"""
+    cfg = tiny(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2)
+    sd = _decoder_sd(cfg, 6)
+    x = rnd(torch.randn(1, 500, 3584, generator=torch.Generator().manual_seed(4)) * 0.5, "bf16")
+    outs = []
+    e = Engine(cfg, dtype="bf16", max_seq=1024, max_batch=1, max_tiles=1, vision=False)
+    e.load_state_dict(sd)
+    for rep in range(2):
+        e.prefill(x)
+        tok, seq = torch.tensor([7]), []
+        for _ in range(40):
+            nxt, lg = e.decode_step(tok, want_logits=True)
+            seq.append(lg.float().cpu().clone())
+            tok = nxt.cpu()
+        outs.append(seq)
+    sync()
+    n, bits = e.fused_status()
+    assert bits == 0 and n == 2 * 40 * 2
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# padded batches, decoded as the reference does
+# ---------------------------------------------------------------------------------------------------------------------
+def _padded_model(dt, g):
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+    cfg = tiny()
+    e = Engine(cfg, dtype=dt, max_seq=128, max_batch=2, max_tiles=3)
+    e.load_state_dict(synth.state_dict(cfg, int(g["seed"])))
+    m = OmChatQwen2ForCausalLM(cfg.clone(), e)
+    feats = rnd(T32(g["feats"]), dt)
+    m.encode_images = lambda images: feats.to(DT[dt]).cuda()
+    return cfg, e, m
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_padded_batch_decode_steps_match_the_reference(gpu_lib, dt, side):
+    """omchat_arch.py:61-70 as HF generate drives it: after the padded prefill of two rows of different spliced length (40 and 19) the
+    reference appends every row's token at the common cache slot, rotates it to sum(mask) - 1 ([40, 34] at step 0) and masks with the
+    token-level mask padded with ones (hides slots 4..9 of row 1, exposes its padded slots).  Teacher-forced on the reference's ids, the
+    logits of all three steps must match the reference's (fp32 CPU, eager attention) for BOTH padding sides -- the left one needs the
+    prefill's fully masked rows to attend uniformly, as the eager backend does."""
+    g = golden("leftpad_decode")
+    cfg, e, m = _padded_model(dt, g)
+    m.config.mm["tokenizer_padding_side"] = side
+    ids, mask = torch.from_numpy(g["ids"]).long(), torch.from_numpy(g["mask"]).long()
+    dummy = torch.zeros(3, 3, 56, 56)
+    out = m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
+    kv = out.past_key_values
+    assert kv.get_seq_length() == int(g[side + "_S"])
+    tok_mask = mask
+    for k in range(int(g["steps"])):
+        nxt = torch.from_numpy(g[f"{side}_tok_{k}"]).long()
+        tok_mask = torch.cat([tok_mask, torch.ones(2, 1, dtype=torch.long)], dim=1)
+        # the host mirror of the decode branch returns the reference's own integers ...
+        _, pos_k, mask_k, _, emb_k, _ = m.prepare_inputs_labels_for_multimodal(nxt[:, None], None, tok_mask, kv, None, dummy)
+        assert emb_k is None and np.array_equal(pos_k.numpy(), g[f"{side}_dec_pos_{k}"]) and np.array_equal(mask_k.numpy(), g[f"{side}_dec_mask_{k}"])
+        # ... and the device step computed with them matches the reference's logits
+        o = m(input_ids=nxt[:, None], attention_mask=tok_mask, past_key_values=kv, images=dummy, use_cache=True)
+        sync()
+        ref = T32(g[f"{side}_logits_{k}"])
+        for i in range(2):
+            assert rel(o.logits[i, 0], ref[i]) < TOL_DEEP[dt], (side, k, i, rel(o.logits[i, 0], ref[i]))
+        assert kv.get_seq_length() == int(g[side + "_S"]) + k + 1
+    # the per-sequence step must not be mixed in after masked steps
+    with pytest.raises(ValueError, match="omchat_decode_step"):
+        e.decode_step(torch.tensor([1, 2]))
+    e.close()
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_generate_on_a_padded_batch_follows_the_reference_calls(gpu_lib, side):
+    """the drop-in generate() on the same batch: no refusal any more; its tokens are the argmax of the masked steps it drives (the same
+    calls HF generate makes on the reference), and where the reference's own top-1 / top-2 margin is clear of the 16-bit noise they are
+    the reference's ids"""
+    g = golden("leftpad_decode")
+    cfg, e, m = _padded_model("f16", g)
+    m.config.mm["tokenizer_padding_side"] = side
+    ids, mask = torch.from_numpy(g["ids"]).long(), torch.from_numpy(g["mask"]).long()
+    out = m.generate(ids, images=torch.zeros(3, 3, 56, 56), attention_mask=mask, max_new_tokens=4)
+    assert out.shape == (2, ids.shape[1] + 4)
+    new = out[:, ids.shape[1]:]
+    # token k + 1 is the argmax of the reference's step-k logits wherever that argmax is decisive
+    for k in range(3):
+        ref = T32(g[f"{side}_logits_{k}"])
+        top2 = torch.topk(ref, 2, dim=-1).values
+        for i in range(2):
+            same_path = all(int(new[i, j]) == int(g[f"{side}_tok_{j}"][i]) for j in range(k + 1))      # still teacher-consistent
+            if same_path and float(top2[i, 0] - top2[i, 1]) > 0.05:
+                assert int(new[i, k + 1]) == int(torch.argmax(ref[i])), (side, k, i)
+    e.close()

@@ -20,7 +20,13 @@ cp $(find $O/stats3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_configs
 cp $O/pmc_traffic_configs2.json $R/profiles/${TAG}_pmc_traffic_configs2.json
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_configs1.csv
 cp $(find $O/stats2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_configs2.csv
-cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json      # the bench line below reads the newest profiles/*pmc_traffic.json
+cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
+# the bench line below reads the files profiles/MANIFEST.json names (bench.py::pmc_traffic), never "the last one in sort order"
+python3 - <<PY
+import json
+json.dump({"note": "which committed PMC pass bench.py::pmc_traffic reads (written by tools/collect_profiles.sh with the files themselves)",
+           "pmc_traffic": "${TAG}_pmc_traffic.json", "pmc_traffic_configs2": "${TAG}_pmc_traffic_configs2.json"}, open("$R/profiles/MANIFEST.json", "w"), indent=1)
+PY
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rm -rf $O/stats $O/stats2 $O/stats3 $O/fetch $O/write $O/fetch2 $O/write2      # keep the folded summaries, drop the raw traces (gpurun_out is size-capped)
 head -c 600 $O/bench.json; echo; head -12 $O/pmc_summary.txt; head -8 $O/pmc_summary_configs2.txt
