@@ -126,9 +126,10 @@ int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* log
  * mixed after one prefill (they place the cache rows differently).  Synchronises the stream. */
 int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld,
                               float* logits, int32_t* next_tokens, void* stream);
-/* Batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch with in-launch hand-offs (csrc/fused_decode.hip; tuning
- * key 22 = 0 turns it off; same bits either way).  launches: how many such launches this context has issued; timeout_bits: sticky bits of
- * hand-offs that gave up after their wall-clock budget (0 = none; otherwise the affected steps' results are wrong).  Synchronises. */
+/* Batch-1 decode on one GPU runs each decoder layer as ONE launch with in-launch hand-offs (csrc/decode_layer.hip, tuning key 23; the
+ * attention + merge + o_proj part alone: csrc/fused_decode.hip, key 22; same bits as the separate launches either way).  launches: how many
+ * such launches this context has issued; timeout_bits: sticky bits of hand-offs that gave up after their wall-clock budget (0 = none;
+ * otherwise the affected steps' results are wrong).  Synchronises. */
 int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits);
 /* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
@@ -215,8 +216,10 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * one-batch form is faster, 4.9 vs 5.9 us);
  * key 21: column groups per head in the split-KV merge: 1 (default) = four workgroups per head beyond 256 partials (33 k keys: 21 -> ~7 us
  * per launch), 2 = also two workgroups per head for 65..256 partials (neutral), 0 = one workgroup per head;
- * key 22: 1 (default) = a batch-1 decode step on one GPU (16-bit weights and cache, <= 4096 keys) runs attention + merge + o_proj as one
- * launch (fused_decode.hip), 0 = as three launches (same bits)) */
+ * key 22: 1 = a batch-1 decode step on one GPU (16-bit weights and cache, <= 4096 keys) runs attention + merge + o_proj as one launch
+ * (fused_decode.hip), 0 (default) = as three launches (same bits);
+ * key 23: 1 (default) = such a step runs every decoder layer as ONE launch (decode_layer.hip: qkv, attention, merge, o_proj, gate|up, down
+ * with in-launch hand-offs), 0 = six launches per layer (same bits)) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -6,7 +6,7 @@ SRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomchat_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip", "fused_decode.hip"]
+SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip", "fused_decode.hip", "decode_layer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -36,7 +36,8 @@ def build(force=False, verbose=True):
 
     with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,-z,defs"]      # an undefined symbol fails the build here, not the first dlopen on the GPU box
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])

@@ -49,6 +49,10 @@ template <> __device__ __forceinline__ f16x8 widen8<f16>(u32x2 w) {
 // x = own chunk, o = partner chunk 64 elements away, first half gets -partner*sin, second half +partner*sin
 template <typename T>
 __device__ __forceinline__ typename V8<T>::type rope_chunk(typename V8<T>::type x, typename V8<T>::type o, const float* cs, bool second_half) {
+  // No contraction here: the reference rounds each product to the 16-bit type before the add (x * cos, rotate_half(x) * sin, then +).  The
+  // compiler narrows this expression to 16-bit fmul / fadd, and under the default -ffp-contract=fast it may then fuse one product into the
+  // add (an fma that skips that product's rounding) -- it did so in one kernel and not in another: 1-ulp differences in rotated q / k.
+#pragma clang fp contract(off)
   typename V8<T>::type r;
   const float sgn = second_half ? 1.f : -1.f;
 #pragma unroll

@@ -362,12 +362,16 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, 
   const float sgn = c < 8 ? -1.f : 1.f;             // rotate_half: first half gets -x2, second half +x1
   const float* cs = cos_sin + ((size_t)pt * 64 + (c & 7) * 8) * 2;
   v8 r;
+  {
+    // no contraction: each product is rounded to the 16-bit type before the add, as the reference does (attn_common.h: rope_chunk)
+#pragma clang fp contract(off)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
-    const float a = rnd<T>(tof(x[j]) * co);
-    const float b = rnd<T>(sgn * tof(o[j]) * si);
-    r[j] = fromf<T>(a + b);
+    for (int j = 0; j < 8; ++j) {
+      const float co = rnd<T>(cs[2 * j]), si = rnd<T>(cs[2 * j + 1]);
+      const float a = rnd<T>(tof(x[j]) * co);
+      const float b = rnd<T>(sgn * tof(o[j]) * si);
+      r[j] = fromf<T>(a + b);
+    }
   }
   if (h < nq) {
     // every lane of the 16-lane group has read both chunks before anyone writes (same wave, program order)

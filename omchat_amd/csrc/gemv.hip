@@ -471,7 +471,6 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 // epilogue.  Split-K slices are chunk ranges of 512 elements, <= RW_MAXC chunks each.
 // ---------------------------------------------------------------------------------------------------------
 int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
-int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 int g_gemv_no_xs = 0;          // tuning knob (key 11): 1 = batched decode never takes the x-stationary persistent kernel (A/B)
 constexpr int RW_MAXC = 8;
 // weight-only fp8 (OCP e4m3): 8 weights of a lane = 8 bytes.  gfx950's v_cvt_scalef32_pk_{bf16,f16}_fp8 widens two e4m3
@@ -1173,6 +1172,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 }  // namespace
 
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
+int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }

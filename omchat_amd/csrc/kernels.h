@@ -171,6 +171,28 @@ size_t fused_decode_ws_bytes(int q_heads);
 bool attn_oproj_fused_ok(const AttnDecodeArgs& a, int H, int qd);
 int launch_attn_oproj_fused(int dtype, const AttnDecodeArgs& a, const FusedDecodeArgs& f, hipStream_t s);
 void model_set_fuse_attn_oproj(int v);
+void model_set_decode_layer(int v);
+
+// batch-1 decode on one GPU (decode_layer.hip, round 4): ONE decoder layer -- the six launches qkv GEMV (+ input RMSNorm), split-KV
+// attention (+ RoPE, cache append), merge, o_proj (+ residual), gate|up GEMV (+ post-attention RMSNorm, SwiGLU), down_proj (+ residual) -- as
+// ONE launch with in-launch hand-offs; the same bits.  Weights row-major as the context holds them (wgu: gate / up interleaved in 16-row
+// blocks); x [H] is the residual stream, read and overwritten with the layer's output; kc / vc this layer's cache [kv_heads][cap][128] with
+// head stride k_sh elements; kv_len = keys after this step (the new token at kv_len - 1).  ws = decode_layer_ws_bytes(...) bytes of
+// zero-initialised device memory used by no other launch at the same time; epoch: a value no earlier launch on the same ws has used (never 0).
+struct DecodeLayerArgs {
+  const void *ln1, *ln2, *wqkv, *bqkv, *wo, *wgu, *wd;
+  void *kc, *vc; int64_t k_sh;
+  void* x;
+  int H, qd, kvd, It, q_heads, kv_heads, kv_len;
+  const float* rope; int rope_max;
+  float eps, scale;
+  void* ws; unsigned epoch;
+  unsigned* err; int timeout_ms;
+  void* dbg = nullptr;      // diagnostic build only
+};
+size_t decode_layer_ws_bytes(int q_heads, int H, int qd, int kvd, int It);
+bool decode_layer_ok(const DecodeLayerArgs& a);
+int launch_decode_layer(int dtype, const DecodeLayerArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ RoPE + KV append
 // qkv [rows, (nq + 2 nkv) * 128] post-bias; rotate q in place, write rotated k and raw v into the caches at

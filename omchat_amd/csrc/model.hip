@@ -69,6 +69,8 @@ struct Route {
 
 }  // namespace
 
+int g_decode_layer = 1;          // omchat_op_set_tuning key 23: 1 = batch-1 decode on one GPU runs each decoder layer as ONE launch (decode_layer.hip); 0 = six launches (same bits)
+void model_set_decode_layer(int v) { g_decode_layer = v; }
 int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
 void model_set_fuse_attn_oproj(int v) { g_fuse_attn_oproj = v; }
 int g_fuse_peer_norm = 1;      // omchat_op_set_tuning key 9: 0 = tensor-parallel decode keeps the all-reduce and the residual + RMSNorm as two launches (A/B)
@@ -145,6 +147,9 @@ struct omchat_ctx {
   unsigned* fd_err = nullptr;
   unsigned fd_epoch = 0;
   long n_fused_launches = 0;
+  // one-launch decoder layer (decode_layer.hip): granule buffers; shares the error word and the launch counter above
+  void* dl_ws = nullptr;
+  long n_layer_launches = 0;
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_start = nullptr;
   bool left_padded = false;
   // decode of a padded batch as the reference computes it (omchat_decode_step_masked): every row's cache holds pre_S + masked_steps slots;
@@ -375,6 +380,9 @@ int build(omchat_ctx* ctx) {
       TRY(ctx->alloc((void**)&ctx->fd_err, 64));
       OM_HIP(hipMemset(ctx->fd_ws, 0, fb));
       OM_HIP(hipMemset(ctx->fd_err, 0, 64));
+      const size_t lb = decode_layer_ws_bytes(c.t_heads, H, ctx->t_qdim, ctx->t_kvdim, It);
+      TRY(ctx->alloc(&ctx->dl_ws, lb));
+      OM_HIP(hipMemset(ctx->dl_ws, 0, lb));
     }
     TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
@@ -1134,6 +1142,21 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
     char* vc = (char*)ctx->vcache + (size_t)i * ctx->cache_layer_stride() * 2;
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
+    // batch 1, one GPU (round 4): the whole layer as ONE launch with in-launch hand-offs (decode_layer.hip; the same bits as the six
+    // launches below).  Eager steps only: the launch is tagged with a per-launch counter, which a captured graph would freeze.
+    if (g_decode_layer && n1 && exact_len && !f8 && !(ctx->fp8_kv && ctx->kv8_valid) && ctx->dl_ws) {
+      DecodeLayerArgs d{L.ln1, L.ln2, L.wqkv, L.bqkv, L.wo, L.wgu, L.wd, kc, vc, ctx->cache_sh(), x, H, qd, ctx->t_kvdim, It, c.t_heads, c.t_kv_heads, Lmax,
+                        ctx->rope, c.max_seq, c.t_eps, 0.08838834764831845f, ctx->dl_ws, ++ctx->fd_epoch, ctx->fd_err, 2000};
+      if (decode_layer_ok(d)) {
+        const bool mark_l = allow_prof && i == c.t_layers / 2;      // HIP-event bracket on one layer per token (bench.py roofline)
+        if (mark_l) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
+        TRY(launch_decode_layer(ctx->dt, d, s));
+        if (mark_l) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
+        ++ctx->n_layer_launches;
+        continue;
+      }
+      --ctx->fd_epoch;
+    }
     if (n1) {
       GemvArgs g = gemv_args(x, H, L.wqkv, H, ctx->tw_qkv, qkvd, 1, qkvd, L.bqkv, nullptr, EPI_NONE, 0, Q.wqkv, Q.sqkv, nullptr, false);
       g.norm_w = L.ln1; g.norm_eps = c.t_eps;
@@ -1423,7 +1446,7 @@ extern "C" int omchat_prof_read(omchat_ctx* ctx, int cat, double* total_ms, long
 // caller must not use them).  Synchronises the device.
 extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits) {
   OM_CHECK(ctx, "null ctx");
-  if (launches) *launches = ctx->n_fused_launches;
+  if (launches) *launches = ctx->n_fused_launches + ctx->n_layer_launches;
   if (timeout_bits) {
     *timeout_bits = 0;
     if (ctx->fd_err) OM_HIP(hipMemcpy(timeout_bits, ctx->fd_err, 4, hipMemcpyDeviceToHost));

@@ -31,12 +31,19 @@ GEOMS = {
     "tiny_q7kv1_tile_edge": (dict(q_heads=7, kv_heads=1), 61, 8, 128),              # K = 896: ragged second chunk; the steps cross key 64
     "qwen2_7b_width": (dict(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2), 3000, 5, 3072),   # 14 rows per workgroup, 47 splits
     "qwen2_7b_width_short": (dict(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2), 70, 4, 128),
+    "qwen2_7b_layer": (dict(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=18944, layers_t=1), 3580, 6, 3600),    # the real MLP width, 56 -> 57 splits
+    "tiny_long_mlp": (dict(q_heads=4, kv_heads=2, mlp_t=4608), 21, 5, 64),                                    # 9 activation chunks, 2 passes
 }
+
+
+MODES = {"layer": (1, 0), "attn_oproj": (0, 1), "six_launches": (0, 0)}      # tuning keys (23, 22)
 
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("geom", list(GEOMS))
-def test_fused_attn_oproj_gives_the_bits_of_the_three_launches(gpu_lib, dt, geom):
+def test_one_launch_layer_and_fused_attention_give_the_bits_of_the_six_launches(gpu_lib, dt, geom):
+    """decode_layer.hip (the whole layer as one launch, tuning key 23) and fused_decode.hip (attention + merge + o_proj as one launch, key
+    22) against the six launches per layer: the same model, free-running greedy steps, logits compared BIT FOR BIT at every step"""
     kw, S, steps, max_seq = GEOMS[geom]
     cfg = tiny(**kw)
     sd = _decoder_sd(cfg, 5)
@@ -44,8 +51,8 @@ def test_fused_attn_oproj_gives_the_bits_of_the_three_launches(gpu_lib, dt, geom
     x = rnd(torch.randn(1, S, H, generator=torch.Generator().manual_seed(3)) * 0.5, dt)
     runs = {}
     try:
-        for key in (1, 0):
-            _lib.check(gpu_lib.omchat_op_set_tuning(22, key))
+        for mode, (k23, k22) in MODES.items():
+            _lib.check(gpu_lib.omchat_op_set_tuning(23, k23)); _lib.check(gpu_lib.omchat_op_set_tuning(22, k22))
             e = Engine(cfg, dtype=dt, max_seq=max_seq, max_batch=1, max_tiles=1, vision=False)
             e.load_state_dict(sd)
             e.prefill(x)
@@ -57,20 +64,21 @@ def test_fused_attn_oproj_gives_the_bits_of_the_three_launches(gpu_lib, dt, geom
             sync()
             n, bits = e.fused_status()
             assert bits == 0, f"a hand-off of the fused launch timed out: {bits:#x}"
-            assert n == (steps * cfg.text["num_hidden_layers"] if key else 0), (key, n)
-            runs[key] = outs
+            assert n == (steps * cfg.text["num_hidden_layers"] if mode != "six_launches" else 0), (mode, n)
+            runs[mode] = outs
             e.close()
     finally:
-        _lib.check(gpu_lib.omchat_op_set_tuning(22, 1))
-    for s_, (a_, b_) in enumerate(zip(runs[1], runs[0])):
-        assert torch.isfinite(a_).all()
-        assert torch.equal(a_, b_), (geom, s_, rel(a_, b_))
+        _lib.check(gpu_lib.omchat_op_set_tuning(23, 1)); _lib.check(gpu_lib.omchat_op_set_tuning(22, 0))
+    for mode in ("layer", "attn_oproj"):
+        for s_, (a_, b_) in enumerate(zip(runs[mode], runs["six_launches"])):
+            assert torch.isfinite(a_).all()
+            assert torch.equal(a_, b_), (mode, geom, s_, rel(a_, b_))
 
 
 def test_fused_launch_is_repeatable_and_race_screened(gpu_lib):
-    """the same 40 decode steps twice at the full width: every step's logits bit-identical between the runs (a hand-off that let a
-    stale granule through, or a read before its sweep, would show up as a difference sooner or later), no time-out bit"""
-    cfg = tiny(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=1024, layers_t=2)
+    """the same 40 decode steps twice at the full width (one-launch layers): every step's logits bit-identical between the runs (a hand-off
+    that let a stale granule through, or a read before its sweep, would show up as a difference sooner or later), no time-out bit"""
+    cfg = tiny(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=2048, layers_t=2)
     sd = _decoder_sd(cfg, 6)
     x = rnd(torch.randn(1, 500, 3584, generator=torch.Generator().manual_seed(4)) * 0.5, "bf16")
     outs = []
