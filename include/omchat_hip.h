@@ -218,8 +218,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * per launch), 2 = also two workgroups per head for 65..256 partials (neutral), 0 = one workgroup per head;
  * key 22: 1 = a batch-1 decode step on one GPU (16-bit weights and cache, <= 4096 keys) runs attention + merge + o_proj as one launch
  * (fused_decode.hip), 0 (default) = as three launches (same bits);
- * key 23: 1 (default) = such a step runs every decoder layer as ONE launch (decode_layer.hip: qkv, attention, merge, o_proj, gate|up, down
- * with in-launch hand-offs), 0 = six launches per layer (same bits)) */
+ * key 23: 1 = such a step runs every decoder layer as ONE launch (decode_layer.hip: qkv, attention, merge, o_proj, gate|up, down
+ * with in-launch hand-offs; measured slower: 98 vs 91.5 us per layer), 0 (default) = six launches per layer (same bits)) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -21,6 +21,7 @@ struct GemvP {
   const float* w_scale;
   int y_packed;
   const void* norm_w; float norm_eps;      // whole-row batch-1 form: X is the RAW hidden row, normalised in registers (gemv_rows_norm_kernel)
+  unsigned* dyn;                           // gemv_rows_norm_dyn_kernel: 8 pool counters + 1 completion counter (one 256-byte line each), zero before the first launch
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
@@ -878,6 +879,178 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int p
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Dynamic form of the loop kernel (round 4).  The loop form deals every workgroup the same number of outputs and ends when the SLOWEST
+// workgroup ends -- and the eight XCDs of this chip do not stream at the same rate: with equal shares the gate|up phase of a CU took
+// 32.8 / 39.9 / 34.7 / 37.8 / 33.0 / 38.2 / 35.1 / 38.1 us by blockIdx % 8 (= the XCD group under round-robin dispatch; phase stamps of
+// tools/tune_layer.hip), i.e. the launch waits ~10 % for three of the XCDs.  Here the outputs are cut into chunks of DYN_CH and dealt by
+// atomic counters: DYN_POOLS pools (workgroup b starts at pool b % DYN_POOLS, so pool p is drained by one XCD group, p % 8), a wave takes
+// chunks from its pool and, when that is empty, from the following pools -- the fast XCDs end up with more chunks.  (Eight pools measured
+// 80 us per launch: a counter under streaming load answers ~15 tickets per us, not the 88 of an idle chip.)
+// Which wave computes an output changes nothing in its arithmetic: the same bits as the loop form.  Placement independent: the pool index
+// is only a shard label.  A chunk id is requested BEFORE the loads of the previous chunk are issued and used when that chunk is half
+// done, so the returning atomic never waits behind weight loads that are younger than the ones the wave needs next.
+// Counters: one 256-byte line each (nine counters in ONE line took 331 us per launch: the memory-side atomic unit serialises a line):
+// p.dyn[64 g] pool g, p.dyn[64 DYN_POOLS] finished waves; the last wave to finish zeroes them for the next launch on the same slot.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DYN_CH = 2;
+constexpr int DYN_POOLS = 64;      // work counters per launch, one 256-byte line each (a counter then sees ~4 grabs per us)
+template <typename T, int EPI, int NCH, bool F8>
+__global__ __launch_bounds__(256) void gemv_rows_norm_dyn_kernel(GemvP p) {
+  typedef typename V8<T>::type v8;
+  constexpr int R = EPI == EPI_SWIGLU ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T xs[NCH * 512];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
+  const int n_chunks = (n_out + DYN_CH - 1) / DYN_CH, pool_sz = (n_chunks + DYN_POOLS - 1) / DYN_POOLS;
+  typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
+  auto row_of = [&](int n, int r) { return EPI == EPI_SWIGLU ? 32 * (n >> 4) + (n & 15) + r * 16 : n; };
+  auto load_w = [&](wreg_t (&w)[R][NCH], int n) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t row = (size_t)row_of(n, r);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int k = c * 512 + lane * 8;
+        k = k < p.K ? k : 0;
+        if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + row * p.ldw + k));
+        else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + row * p.ldw + k));
+      }
+    }
+  };
+  // ---- chunk queue of this wave.  `pool` walks the eight pools starting at the workgroup's own; a raw ticket >= the pool's size means
+  // that pool is empty: move on (blocking grabs from then on: the tail of the launch).
+  int pool = 0;                                   // pools tried so far (DYN_POOLS = nothing left anywhere)
+  const int g0 = blockIdx.x % DYN_POOLS;
+  auto pool_count = [&](int g) { const int lo = g * pool_sz; return lo >= n_chunks ? 0 : (lo + pool_sz <= n_chunks ? pool_sz : n_chunks - lo); };
+  auto ticket = [&]() -> unsigned {               // one ticket from the current pool (returning atomic; wave-uniform through lane 0)
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(p.dyn + 64 * ((g0 + pool) % DYN_POOLS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  auto resolve = [&](unsigned t) -> int {         // ticket -> chunk id, or -1 when every pool is empty
+    int tk = (int)__builtin_amdgcn_readfirstlane(t);
+    for (;;) {
+      const int g = (g0 + pool) % DYN_POOLS;
+      if (tk < pool_count(g)) return g * pool_sz + tk;
+      if (++pool >= DYN_POOLS) return -1;
+      tk = (int)__builtin_amdgcn_readfirstlane(ticket());
+    }
+  };
+  // ---- 1. the first two chunks: tickets first, then the first chunk's loads as soon as its id is known
+  int cur = resolve(ticket());
+  unsigned nxt_t = cur >= 0 ? ticket() : 0u;
+  wreg_t wa[R][NCH], wb[R][NCH], wc[R][NCH];
+  auto out_ok = [&](int chunk, int i) { return chunk >= 0 && chunk * DYN_CH + i < n_out; };
+  if (out_ok(cur, 0)) load_w(wa, cur * DYN_CH);
+  if (out_ok(cur, 1)) load_w(wb, cur * DYN_CH + 1);
+  // ---- 2. the norm, shared by the workgroup (gemv_rows_norm_kernel step 2; four-wave order)
+  constexpr int MC = (NCH + 3) / 4;
+  rw_u32x4 xq[MC], nq[MC];
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i, k = c * 512 + lane * 8;
+    const rw_u32x4 z = {0u, 0u, 0u, 0u};
+    const bool ok = c < NCH && k < p.K;
+    xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const v8 xv = __builtin_bit_cast(v8, xq[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = tof(xv[j]); ss += v * v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) red[wave] = ss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float inv = rsqrtf((((red[0] + red[1]) + red[2]) + red[3]) / (float)p.K + p.norm_eps);
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + 4 * i;
+    if (c < NCH) {
+      const v8 xv = __builtin_bit_cast(v8, xq[i]), wv = __builtin_bit_cast(v8, nq[i]);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(tof(xv[j]) * inv));
+      *reinterpret_cast<v8*>(xs + c * 512 + lane * 8) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rw_u32x4 xr[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const rw_u32x4*>(xs + c * 512 + lane * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  auto finish = [&](wreg_t (&w)[R][NCH], int n) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (F8) a = rw_dot8_fp8<T>(w[r][c], xr[c], a);
+        else a = rw_dot8<T>(w[r][c], xr[c], a);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if constexpr (F8) a *= p.w_scale[row_of(n, r)];
+      acc[r] = a;
+    }
+    if (lane == 0) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        const float gt = rnd<T>(acc[0]), up = rnd<T>(acc[R - 1]);
+        ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
+      } else {
+        const float y = acc[0] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+        if (p.out_f32) ((float*)p.Y)[n] = y;
+        else ((T*)p.Y)[n] = fromf<T>(y);
+      }
+    }
+  };
+  // ---- 3. chunks of two outputs through three register buffers: while chunk j is computed, the first output of chunk j + 1 is in flight
+  // (its id was requested before chunk j's loads were issued), and the ticket of chunk j + 2 goes out before chunk j + 1's loads
+  while (cur >= 0) {
+    const int nxt = resolve(nxt_t);               // usually long answered; blocking only when a pool ran dry
+    if (nxt >= 0) nxt_t = ticket();
+    if (out_ok(nxt, 0)) load_w(wc, nxt * DYN_CH);
+    finish(wa, cur * DYN_CH);
+    if (out_ok(nxt, 1)) load_w(wa, nxt * DYN_CH + 1);
+    if (out_ok(cur, 1)) finish(wb, cur * DYN_CH + 1);
+    cur = nxt;
+    if (cur < 0) break;
+    // the roles of the buffers rotate: (wa, wb, wc) held (cur.0, cur.1, nxt.0); now cur.0 sits in wc and cur.1 in wa
+    const int nx2 = resolve(nxt_t);
+    if (nx2 >= 0) nxt_t = ticket();
+    if (out_ok(nx2, 0)) load_w(wb, nx2 * DYN_CH);
+    finish(wc, cur * DYN_CH);
+    if (out_ok(nx2, 1)) load_w(wc, nx2 * DYN_CH + 1);
+    if (out_ok(cur, 1)) finish(wa, cur * DYN_CH + 1);
+    cur = nx2;
+    if (cur < 0) break;
+    // now cur.0 sits in wb and cur.1 in wc
+    const int nx3 = resolve(nxt_t);
+    if (nx3 >= 0) nxt_t = ticket();
+    if (out_ok(nx3, 0)) load_w(wa, nx3 * DYN_CH);
+    finish(wb, cur * DYN_CH);
+    if (out_ok(nx3, 1)) load_w(wb, nx3 * DYN_CH + 1);
+    if (out_ok(cur, 1)) finish(wc, cur * DYN_CH + 1);
+    cur = nx3;                                    // cur.0 in wa, cur.1 in wb again
+  }
+  // ---- 4. the last wave of the launch zeroes the counters for the next launch on this slot
+  if (lane == 0) {
+    const unsigned done = __hip_atomic_fetch_add(p.dyn + 64 * DYN_POOLS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x * 4u - 1u) {
+      for (int i = 0; i <= DYN_POOLS; ++i) __hip_atomic_store(p.dyn + 64 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Whole-row GEMV for LONG K without split-K (round 3; batch 1: down_proj, K = 18944): y[n] = resid[n] + T(sum_k W[n][k] x[k]), in place.
 // The split-K form leaves fp32 slices that a residual + RMSNorm launch must sum; here a workgroup stages x (37 KB) in LDS once, every
 // wave streams whole rows in passes of 8 chunks of 512 (weights of pass p + 1 in flight under the dot products of pass p) and lane 0
@@ -970,6 +1143,7 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
 }
 
 int g_gemv_rows_balance = 1;   // omchat_op_set_tuning key 17: 1 = one-row-per-wave launches whose rows deal evenly to 2 workgroups per CU take N / (2 CUs) waves per workgroup (o_proj 7, qkv 9)
+int g_gemv_dyn = 0;            // omchat_op_set_tuning key 24: 1 = the loop form takes its outputs from atomic work counters when the caller provides them (gemv_rows_norm_dyn_kernel)
 int g_gemv_norm_loop = 1;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
 
 template <typename T, int EPI, int RR, bool F8, int NCH>
@@ -979,6 +1153,11 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
     // measured (profiles/r03_p): gate|up 44.3 -> 42.8 us (2.778 -> 2.738 ms per token); qkv 9.2 us either way; e4m3 gate|up 0.6 % slower
     const bool want = EPI == EPI_SWIGLU ? (g_gemv_norm_loop & (F8 ? 4 : 1)) : (p.N < 32768 ? (g_gemv_norm_loop & 2) : (g_gemv_norm_loop & 8));
     const int n_cu = device_cus();
+    // dynamic form: the outputs dealt by atomic counters instead of equal shares (the XCDs do not stream at the same rate); tuning key 24
+    if (want && p.dyn && g_gemv_dyn && n_out >= 8 * n_cu) {
+      hipLaunchKernelGGL((gemv_rows_norm_dyn_kernel<T, EPI, NCH, F8>), dim3(2 * n_cu), dim3(256), 0, s, p);
+      return;
+    }
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
       hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per);
@@ -1061,7 +1240,8 @@ void launch_rows(const GemvP& p, hipStream_t s) {
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed, a.norm_w, a.norm_eps};
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed, a.norm_w, a.norm_eps,
+          (unsigned*)a.dyn_ctr};
   if (a.norm_w && a.x_packed) { omchat_set_error("launch_gemv: the in-register RMSNorm is a batch-1 form (row-major x)"); return 1; }
   if (a.x_packed) {
     // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
@@ -1175,6 +1355,7 @@ void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
+void gemv_set_dyn(int v) { g_gemv_dyn = v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }
 
 namespace {

@@ -58,6 +58,9 @@ struct GemvArgs {
   int y_packed;             // EPI_SWIGLU only: write Y in the packed x layout of the consumer (same NB; ldy ignored)
   // b == 1, ksplit <= 1, whole-row form: X is the RAW hidden row and y = epi(W RMSNorm(X; norm_w, norm_eps)) -- the norm runs in registers
   const void* norm_w; float norm_eps;
+  // optional: 65 x 64 unsigned (65 lines of 256 bytes) of ZEROED device memory owned by the caller and used by no other launch at the same time (the kernel leaves them
+  // zero): the loop form of a norm GEMV then takes its outputs from atomic work counters (gemv_rows_norm_dyn_kernel) instead of equal shares
+  void* dyn_ctr = nullptr;
 };
 // row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
@@ -121,6 +124,7 @@ void attn_set_klds(int v);
 void attn_set_merge_mid_min(int v);
 void attn_set_merge_dg(int v);
 void gemv_set_norm_loop(int v);
+void gemv_set_dyn(int v);
 void gemv_set_rows_balance(int v);
 void gemv_set_no_xs(int v);
 

@@ -69,7 +69,7 @@ struct Route {
 
 }  // namespace
 
-int g_decode_layer = 1;          // omchat_op_set_tuning key 23: 1 = batch-1 decode on one GPU runs each decoder layer as ONE launch (decode_layer.hip); 0 = six launches (same bits)
+int g_decode_layer = 0;          // omchat_op_set_tuning key 23: 1 = batch-1 decode on one GPU runs each decoder layer as ONE launch (decode_layer.hip); 0 = six launches (same bits)
 void model_set_decode_layer(int v) { g_decode_layer = v; }
 int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
 void model_set_fuse_attn_oproj(int v) { g_fuse_attn_oproj = v; }
@@ -150,6 +150,7 @@ struct omchat_ctx {
   // one-launch decoder layer (decode_layer.hip): granule buffers; shares the error word and the launch counter above
   void* dl_ws = nullptr;
   long n_layer_launches = 0;
+  unsigned* dyn_ctr = nullptr;      // [layers][65 * 64] work counters of the dynamic gate|up GEMV (gemv_rows_norm_dyn_kernel), zero between launches
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_start = nullptr;
   bool left_padded = false;
   // decode of a padded batch as the reference computes it (omchat_decode_step_masked): every row's cache holds pre_S + masked_steps slots;
@@ -383,6 +384,8 @@ int build(omchat_ctx* ctx) {
       const size_t lb = decode_layer_ws_bytes(c.t_heads, H, ctx->t_qdim, ctx->t_kvdim, It);
       TRY(ctx->alloc(&ctx->dl_ws, lb));
       OM_HIP(hipMemset(ctx->dl_ws, 0, lb));
+      TRY(ctx->alloc((void**)&ctx->dyn_ctr, (size_t)c.t_layers * 65 * 64 * 4));
+      OM_HIP(hipMemset(ctx->dyn_ctr, 0, (size_t)c.t_layers * 65 * 64 * 4));
     }
     TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
@@ -1226,6 +1229,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (n2) {
       GemvArgs g = gemv_args(x, H, L.wgu, H, ctx->tw_act, It, 1, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, Q.wgu, Q.sgu, nullptr, false);
       g.norm_w = L.ln2; g.norm_eps = c.t_eps;
+      if (ctx->dyn_ctr && !ctx->graph_on) g.dyn_ctr = ctx->dyn_ctr + (size_t)i * 65 * 64;
       TRY(launch_gemv(ctx->dt, g, s));
     } else {
       TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));

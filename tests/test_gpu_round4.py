@@ -68,7 +68,7 @@ def test_one_launch_layer_and_fused_attention_give_the_bits_of_the_six_launches(
             runs[mode] = outs
             e.close()
     finally:
-        _lib.check(gpu_lib.omchat_op_set_tuning(23, 1)); _lib.check(gpu_lib.omchat_op_set_tuning(22, 0))
+        _lib.check(gpu_lib.omchat_op_set_tuning(23, 0)); _lib.check(gpu_lib.omchat_op_set_tuning(22, 0))
     for mode in ("layer", "attn_oproj"):
         for s_, (a_, b_) in enumerate(zip(runs[mode], runs["six_launches"])):
             assert torch.isfinite(a_).all()
@@ -82,22 +82,26 @@ def test_fused_launch_is_repeatable_and_race_screened(gpu_lib):
     sd = _decoder_sd(cfg, 6)
     x = rnd(torch.randn(1, 500, 3584, generator=torch.Generator().manual_seed(4)) * 0.5, "bf16")
     outs = []
-    e = Engine(cfg, dtype="bf16", max_seq=1024, max_batch=1, max_tiles=1, vision=False)
-    e.load_state_dict(sd)
-    for rep in range(2):
-        e.prefill(x)
-        tok, seq = torch.tensor([7]), []
-        for _ in range(40):
-            nxt, lg = e.decode_step(tok, want_logits=True)
-            seq.append(lg.float().cpu().clone())
-            tok = nxt.cpu()
-        outs.append(seq)
-    sync()
-    n, bits = e.fused_status()
-    assert bits == 0 and n == 2 * 40 * 2
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)
-    e.close()
+    _lib.check(gpu_lib.omchat_op_set_tuning(23, 1))
+    try:
+        e = Engine(cfg, dtype="bf16", max_seq=1024, max_batch=1, max_tiles=1, vision=False)
+        e.load_state_dict(sd)
+        for rep in range(2):
+            e.prefill(x)
+            tok, seq = torch.tensor([7]), []
+            for _ in range(40):
+                nxt, lg = e.decode_step(tok, want_logits=True)
+                seq.append(lg.float().cpu().clone())
+                tok = nxt.cpu()
+            outs.append(seq)
+        sync()
+        n, bits = e.fused_status()
+        assert bits == 0 and n == 2 * 40 * 2
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_)
+        e.close()
+    finally:
+        _lib.check(gpu_lib.omchat_op_set_tuning(23, 0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -171,3 +175,32 @@ def test_generate_on_a_padded_batch_follows_the_reference_calls(gpu_lib, side):
             if same_path and float(top2[i, 0] - top2[i, 1]) > 0.05:
                 assert int(new[i, k + 1]) == int(torch.argmax(ref[i])), (side, k, i)
     e.close()
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_dynamic_gate_up_gives_the_bits_of_the_equal_share_form(gpu_lib, dt):
+    """gemv_rows_norm_dyn_kernel (tuning key 24: the gate|up outputs of a batch-1 step dealt by atomic work counters, because the XCDs do not
+    stream at the same rate) against the loop form with equal shares: the same bits at every step, and the counters are back at zero after
+    every launch (the second, third ... step would otherwise start from a drained pool and produce garbage or hang)"""
+    cfg = tiny(q_heads=28, kv_heads=4, hidden_t=3584, mlp_t=18944, layers_t=2)
+    sd = _decoder_sd(cfg, 8)
+    x = rnd(torch.randn(1, 100, 3584, generator=torch.Generator().manual_seed(5)) * 0.5, dt)
+    runs = {}
+    try:
+        for key in (1, 0):
+            _lib.check(gpu_lib.omchat_op_set_tuning(24, key))
+            e = Engine(cfg, dtype=dt, max_seq=256, max_batch=1, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x)
+            tok, outs = torch.tensor([3]), []
+            for _ in range(12):
+                nxt, lg = e.decode_step(tok, want_logits=True)
+                outs.append(lg.float().cpu().clone())
+                tok = nxt.cpu()
+            sync()
+            runs[key] = outs
+            e.close()
+    finally:
+        _lib.check(gpu_lib.omchat_op_set_tuning(24, 1))
+    for s_, (a_, b_) in enumerate(zip(runs[1], runs[0])):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_), (s_, rel(a_, b_))
