@@ -126,10 +126,11 @@ int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* log
  * mixed after one prefill (they place the cache rows differently).  Synchronises the stream. */
 int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld,
                               float* logits, int32_t* next_tokens, void* stream);
-/* Batch-1 decode on one GPU runs each decoder layer as ONE launch with in-launch hand-offs (csrc/decode_layer.hip, tuning key 23; the
- * attention + merge + o_proj part alone: csrc/fused_decode.hip, key 22; same bits as the separate launches either way).  launches: how many
- * such launches this context has issued; timeout_bits: sticky bits of hand-offs that gave up after their wall-clock budget (0 = none;
- * otherwise the affected steps' results are wrong).  Synchronises. */
+/* Experimental one-launch forms of the batch-1 decode layer (default OFF, measured slower than the six launches; DESIGN.md section 6,
+ * round 4): with tuning key 23 a decoder layer is ONE launch with in-launch hand-offs (csrc/decode_layer.hip), with key 22 attention +
+ * merge + o_proj are one launch (csrc/fused_decode.hip); same bits as the separate launches either way.  launches: how many such launches
+ * this context has issued; timeout_bits: sticky bits of hand-offs that gave up after their wall-clock budget (0 = none; otherwise the
+ * affected steps' results are wrong).  Synchronises. */
 int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits);
 /* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
@@ -219,7 +220,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 22: 1 = a batch-1 decode step on one GPU (16-bit weights and cache, <= 4096 keys) runs attention + merge + o_proj as one launch
  * (fused_decode.hip), 0 (default) = as three launches (same bits);
  * key 23: 1 = such a step runs every decoder layer as ONE launch (decode_layer.hip: qkv, attention, merge, o_proj, gate|up, down
- * with in-launch hand-offs; measured slower: 98 vs 91.5 us per layer), 0 (default) = six launches per layer (same bits)) */
+ * with in-launch hand-offs; measured slower: 98 vs 91.5 us per layer), 0 (default) = six launches per layer (same bits);
+ * key 24: 1 = the batch-1 gate|up GEMV takes its shares from per-XCD work queues (gemv_rows_norm_dyn_kernel; eager steps only; same
+ * bits; measured 80-331 us against 45: the returning atomic drains the wave's load ring), 0 (default) = equal static shares) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */
