@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
         const int key = key0 + i * 4 + fg;
         const bool fresh = fuse && key >= pp;
         const T* src = fresh ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
-        kv[i] = ld8<T>(src + fc * 8);
+        kv[i] = ld8s<T>(src + fc * 8);
       }
       if (fuse && key0 + KV_TILE > pp) {      // only the tile that owns the new position (uniform): rotate the fresh row, append it
         const float* cs = p.rope + ((size_t)pt * 64 + (fc & 7) * 8) * 2;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
         kfresh[kt] = fuse && key >= pp;
         const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) kv[kt * 4 + ds] = ld8<T>(src + ds * 32 + fg * 8);
+        for (int ds = 0; ds < 4; ++ds) kv[kt * 4 + ds] = ld8s<T>(src + ds * 32 + fg * 8);
       }
       if (fuse && key0 + KV_TILE > pp) {      // only the tile that owns the new position (uniform)
 #pragma unroll
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
       const int key = key0 + i * 4 + fg;
       const bool fresh = fuse && key >= pp;
       const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
-      kv[i] = ld8<T>(src + fc * 8);
+      kv[i] = ld8s<T>(src + fc * 8);
     }
     float mx = NEG_BIG;
 #pragma unroll
@@ -768,6 +768,218 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
         const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
       }
+  }
+  const float l = sum_xor32(sum_xor16(l_run));
+  if (fc < n_rep) {
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
+    if (fg == 0) { wsb[128] = m_run; wsb[129] = l; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched decode attention with the K / V tiles brought in by LDS-DMA (round 4; tuning key 25).  attn_decode_multi_kernel above walks its
+// tiles with TWO exposed memory round trips per tile (K -> S^T -> V -> PV: K and V share one register block because both next to the
+// running output do not fit), 7.5 waves per CU at b = 32: by its own timeline the launch is 4 tiles x 2 round trips of ~5 us.  Here the
+// tiles never touch the vector registers on their way in: one wave per workgroup owns a two-stage LDS ring of 32-key tiles (stage = K
+// 8 KiB + V 8 KiB, written by global_load_lds_dwordx4 in the swizzled images the operand reads want: the swizzle is applied to the
+// per-lane SOURCE address, the DMA destination is lane-linear), tile t + 1 (and, once a stage is free, t + 2) is in flight while tile t is
+// computed, and four such workgroups per CU keep up to 128 KB per CU on the way -- what the weight-streaming GEMVs hold.  A 32-key tile is
+// one K = 32 step of the PV MFMA and two S^T fragments; running max / sum per tile as in the multi-tile kernel; the partials, the merge
+// and the fused RoPE + append (the split that owns the new position patches the rotated key row into its LDS image and appends k / v)
+// are the same.  p.tpw = 32-key tiles per split.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DMA_TILE = 32;
+template <typename T, int NST, bool NT = (OMCHAT_KV_NT != 0)>
+__global__ __launch_bounds__(64) void attn_decode_dma_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(256))) char dsm[];      // NST stages x (K 8 KiB | V 8 KiB)
+  const int lane = threadIdx.x, fc = lane & 15, fg = lane >> 4;
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  const int key_base = split * DMA_TILE * p.tpw;
+  float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
+  if (key_base >= kv_len) {                   // empty split (uniform): neutral partial
+    if (fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
+    return;
+  }
+  const int left = (kv_len - key_base + DMA_TILE - 1) / DMA_TILE;
+  const int nt = left < p.tpw ? left : p.tpw;                     // tiles this wave walks (uniform)
+  const bool fuse = p.rope != nullptr;
+  const int pp = kv_len - 1;
+  const int pt = pp < p.rope_max ? pp : p.rope_max - 1;
+  const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
+  const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
+
+  // tile t -> stage st: lane (fg, fc) brings LDS chunk position fc of tile row 4 i + fg, i.e. source chunk fc ^ swizzle(row)
+  // p.causal (unused by decode) = 1: every wave starts at a different tile of its split and wraps around (experiment: do the lock-step
+  // streams of a launch camp on the same HBM channels?)
+  const int rot = p.causal ? (b * 5 + kvh * 3 + split * 7) % nt : 0;
+  auto issue = [&](int t_, int st) {
+    const int t = t_ + rot < nt ? t_ + rot : t_ + rot - nt;
+    const int key0 = key_base + t * DMA_TILE;
+    char* kb = dsm + st * 16384;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + fg, key = key0 + row;
+      const bool fresh = fuse && key >= pp;                         // not in the cache yet (or clamped onto it): the raw new row, finite
+      const int64_t kc = key < kv_len ? key : kv_len - 1;
+      const T* ks = (fresh ? kn : Kg + kc * p.k_sr) + ((fc ^ (row & 15)) << 3);
+      const T* vs = (fresh ? vn : Vg + kc * p.v_sr) + ((fc ^ ((row & 7) << 1)) << 3);
+      if (NT) {      // streamed once: non-temporal (the weight-streaming GEMVs load theirs the same way)
+        __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(kb + i * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(kb + 8192 + i * 1024), 16, 0, 2);
+      } else {
+        __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(kb + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(kb + 8192 + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // q, the RoPE table row and (in the split that owns the new position) the raw new rows are requested FIRST: vector memory returns in
+  // order, so behind the tiles they would not be usable before both stages have landed
+  frag_t qf[4];
+  const bool owner = fuse && pp >= key_base && pp < key_base + nt * DMA_TILE;      // uniform
+  frag_t kown = {}, koth = {}, vnew = {};
+  float csq[2][16], cso[16];
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
+    if (fuse) {
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const f32x4* cs = reinterpret_cast<const f32x4*>(p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) { const f32x4 v = cs[q4]; csq[ds][4 * q4] = v[0]; csq[ds][4 * q4 + 1] = v[1]; csq[ds][4 * q4 + 2] = v[2]; csq[ds][4 * q4 + 3] = v[3]; }
+      }
+    }
+    if (owner) {
+      kown = ld8<T>(kn + fc * 8); koth = ld8<T>(kn + (fc ^ 8) * 8); vnew = ld8<T>(vn + fc * 8);
+      const f32x4* cs = reinterpret_cast<const f32x4*>(p.rope + ((size_t)pt * 64 + (fc & 7) * 8) * 2);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) { const f32x4 v = cs[q4]; cso[4 * q4] = v[0]; cso[4 * q4 + 1] = v[1]; cso[4 * q4 + 2] = v[2]; cso[4 * q4 + 3] = v[3]; }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NST; ++i)
+    if (i < nt) issue(i, i);
+  __builtin_amdgcn_sched_barrier(0);
+  if (fuse) {
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const frag_t lo = qf[ds], hi = qf[ds + 2];
+      qf[ds] = rope_chunk<T>(lo, hi, csq[ds], false);
+      qf[ds + 2] = rope_chunk<T>(hi, lo, csq[ds], true);
+    }
+  }
+  frag_t knew = {};
+  if (owner) {      // chunk fc of the new rows in every lane group (only group 0 writes); rotate-half partner = chunk fc ^ 8
+    knew = rope_chunk<T>(kown, koth, cso, fc >= 8);
+    if (fg == 0) {
+      st8<T>((T*)p.k_cache_w + b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr + fc * 8, knew);
+      st8<T>((T*)p.v_cache_w + b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr + fc * 8, vnew);
+    }
+  }
+
+  f32x4 o[8];
+#pragma unroll
+  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;
+  const int vswz = ((vrow_lo & 7) << 1);
+
+  for (int t = 0; t < nt; ++t) {
+    const int st = t % NST;
+    const int key0 = key_base + (t + rot < nt ? t + rot : t + rot - nt) * DMA_TILE;
+    const char* kb = dsm + st * 16384;
+    const char* vb = kb + 8192;
+    // tile t has landed when at most the 16 DMA instructions of each tile issued behind it are outstanding
+    {
+      const int behind = nt - 1 - t < NST - 1 ? nt - 1 - t : NST - 1;      // uniform
+      if (behind >= 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      else if (behind == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (behind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (owner && pp >= key0 && pp < key0 + DMA_TILE) {             // uniform: the rotated key row replaces the raw one in the image
+      const int r = pp - key0;
+      if (fg == 0) *reinterpret_cast<frag_t*>(dsm + st * 16384 + r * 256 + ((fc ^ (r & 15)) << 4)) = knew;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    f32x4 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      frag_t kf[4];
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf[ds] = *reinterpret_cast<const frag_t*>(kb + (kt * 16 + fc) * 256 + (((ds * 4 + fg) ^ fc) << 4));
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) s[kt] = mfma16(kf[ds], qf[ds], s[kt]);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? s[kt][r] : NEG_BIG;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = max_xor32(max_xor16(mx));
+    if (t > 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      l_run *= alpha;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) o[dn] *= alpha;
+      mx = m_new;
+    }
+    m_run = mx;
+    const float mc = mx * p.c;
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      e[j] = __builtin_amdgcn_exp2f(fmaf(s[j >> 2][j & 3], p.c, -mc));
+      l_run += e[j];
+    }
+    const frag_t pf = __builtin_convertvector(e, frag_t);
+    // the transposed reads go out as inline assembly: hipcc puts an s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 it emits itself
+    // while an LDS-DMA is outstanding (the intrinsic carries no memory operand to disambiguate), which would drain the ring at every tile
+    s16x4 vlo[8], vhi[8];
+    {
+      const unsigned vbase = (unsigned)(size_t)(lds_s16x4_ptr)(vb + vrow_lo * 256 + 8 * (tp & 1));
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) {
+        const unsigned addr = vbase + ((unsigned)((2 * dn + (tp >> 1)) ^ vswz) << 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[dn]) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vhi[dn]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vlo[4]), "+v"(vlo[5]), "+v"(vlo[6]), "+v"(vlo[7]),
+                     "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3]), "+v"(vhi[4]), "+v"(vhi[5]), "+v"(vhi[6]), "+v"(vhi[7]));
+    }
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 cat = __builtin_shufflevector(vlo[dn], vhi[dn], 0, 1, 2, 3, 4, 5, 6, 7);
+      o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf, o[dn]);
+    }
+    // every LDS read of this stage has returned (its MFMAs are issued): the stage takes tile t + NST
+    if (t + NST < nt) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue(t + NST, st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   const float l = sum_xor32(sum_xor16(l_run));
   if (fc < n_rep) {
@@ -957,6 +1169,13 @@ int g_merge_dg = 1;       // omchat_op_set_tuning key 21: split-KV merge, column
 void attn_set_merge_dg(int v) { g_merge_dg = v; }
 int g_merge_mid_min = 64;   // omchat_op_set_tuning key 19: split-KV merges with more partials per head than this take the 512-thread form
 void attn_set_merge_mid_min(int v) { g_merge_mid_min = v < 1 ? 1 : v; }
+int g_attn_dma = 1;     // omchat_op_set_tuning key 25: 1 = large-grid batched decode attention takes the LDS-DMA ring form (attn_decode_dma_kernel), 0 = attn_decode_multi_kernel
+void attn_set_dma(int v) { g_attn_dma = v; }
+int g_attn_dma_slots = 4;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
+int g_attn_dma_stages = 2;
+void attn_set_dma_slots(int v) { g_attn_dma_slots = (v & 255) < 1 ? 1 : (v & 255); const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
+int g_attn_dma_rot = 0;       // key 27 (experiment): rotated tile order per wave
+void attn_set_dma_rot(int v) { g_attn_dma_rot = v; }
 int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
 void attn_set_klds(int v) { g_attn_klds = v; }
 int g_attn_v2 = 1;      // omchat_op_set_tuning key 8: 0 = first-generation 16x16x32 prefill kernel (A/B)
@@ -1060,7 +1279,18 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   int tpw = kv8 ? 1 : (waves1 >= 6144 ? 4 : (waves1 >= 3072 ? 2 : 1));
   if (g_attn_tpw > 0 && !kv8) tpw = g_attn_tpw;
   if (a.key_mask) tpw = 1;      // the masked form exists for the one-tile kernel only (a rare mode)
-  const int nsplit = cdiv(a.L, KV_TILE * tpw);
+  // large grids (round 4): the LDS-DMA ring form.  One wave per workgroup, 32 KiB of LDS: g_attn_dma_slots of them are resident per CU,
+  // and the split count is chosen so that the launch is (at most) one resident round of equal splits of 32-key tiles
+  const bool dma = tpw > 1 && g_attn_dma && !kv8 && a.k_sr == 128 && a.v_sr == 128;
+  int split_keys = KV_TILE * tpw;
+  if (dma) {
+    const int slots = g_attn_dma_slots * device_cus(), pairs = a.kv_heads * a.batch;
+    const int tiles = cdiv(a.L, DMA_TILE);
+    const int ns_target = std::max(1, slots / pairs);
+    tpw = std::max(2, cdiv(tiles, ns_target));      // >= 2 tiles of 32 keys: never more partials than the workspace holds (one per 64 keys)
+    split_keys = DMA_TILE * tpw;
+  }
+  const int nsplit = cdiv(a.L, split_keys);
   OM_CHECK(a.ws && a.ws_bytes >= attn_decode_ws_bytes(a.batch, a.q_heads, a.L), "workspace too small");
   AttnP p{a.Q, a.K, a.V, nullptr, a.q_sb, a.q_sh, 0, a.k_sb, a.k_sh, a.k_sr, a.v_sb, a.v_sh, a.v_sr, 0, 0, 0,
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
@@ -1071,36 +1301,46 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
   OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
+  if (dma) p.causal = g_attn_dma_rot == 1;
+  // LDS request of the ring form: the ring, padded so that exactly g_attn_dma_slots workgroups fit a CU's 160 KiB (the split count is sized
+  // for that many; a CU that took more would leave another one short)
+  const int dma_lds = std::min(65536, std::max(g_attn_dma_stages * 16384, (160 / g_attn_dma_slots) * 1024));
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
     if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
+    else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 2>), grid, dim3(64), dma_lds, s, p);
+    else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 3>), grid, dim3(64), dma_lds, s, p);
+    else if (dma) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 4>), grid, dim3(64), dma_lds, s, p);
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<f16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16, false>), grid, dim3(64), 0, s, p);
     if (nsplit > g_merge_mid_min && nsplit <= 256) {
-      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     } else if (nsplit > 256 && nsplit <= 1024) {
-      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
   } else if (dtype == OMCHAT_BF16) {
     if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
+    else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 2>), grid, dim3(64), dma_lds, s, p);
+    else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 3>), grid, dim3(64), dma_lds, s, p);
+    else if (dma) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 4>), grid, dim3(64), dma_lds, s, p);
     else if (tpw > 1 && g_attn_klds) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (tpw > 1) hipLaunchKernelGGL((attn_decode_multi_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_decode_kernel<bf16, false>), grid, dim3(64), 0, s, p);
     if (nsplit > g_merge_mid_min && nsplit <= 256) {
-      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      if (g_merge_dg == 2) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 2>), dim3(a.q_heads, a.batch, 2), dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 4, 1>), mgrid, dim3(512), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     } else if (nsplit > 256 && nsplit <= 1024) {
-      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
-      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+      if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+      else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, KV_TILE * tpw);
+    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

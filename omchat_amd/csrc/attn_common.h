@@ -133,13 +133,15 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
     const int key = key0 + kt * 16 + fc;
     kfresh[kt] = fuse && key >= pp;           // not in the cache yet (or clamped onto it)
     if constexpr (KV8) {                      // e4m3 cache bytes, widened exactly; the per-key scale multiplies the score below
+      // (plain loads: a 128-byte e4m3 row is fetched by four instructions of 32 bytes each, and with non-temporal loads the line can leave
+      // L2 between them -- configs[4] decode 2.27 -> 2.35 ms per token, profiles/r04_p)
       const unsigned char* src = (const unsigned char*)p.K + b * p.k_sb + kvh * p.k_sh + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = widen8<T>(*reinterpret_cast<const u32x2*>(src + ds * 32 + fg * 8));
     } else {
       const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
 #pragma unroll
-      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8<T>(src + ds * 32 + fg * 8);
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8s<T>(src + ds * 32 + fg * 8);
     }
   }
   frag_t vreg[16];                            // V^T image source: chunk idx = i*64 + lane -> row = 4*i + fg, ch = fc
@@ -152,7 +154,7 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
       vreg[i] = widen8<T>(*reinterpret_cast<const u32x2*>(src + fc * 8));
     } else {
       const T* src = fresh ? vn : Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr;
-      vreg[i] = ld8<T>(src + fc * 8);
+      vreg[i] = ld8s<T>(src + fc * 8);
     }
   }
   // fp8 cache: scales of the keys this lane's score registers hold (key0 + 16 kt + 4 fg + r), clamped like the rows

@@ -766,14 +766,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
 // once per workgroup.  Per output the arithmetic and its order are those of the one-shot form: the same bits.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int EPI, int NCH, bool F8>
-__global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int per_wg) {
+__global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int per_wg, unsigned skew) {
   typedef typename V8<T>::type v8;
   constexpr int R = EPI == EPI_SWIGLU ? 2 : 1;
   __shared__ __attribute__((aligned(16))) T xs[NCH * 512];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
-  const int o0 = blockIdx.x * per_wg, o1 = o0 + per_wg < n_out ? o0 + per_wg : n_out;
+  int o0 = blockIdx.x * per_wg, o1 = o0 + per_wg < n_out ? o0 + per_wg : n_out;
+  if (skew) {      // experiment (tuning key 28): shares by blockIdx % 8, per_wg + d_l with d_l = nibble l of skew - 8 (the deltas sum to 0)
+    const int l = blockIdx.x & 7;
+    int pre = 0;
+    for (int i = 0; i < l; ++i) pre += per_wg + (int)((skew >> (4 * i)) & 15u) - 8;
+    o0 = (blockIdx.x >> 3) * 8 * per_wg + pre;
+    o1 = o0 + per_wg + (int)((skew >> (4 * l)) & 15u) - 8;
+    o1 = o1 < n_out ? o1 : n_out;
+  }
   typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
   auto row_of = [&](int n, int r) { return EPI == EPI_SWIGLU ? 32 * (n >> 4) + (n & 15) + r * 16 : n; };
   auto load_w = [&](wreg_t (&w)[R][NCH], int n) {
@@ -1143,6 +1151,7 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
 }
 
 int g_gemv_rows_balance = 1;   // omchat_op_set_tuning key 17: 1 = one-row-per-wave launches whose rows deal evenly to 2 workgroups per CU take N / (2 CUs) waves per workgroup (o_proj 7, qkv 9)
+unsigned g_gemv_skew = 0;      // omchat_op_set_tuning key 28 (experiment): per-(blockIdx % 8) share deltas of the loop form, eight nibbles (d + 8)
 int g_gemv_dyn = 0;            // omchat_op_set_tuning key 24: 1 = the loop form takes its outputs from atomic work counters when the caller provides them (gemv_rows_norm_dyn_kernel)
 int g_gemv_norm_loop = 1;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
 
@@ -1160,7 +1169,8 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
     }
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
-      hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per);
+      const unsigned skew = (g_gemv_skew && n_out == per * 2 * n_cu && (2 * n_cu) % 8 == 0) ? g_gemv_skew : 0u;
+      hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per, skew);
       return;
     }
   }
@@ -1356,6 +1366,7 @@ int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
 void gemv_set_dyn(int v) { g_gemv_dyn = v; }
+void gemv_set_skew(int v) { g_gemv_skew = (unsigned)v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }
 
 namespace {

@@ -121,10 +121,14 @@ void attn_set_v2(int v);
 void model_set_fuse_peer_norm(int v);
 void attn_set_tpw(int v);
 void attn_set_klds(int v);
+void attn_set_dma(int v);
+void attn_set_dma_slots(int v);
+void attn_set_dma_rot(int v);
 void attn_set_merge_mid_min(int v);
 void attn_set_merge_dg(int v);
 void gemv_set_norm_loop(int v);
 void gemv_set_dyn(int v);
+void gemv_set_skew(int v);
 void gemv_set_rows_balance(int v);
 void gemv_set_no_xs(int v);
 

@@ -233,6 +233,7 @@ def test_decode_attention_k_through_lds_is_bit_identical(gpu_lib, dt):
     outs = {}
     try:
         gpu_lib.omchat_op_set_tuning(10, 4)
+        gpu_lib.omchat_op_set_tuning(25, 0)      # the register multi-tile kernel (the LDS-DMA ring form of round 4 has its own tests)
         for klds in (0, 1):
             gpu_lib.omchat_op_set_tuning(12, klds)
             out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
@@ -265,6 +266,7 @@ def test_decode_attention_k_through_lds_is_bit_identical(gpu_lib, dt):
     finally:
         gpu_lib.omchat_op_set_tuning(10, 0)
         gpu_lib.omchat_op_set_tuning(12, 0)
+        gpu_lib.omchat_op_set_tuning(25, 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -204,3 +204,84 @@ def test_dynamic_gate_up_gives_the_bits_of_the_equal_share_form(gpu_lib, dt):
         _lib.check(gpu_lib.omchat_op_set_tuning(24, 1))
     for s_, (a_, b_) in enumerate(zip(runs[1], runs[0])):
         assert torch.isfinite(a_).all() and torch.equal(a_, b_), (s_, rel(a_, b_))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched decode attention, LDS-DMA ring form (attention.hip: attn_decode_dma_kernel, tuning keys 25 / 26)
+# ---------------------------------------------------------------------------------------------------------------------
+def _attn_decode_ref(q, k, v, lens, scale):
+    """fp32 restatement of eager_attention_forward (modeling_qwen2.py:150-172) for one new token per sequence, GQA by repetition"""
+    b, Hq, _ = q.shape
+    rep = Hq // k.shape[1]
+    out = torch.zeros(b, Hq, 128)
+    for i, n in enumerate(lens):
+        kk = k[i, :, :n].float().repeat_interleave(rep, 0); vv = v[i, :, :n].float().repeat_interleave(rep, 0)
+        p = torch.softmax(torch.einsum("hd,hnd->hn", q[i].float(), kk) * scale, -1)
+        out[i] = torch.einsum("hn,hnd->hd", p, vv)
+    return out
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Hq,Hkv,cap,lens", [(3, 8, 2, 1024, [1000, 513, 64]), (2, 28, 4, 4096, [3700, 33]), (5, 7, 1, 512, [1, 31, 32, 97, 512])])
+def test_batched_decode_attention_dma_ring_vs_reference_and_register_form(gpu_lib, dt, b, Hq, Hkv, cap, lens):
+    """op level: ragged lengths incl. a single key, tile edges (31 / 32 / 33 keys), a poisoned cache tail that must never leak; every split
+    size the slot count (key 26) produces; against the fp32 reference and against the register form (key 25 = 0) it replaces"""
+    from gpu_util import dev, ptr, randn, CODE, TOL
+    q = rnd(randn((b, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3), dt)
+    ref = _attn_decode_ref(q, k, v, lens, 128 ** -0.5)
+    for i, n in enumerate(lens):
+        k[i, :, n:] = float("nan"); v[i, :, n:] = float("nan")
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    L = max(lens)
+    wsb = gpu_lib.omchat_op_attn_decode_ws(b, Hq, L)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    outs = {}
+    try:
+        gpu_lib.omchat_op_set_tuning(10, 4)
+        for dma, slots in ((0, 4), (1, 4), (1, 1), (1, 64)):
+            gpu_lib.omchat_op_set_tuning(25, dma); gpu_lib.omchat_op_set_tuning(26, slots)
+            out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda"); ws.fill_(float("nan"))
+            _lib.check(gpu_lib.omchat_op_attn_decode(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(out), b, Hq, Hkv, cap, L, ptr(dl), 128 ** -0.5, ptr(ws), wsb, None))
+            sync()
+            assert torch.isfinite(out.float()).all(), (dma, slots)
+            assert rel(out, ref) < TOL[dt], (dma, slots, rel(out, ref))
+            outs[(dma, slots)] = out.float().cpu()
+        assert rel(outs[(1, 4)], outs[(0, 4)]) < TOL[dt]
+    finally:
+        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batched_decode_attention_dma_ring_in_the_model(gpu_lib, dt):
+    """inside the decode step the split that owns the new position rotates the fresh key row, patches it into its LDS image and appends k / v:
+    ragged contexts whose new positions sit on the last row of a 32-key tile, the first row, mid-tile and in a one-tile split; 5 free-running
+    steps; logits against the one-tile kernel (key 10 = 1) and the register multi-tile form (key 25 = 0), and the cache rows the steps
+    appended must be the same bits in all three (the next step reads them)"""
+    cfg = tiny(q_heads=4, kv_heads=2)
+    sd = _decoder_sd(cfg, 5)
+    b, S = 5, 200
+    x = torch.randn(b, S, 256, generator=torch.Generator().manual_seed(11)) * 0.5
+    lens = [200, 127, 129, 64, 31]
+    runs = {}
+    try:
+        for name, (tpw, dma, slots) in {"one_tile": (1, 0, 4), "register": (4, 0, 4), "dma": (4, 1, 4), "dma_one_split": (4, 1, 1)}.items():
+            gpu_lib.omchat_op_set_tuning(10, tpw); gpu_lib.omchat_op_set_tuning(25, dma); gpu_lib.omchat_op_set_tuning(26, slots)
+            e = Engine(cfg, dtype=dt, max_seq=256, max_batch=b, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x, lens)
+            tok = torch.arange(b) % 300 + 7
+            seq = []
+            for _ in range(5):
+                tok, lg = e.decode_step(tok, want_logits=True)
+                seq.append((tok.cpu().clone(), lg.float().cpu().clone()))
+            sync()
+            runs[name] = seq
+            e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 4)
+    for name in ("register", "dma", "dma_one_split"):
+        for step in range(5):
+            a_, r_ = runs[name][step][1], runs["one_tile"][step][1]
+            assert torch.isfinite(a_).all()
+            assert rel(a_, r_) < TOL_DEEP[dt], (name, step, rel(a_, r_))
