@@ -1171,9 +1171,9 @@ int g_merge_mid_min = 64;   // omchat_op_set_tuning key 19: split-KV merges with
 void attn_set_merge_mid_min(int v) { g_merge_mid_min = v < 1 ? 1 : v; }
 int g_attn_dma = 1;     // omchat_op_set_tuning key 25: 1 = large-grid batched decode attention takes the LDS-DMA ring form (attn_decode_dma_kernel), 0 = attn_decode_multi_kernel
 void attn_set_dma(int v) { g_attn_dma = v; }
-int g_attn_dma_slots = 4;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
+int g_attn_dma_slots = 0;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte; 0 = by the launch's size), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
 int g_attn_dma_stages = 2;
-void attn_set_dma_slots(int v) { g_attn_dma_slots = (v & 255) < 1 ? 1 : (v & 255); const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
+void attn_set_dma_slots(int v) { g_attn_dma_slots = v & 255; const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
 int g_attn_dma_rot = 0;       // key 27 (experiment): rotated tile order per wave
 void attn_set_dma_rot(int v) { g_attn_dma_rot = v; }
 int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
@@ -1279,12 +1279,18 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   int tpw = kv8 ? 1 : (waves1 >= 6144 ? 4 : (waves1 >= 3072 ? 2 : 1));
   if (g_attn_tpw > 0 && !kv8) tpw = g_attn_tpw;
   if (a.key_mask) tpw = 1;      // the masked form exists for the one-tile kernel only (a rare mode)
-  // large grids (round 4): the LDS-DMA ring form.  One wave per workgroup, 32 KiB of LDS: g_attn_dma_slots of them are resident per CU,
-  // and the split count is chosen so that the launch is (at most) one resident round of equal splits of 32-key tiles
-  const bool dma = tpw > 1 && g_attn_dma && !kv8 && a.k_sr == 128 && a.v_sr == 128;
+  // enough keys in the launch (round 4): the LDS-DMA ring form.  One wave per workgroup owns a ring of 32-key tiles; `slots` of them are
+  // resident per CU and the split count is chosen so that the launch is one resident round of (nearly) equal splits.  Measured against the
+  // kernels above (tools/bench_attn_decode.py, attention + merge, us): b = 4 / 8 / 12 / 32 at 3.7 k keys 12.6 -> 11.9, 19.9 -> 16.3,
+  // 27.1 -> 21.2, 52.7 -> 44.0; b = 1 / 4 at 33 k keys 27.1 -> 21.2, 60.2 -> 48.3; a single sequence at 3.7 k keys (464 tiles of 32) stays
+  // with the one-tile kernel, whose few waves keep everything in flight at once.  From ~3 tiles per wave on the ring wins; two resident
+  // waves per CU once every wave has >= 16 tiles, four below.
+  const long tiles32 = (long)cdiv(a.L, DMA_TILE) * a.kv_heads * a.batch;
+  const bool dma = g_attn_dma && !kv8 && !a.key_mask && a.k_sr == 128 && a.v_sr == 128 && (g_attn_tpw > 1 || (g_attn_tpw == 0 && tiles32 >= 6L * device_cus()));
+  const int dma_slots = g_attn_dma_slots ? g_attn_dma_slots : (tiles32 >= 32L * device_cus() ? 2 : 4);
   int split_keys = KV_TILE * tpw;
   if (dma) {
-    const int slots = g_attn_dma_slots * device_cus(), pairs = a.kv_heads * a.batch;
+    const int slots = dma_slots * device_cus(), pairs = a.kv_heads * a.batch;
     const int tiles = cdiv(a.L, DMA_TILE);
     const int ns_target = std::max(1, slots / pairs);
     tpw = std::max(2, cdiv(tiles, ns_target));      // >= 2 tiles of 32 keys: never more partials than the workspace holds (one per 64 keys)
@@ -1304,7 +1310,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   if (dma) p.causal = g_attn_dma_rot == 1;
   // LDS request of the ring form: the ring, padded so that exactly g_attn_dma_slots workgroups fit a CU's 160 KiB (the split count is sized
   // for that many; a CU that took more would leave another one short)
-  const int dma_lds = std::min(65536, std::max(g_attn_dma_stages * 16384, (160 / g_attn_dma_slots) * 1024));
+  const int dma_lds = std::min(65536, std::max(g_attn_dma_stages * 16384, (160 / dma_slots) * 1024));
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {

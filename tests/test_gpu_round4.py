@@ -249,7 +249,7 @@ def test_batched_decode_attention_dma_ring_vs_reference_and_register_form(gpu_li
             outs[(dma, slots)] = out.float().cpu()
         assert rel(outs[(1, 4)], outs[(0, 4)]) < TOL[dt]
     finally:
-        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 4)
+        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 0)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -279,7 +279,7 @@ def test_batched_decode_attention_dma_ring_in_the_model(gpu_lib, dt):
             runs[name] = seq
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 4)
+        gpu_lib.omchat_op_set_tuning(10, 0); gpu_lib.omchat_op_set_tuning(25, 1); gpu_lib.omchat_op_set_tuning(26, 0)
     for name in ("register", "dma", "dma_one_split"):
         for step in range(5):
             a_, r_ = runs[name][step][1], runs["one_tile"][step][1]

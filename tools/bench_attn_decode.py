@@ -33,9 +33,10 @@ def run(n):
 
 
 ref = None
-for name, dma, slots, rot in (("register form (tpw auto)", 0, 4, 0), ("dma ring, 4 slots x 2 stages", 1, 4 + 2 * 256, 0), ("dma ring, 3 slots x 3 stages", 1, 3 + 3 * 256, 0),
-                              ("dma ring, 2 slots x 2 stages", 1, 2 + 2 * 256, 0), ("dma ring, 2 slots x 3 stages", 1, 2 + 3 * 256, 0), ("dma ring, 2 slots x 4 stages", 1, 2 + 4 * 256, 0),
-                              ("register form again", 0, 4, 0)):
+tpw_force = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # tuning key 10: 0 = the launcher's own choice of form
+lib.omchat_op_set_tuning(10, tpw_force)
+for name, dma, slots, rot in (("register form", 0, 4, 0), ("dma ring, 4 slots x 2 stages", 1, 4 + 2 * 256, 0), ("dma ring, 2 slots x 2 stages", 1, 2 + 2 * 256, 0),
+                              ("dma ring, 2 slots x 4 stages", 1, 2 + 4 * 256, 0), ("register form again", 0, 4, 0)):
     lib.omchat_op_set_tuning(25, dma); lib.omchat_op_set_tuning(26, slots); lib.omchat_op_set_tuning(27, rot)
     run(20); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,4 +45,4 @@ for name, dma, slots, rot in (("register form (tpw auto)", 0, 4, 0), ("dma ring,
     o = out.float().clone()
     if ref is None: ref = o
     print(f"b {b} L {L} cap {cap} ({mb:.0f} MB)  {name:34s} {us:7.2f} us per attention + merge   ({mb / us / 1e3 * 1e3:.0f} GB/s incl. merge)   max |diff| vs first {float((o - ref).abs().max()):.3e}")
-lib.omchat_op_set_tuning(25, 1); lib.omchat_op_set_tuning(26, 4 + 2 * 256); lib.omchat_op_set_tuning(27, 0)
+lib.omchat_op_set_tuning(25, 1); lib.omchat_op_set_tuning(26, 0); lib.omchat_op_set_tuning(27, 0); lib.omchat_op_set_tuning(10, 0)
