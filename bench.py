@@ -325,7 +325,9 @@ def main():
                 transport["rccl"] = transport.get("rccl", "") + " (disabled: not every rank initialised)"
         if a.transport in ("auto", "peer") or comm is None:
             try:
-                peer = tp.init_peer(rank, world, cap_bytes=64 << 20)
+                # ranks sharing ONE GPU (debug): every rank's spinning exchange workgroups sit on the CUs the other ranks' GEMMs need -- with the
+                # default 64-workgroup grids eight ranks starved each other into the barrier timeout; 8 workgroups per exchange leave room
+                peer = tp.init_peer(rank, world, cap_bytes=64 << 20, max_blocks=8 if oversub else 0)
                 ok, detail = tp.peer_selftest(peer, rank, world)
                 transport["peer_selftest"] = detail
             except Exception as e:          # noqa
@@ -356,6 +358,16 @@ def main():
 
     eng = new_engine(cfg, S, a.gen, B2, n_tiles * B2, vision=not vit_dp)
     tower = None
+
+    def peer_timed_out():
+        """did a barrier spin of the peer exchange give up on ANY rank since the last call?  (the kernels then went on with whatever was in the
+        slots: every number after that is void)"""
+        if peer is None:
+            return 0
+        import ctypes as C_
+        err = C_.c_int(0)
+        _lib.check(_lib.lib().omchat_peer_error(peer, C_.byref(err)))
+        return 1 - int(_allmin(dist, torch, 0 if err.value else 1))
 
     def make_tower():          # replicated vision-only context of this rank (data-parallel tower)
         tw = Engine(cfg, dtype=a.dtype, max_seq=64, max_batch=1, max_tiles=min(24, max(1, -(-n_tiles * B2 // world))), text=False)
@@ -464,6 +476,9 @@ def main():
                          "logit_rel_err": rel_err, "logit_rms_diff": rms, "logit_tolerance": tol, "min_margin": float(margin.min()),
                          "median_margin": float(margin.median())}
             tokens_match = bool(tp1_check["guarded_equal"] == tp1_check["guarded"] and rel_err < tol)
+        if peer_timed_out():
+            raise SystemExit("tp1_check: a peer-exchange barrier timed out on some rank (ranks oversubscribing one GPU starve each other; on one "
+                             "rank per GPU this means a lost peer): the comparison is void")
 
     eng.fill_synthetic(0, local=bool(shard))
     if a.graph and world == 1 and not shard:
@@ -606,6 +621,10 @@ def main():
         r2 = run_workload(eng, encode, px2, ids2, steps2, a.warmup if not do1 else 1, a.gen)
         del px2
     comm_stats = eng.comm_stats() if world > 1 else None
+    peer_timeouts = peer_timed_out() if world > 1 else None
+    if peer_timeouts:
+        raise SystemExit("bench.py: a peer-exchange barrier timed out on some rank inside the measured steps: the kernels went on with stale slots, "
+                         "the numbers are void (ranks oversubscribing one GPU can starve each other; one rank per GPU: a lost peer)")
     # data-parallel tower beside the tensor-parallel headline: same tiles, replicated tower, one gather (all ranks take part)
     vit_dp_side = None
     if world > 1 and a.vit == "both":
@@ -679,6 +698,7 @@ def main():
         res["tp1_check"] = tp1_check
         res["transport"] = transport
         res["comm_stats"] = comm_stats
+        res["peer_timeouts"] = peer_timeouts
         res["config"]["parallelism"] = f"tp{world}" + (" (vision tower data-parallel over tiles)" if vit_dp else "")
         if vit_dp_side is not None:
             res["vit_data_parallel"] = dict(vit_dp_side, note="replicated tower, tiles dealt to the ranks, one all-reduce gathers the features; NOT part of `value`")

@@ -222,7 +222,16 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 23: 1 = such a step runs every decoder layer as ONE launch (decode_layer.hip: qkv, attention, merge, o_proj, gate|up, down
  * with in-launch hand-offs; measured slower: 98 vs 91.5 us per layer), 0 (default) = six launches per layer (same bits);
  * key 24: 1 = the batch-1 gate|up GEMV takes its shares from per-XCD work queues (gemv_rows_norm_dyn_kernel; eager steps only; same
- * bits; measured 80-331 us against 45: the returning atomic drains the wave's load ring), 0 (default) = equal static shares) */
+ * bits; measured 80-331 us against 45: the returning atomic drains the wave's load ring), 0 (default) = equal static shares;
+ * key 25: 1 (default) = decode attention launches with enough keys (>= 6 tiles of 32 keys per CU: b >= 4 at 3.7 k keys, b = 1 from ~12 k)
+ * take the LDS-DMA ring form (attention.hip: attn_decode_dma_kernel; 16-bit cache), 0 = the register multi-tile / one-tile kernels;
+ * key 26: low byte = resident waves per CU that form's split count is sized for (0 = by launch size: 2 or 4), next byte = ring stages 2..4;
+ * key 27 / 28: experiments (rotated tile order of that form; per-(blockIdx % 8) share deltas of the batch-1 gate|up GEMV, eight nibbles
+ * d + 8: measured 1 % at best, profiles/r04_n);
+ * key 29: tensor parallelism, 1 = the row-parallel projections of the ViT / the prefill are all-reduced as fp32 partial sums and the
+ * epilogue (bias, layer scale, residual) is applied once to the sum, so TP = N differs from TP = 1 in fp32 summation order only (twice
+ * the bytes on the links); 0 (default) = every rank applies the epilogue to its own partial and 16-bit results are summed.  TP = 8 f16
+ * logit error against TP = 1: 4.97e-3 with, 5.32e-3 without (profiles/r04_w, r04_x)) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

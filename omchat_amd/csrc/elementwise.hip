@@ -614,6 +614,45 @@ int launch_vit_assemble(int dtype, const void* pe, const void* cls, const void* 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tensor parallelism, fp32 partial sums (tuning key 29): the row-parallel projections write their raw fp32 accumulators (EPI_F32OUT), the
+// all-reduce sums them in fp32, and this kernel applies the epilogue ONCE to the sum, with the rounding points of the one-GPU epilogue:
+//   EPI_NONE: T(sum + b)    EPI_RESID: T(r + T(sum + b))    EPI_LS_RESID: T(r + T(T(sum + b) * ls))      (gemm.hip: gemm_epilogue)
+// so that a TP = N result differs from TP = 1 only in the fp32 summation order of the K range.  (Default path: every rank rounds its own
+// partial -- and, in the ViT, applies the layer scale to it -- before the sum: N roundings instead of one.)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tp_finish_kernel(const float* __restrict__ sum, const T* __restrict__ bias, const T* __restrict__ ls,
+                                                        const T* resid, T* out, long total4, int N, int epi) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int col = (int)(e % N);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sum + e);
+    typename V8<T>::half_type o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = a[j] + (bias ? tof(bias[col + j]) : 0.f);
+      if (epi != EPI_NONE) v = rnd<T>(v);
+      if (epi == EPI_LS_RESID) v = tof(resid[e + j]) + rnd<T>(v * tof(ls[col + j]));
+      if (epi == EPI_RESID) v = tof(resid[e + j]) + v;
+      o[j] = fromf<T>(v);
+    }
+    *reinterpret_cast<typename V8<T>::half_type*>(out + e) = o;
+  }
+}
+
+int launch_tp_finish(int dtype, const float* sum, const void* bias, const void* ls, const void* resid, void* out, int M, int N, int epi, hipStream_t s) {
+  OM_CHECK(sum && out && M > 0 && N > 0 && N % 4 == 0, "tp_finish: null argument or N % 4 != 0");
+  OM_CHECK(epi == EPI_NONE || ((epi == EPI_RESID || epi == EPI_LS_RESID) && resid && (epi != EPI_LS_RESID || ls)), "tp_finish: epilogue NONE / RESID / LS_RESID with its operands");
+  const long total4 = (long)M * N / 4;
+  const int grid = (int)std::min<long>((total4 + 255) / 256, 4096);
+  if (dtype == OMCHAT_F16) hipLaunchKernelGGL(tp_finish_kernel<f16>, dim3(grid), dim3(256), 0, s, sum, (const f16*)bias, (const f16*)ls, (const f16*)resid, (f16*)out, total4, N, epi);
+  else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL(tp_finish_kernel<bf16>, dim3(grid), dim3(256), 0, s, sum, (const bf16*)bias, (const bf16*)ls, (const bf16*)resid, (bf16*)out, total4, N, epi);
+  else { omchat_set_error("tp_finish: bad dtype"); return 1; }
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_gather_rows(int dtype, const int* idx, const void* table, const void* feats, void* out, int rows, int H, hipStream_t s) {
   OM_CHECK(H % 8 == 0, "H % 8");
   const long n = (long)rows * (H / 8);

@@ -94,6 +94,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
       for (int i = 0; i < MR; ++i) acc[i][j] *= sw * sa[i];
     }
   }
+  if constexpr (EPI == EPI_F32OUT) {      // raw fp32 accumulators, 16 bytes per fragment row (tensor-parallel partial sums)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((float*)p.C + (size_t)rowu * p.ldc, 0, rows_valid * p.ldc * 4, 0x00020000);
+    const int f_lane = (fr * p.ldc + 4 * fg) * 4;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      if (colu + j * 16 + 4 * fg < p.N) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), frs, f_lane + (colu + j * 16) * 4 + i * 16 * p.ldc * 4, 0, 0);
+      }
+    }
+    return;
+  }
   const T* __restrict__ bias = (const T*)p.bias;
   // byte ranges of the wave tile's rows (< 2^32: at most 128 rows of one matrix row stride each)
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((T*)p.C + (size_t)rowu * p.ldc, 0, rows_valid * p.ldc * 2, 0x00020000);
@@ -728,6 +741,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
     case EPI_LS_RESID: return launch_epi<T, EPI_LS_RESID>(a, stream);
     case EPI_RESID: return launch_epi<T, EPI_RESID>(a, stream);
     case EPI_SWIGLU: return launch_epi<T, EPI_SWIGLU>(a, stream);
+    case EPI_F32OUT: return a.force_tile == 1 ? launch_cfg<T, 128, 128, 2, 2, EPI_F32OUT>(a, stream) : launch_cfg8<T, EPI_F32OUT>(a, stream);
   }
   omchat_set_error("launch_gemm: bad epilogue");
   return 1;
@@ -899,6 +913,11 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
            "N must be a multiple of 4 and bias / layer-scale 8-byte aligned (the epilogue owns four consecutive columns per lane)");
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16, "bad dtype");
   GemmArgs b = a;
+  if (a.epi == EPI_F32OUT) {      // fp32 output (numerics option of the tensor-parallel path): 256^2 staggered kernel, 128^2 for small problems; no tuning
+    OM_CHECK(a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0 && !a.bias && !a.resid, "fp32-output GEMM: C 16-byte aligned, ldc % 4 == 0, no bias / residual");
+    b.force_tile = (long)cdiv(a.M, 256) * cdiv(a.N, 256) < 64 ? 1 : 2;
+    b.stream_k = -1;
+  } else
   if (!a.force_tile && g_autotune && a.stream_k <= 0) b.force_tile = tuned_tile(dtype, a, stream);
   if (dtype == OMCHAT_F16) return launch_t<f16>(b, stream);
   return launch_t<bf16>(b, stream);

@@ -12,6 +12,8 @@ enum {
   EPI_RESID = 3,     // C = T(resid + T(acc + bias?))                         (decoder o_proj / down_proj)
   EPI_SWIGLU = 4,    // W rows interleaved [16 gate | 16 up]: C[M,N/2] = T(T(silu(T(g))) * T(u))
   EPI_PARTIAL = 5,   // skinny GEMM only: raw fp32 K-slice sums Y[ksplit][b][ldy] (split-K across workgroups)
+  EPI_F32OUT = 6,    // MFMA GEMM only: C is float [M, ldc]: the raw fp32 accumulators (tensor parallelism: row-parallel partial sums that are
+                     // all-reduced in fp32 and finished by launch_tp_finish; ldc % 4 == 0, C 16-byte aligned)
 };
 struct GemmArgs {
   const void* A; int lda;
@@ -76,6 +78,7 @@ int gemm_tune_load(const char* path);
 int gemm_tune_dump(const char* path);
 long gemm_tune_runs();
 void model_set_ar_min_rows(int v);
+void model_set_tp_f32(int v);
 void model_set_pack_replica(int v);
 void model_set_norm_in_gemv(int v);
 
@@ -228,6 +231,8 @@ int launch_im2col(int dtype, const void* pixels, void* cols, int B, int HW, int 
 // x[b, 0] = cls + pos[0];  x[b, 1+p] = pe[b*np + p] + pos[1+p]
 int launch_vit_assemble(int dtype, const void* pe, const void* cls, const void* pos, void* x, int B, int np, int C, hipStream_t s);
 // out[r] = table[idx[r]] (idx >= 0) | feats[-1 - idx[r]] (idx <= -1, > PAD) | 0 (idx == INT_MIN)
+// out[M, N] = epi(sum[M, N] (fp32), bias, ls, resid) with the rounding points of the GEMM epilogues (EPI_NONE / EPI_RESID / EPI_LS_RESID)
+int launch_tp_finish(int dtype, const float* sum, const void* bias, const void* ls, const void* resid, void* out, int M, int N, int epi, hipStream_t s);
 int launch_gather_rows(int dtype, const int* idx, const void* table, const void* feats, void* out, int rows, int H, hipStream_t s);
 // strided row copy (drop CLS etc.): dst[r] = src[map(r)]
 int launch_copy_rows(int dtype, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, int rows, int H,

@@ -137,6 +137,7 @@ struct omchat_ctx {
   float* tw_logits = nullptr;
   void* sk_ws = nullptr; size_t sk_ws_bytes = 0;      // stream-K slabs + flags of the MFMA GEMM
   float* tp_table = nullptr;
+  float* tp_f32_ws = nullptr; size_t tp_f32_bytes = 0;      // fp32 partial sums of a row-parallel projection (tuning key 29), grown on demand
   void* arg_scratch = nullptr;
   float* tw_part = nullptr;       // split-K fp32 slices of the decode o_proj / down_proj [KS_MAX][max_batch][H]
   float* tw_attn_ws = nullptr;
@@ -479,6 +480,7 @@ extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
   if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
   for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
+  if (ctx->tp_f32_ws) (void)hipFree(ctx->tp_f32_ws);
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->stage_f32) hipFree(ctx->stage_f32);
   if (ctx->stage_t) hipFree(ctx->stage_t);
@@ -569,8 +571,17 @@ void model_set_ar_min_rows(int v) { g_ar_min_rows = v > 8 ? v : 8; }
 // sums and is all-reduced in place.  The rows are cut into up to AR_CHUNKS chunks of whole 256-row tiles; the all-reduce of
 // chunk i is enqueued on the communication stream behind an event and runs under the GEMM of chunk i + 1 (RCCL's ring kernels
 // take a few CUs, the GEMM the rest).  The launch stream resumes after the last chunk's all-reduce.
-static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* Y, int N, int M, int K, const void* bias,
-                          const void* ls, const void* resid, int epi, hipStream_t s) {
+int g_tp_f32 = 0;      // omchat_op_set_tuning key 29: 1 = row-parallel projections of the prefill / the ViT are all-reduced as fp32 partial sums and the
+                       // epilogue (bias, layer scale, residual) is applied once to the sum (launch_tp_finish); 0 (default) = every rank applies the
+                       // epilogue to its own partial and the 16-bit results are summed (half the bytes on the links)
+void model_set_tp_f32(int v) { g_tp_f32 = v; }
+
+// bias / resid: the true operands on EVERY rank (the 16-bit path hands them to rank 0 only)
+static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* Y, int N, int M, int K, const void* bias_all,
+                          const void* ls, const void* resid_all, int epi, hipStream_t s) {
+  const bool lead = ctx->tp_rank == 0;
+  const void* bias = lead ? bias_all : nullptr;
+  const void* resid = lead ? resid_all : nullptr;
   int nch = M >= 3 * g_ar_min_rows ? 4 : (M >= g_ar_min_rows ? 2 : 1);
   if (!ctx->comm_stream) nch = 1;
   // A chunk must still fill the GPU: cutting the 3-tile ViT (M = 3075: 169 tiles of 256^2) or the single-sequence prefill (S = 3584: 196
@@ -582,16 +593,43 @@ static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W
     const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
     while (nch > 1 && tiles / nch < n_cu) nch >>= 1;
   }
+  const int align = g_ar_min_rows >= 256 ? 256 : 8;
+  const int rows_per = nch == 1 ? M : cdiv(cdiv(M, nch), align) * align;
+  // fp32 partial sums (tuning key 29): GEMM -> raw accumulators, fp32 all-reduce, one epilogue on the sum
+  const bool f32 = g_tp_f32 && N % 4 == 0 && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_LS_RESID);
+  if (f32) {
+    const size_t need = (size_t)M * N * 4;
+    if (ctx->tp_f32_bytes < need) {
+      OM_HIP(hipStreamSynchronize(s));
+      if (ctx->comm_stream) OM_HIP(hipStreamSynchronize(ctx->comm_stream));
+      if (ctx->tp_f32_ws) (void)hipFree(ctx->tp_f32_ws);
+      ctx->tp_f32_ws = nullptr; ctx->tp_f32_bytes = 0;
+      OM_HIP(hipMalloc((void**)&ctx->tp_f32_ws, need));
+      ctx->tp_f32_bytes = need;
+    }
+  }
   if (nch == 1) {
+    if (f32) {
+      TRY(gemm(ctx, A, lda, W, ldw, ctx->tp_f32_ws, N, M, N, K, nullptr, nullptr, nullptr, 0, EPI_F32OUT, s));
+      TRY(ctx->allreduce_f32(ctx->tp_f32_ws, (size_t)M * N, s));
+      return launch_tp_finish(ctx->dt, ctx->tp_f32_ws, bias_all, ls, resid_all, Y, M, N, epi, s);
+    }
     TRY(gemm(ctx, A, lda, W, ldw, Y, N, M, N, K, bias, ls, resid, N, epi, s));
     return ctx->allreduce(Y, (size_t)M * N, s);
   }
-  const int align = g_ar_min_rows >= 256 ? 256 : 8;
-  const int rows_per = cdiv(cdiv(M, nch), align) * align;
   int i = 0;
   for (int r0 = 0; r0 < M; r0 += rows_per, ++i) {
     const int rows = std::min(rows_per, M - r0);
     char* y = (char*)Y + (size_t)r0 * N * 2;
+    if (f32) {
+      float* part = ctx->tp_f32_ws + (size_t)r0 * N;
+      TRY(gemm(ctx, (const char*)A + (size_t)r0 * lda * 2, lda, W, ldw, part, N, rows, N, K, nullptr, nullptr, nullptr, 0, EPI_F32OUT, s));
+      OM_HIP(hipEventRecord(ctx->ev_chunk[i], s));
+      OM_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_chunk[i], 0));
+      TRY(ctx->allreduce_f32(part, (size_t)rows * N, ctx->comm_stream));
+      TRY(launch_tp_finish(ctx->dt, part, bias_all, ls, resid_all ? (const char*)resid_all + (size_t)r0 * N * 2 : nullptr, y, rows, N, epi, ctx->comm_stream));
+      continue;
+    }
     TRY(gemm(ctx, (const char*)A + (size_t)r0 * lda * 2, lda, W, ldw, y, N, rows, N, K, bias, ls,
              resid ? (const char*)resid + (size_t)r0 * N * 2 : nullptr, N, epi, s));
     OM_HIP(hipEventRecord(ctx->ev_chunk[i], s));
@@ -647,7 +685,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID, s));
     } else {
-      TRY(gemm_allreduce(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, Cq, lead ? L.bproj : nullptr, L.ls1, lead ? x : nullptr, EPI_LS_RESID, s));
+      TRY(gemm_allreduce(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, Cq, L.bproj, L.ls1, x, EPI_LS_RESID, s));
       std::swap(x, y);
     }
     TRY(norm(L.n2, L.n2b));
@@ -657,7 +695,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, EPI_LS_RESID, s));
     } else {
-      TRY(gemm_allreduce(ctx, ctx->vw_h, I, L.w2, I, y, C, M, I, lead ? L.b2 : nullptr, L.ls2, lead ? x : nullptr, EPI_LS_RESID, s));
+      TRY(gemm_allreduce(ctx, ctx->vw_h, I, L.w2, I, y, C, M, I, L.b2, L.ls2, x, EPI_LS_RESID, s));
       std::swap(x, y);
     }
   }
@@ -975,7 +1013,7 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, x, H, rows, H, qd, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
-      TRY(gemm_allreduce(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, qd, nullptr, nullptr, lead ? x : nullptr, EPI_RESID, s));
+      TRY(gemm_allreduce(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, qd, nullptr, nullptr, x, EPI_RESID, s));
       std::swap(x, y);
     }
     if (f8p) TRY(launch_rmsnorm_q8(ctx->dt, x, H, L.ln2, ctx->tw_q8, H, ctx->tw_q8s, rows, H, c.t_eps, s));
@@ -987,7 +1025,7 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
     } else {
-      TRY(gemm_allreduce(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, It, nullptr, nullptr, lead ? x : nullptr, EPI_RESID, s));
+      TRY(gemm_allreduce(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, It, nullptr, nullptr, x, EPI_RESID, s));
       std::swap(x, y);
     }
   }

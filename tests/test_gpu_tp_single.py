@@ -213,3 +213,74 @@ def test_tp2_fp8_decode_on_one_gpu(gpu_lib):
         tok = int(torch.argmax(full))
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("min_rows", [1 << 20, 8])
+def test_tp2_fp32_partial_sums_are_closer_to_tp1(gpu_lib, dt, min_rows):
+    """tuning key 29: the row-parallel projections of the ViT and the prefill hand their raw fp32 accumulators to the all-reduce and the epilogue
+    (bias, layer scale, residual) runs once on the sum (launch_tp_finish) -- unchunked and with the all-reduce pipelined in row chunks.  Both
+    ranks hold the same bits; against the TP = 1 ENGINE (same kernels, one rank) the error is within the multi-layer tolerance and not above
+    the default path's (every rank rounding its own partial)"""
+    cfg = tiny(q_heads=4, kv_heads=2, heads_v=2)
+    sd = synth.state_dict(cfg, 13)
+    px = T32(synth.pixels(2, 56, 1))
+    ids = torch.tensor([[3, -200, 17, -200, 19, 20]])
+    e1 = Engine(cfg, dtype=dt, max_seq=128, max_batch=1, max_tiles=2)
+    e1.load_state_dict(sd)
+    f1 = e1.encode_images(px)
+    emb1, len1, _ = e1.splice(ids, None, f1)
+    l1, _ = e1.prefill(emb1, len1)
+    torch.cuda.synchronize()
+    f1, l1 = f1.float().cpu(), l1.float().cpu()
+    e1.close()
+
+    def run_all(f32):
+        gpu_lib.omchat_op_set_tuning(29, f32); gpu_lib.omchat_op_set_tuning(4, min_rows)
+        grp = Group(2)
+        engines, hooks = [], []
+        for r in range(2):
+            e = Engine(cfg, dtype=dt, max_seq=128, max_batch=1, max_tiles=2, tp_rank=r, tp_size=2, comm=C.c_void_p(1))
+            h = grp.hook_for(r)
+            _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+            e.load_state_dict(sd)
+            engines.append(e); hooks.append(h)
+
+        def run(r):
+            e = engines[r]
+            feats = e.encode_images(px)
+            embeds, lengths, _ = e.splice(ids, None, feats)
+            logits, _ = e.prefill(embeds, lengths)
+            torch.cuda.synchronize()
+            return feats.float().cpu(), logits.float().cpu()
+        res = _run_ranks(run, 2)
+        for e in engines:
+            e.close()
+        return res
+    try:
+        base = run_all(0)
+        f32 = run_all(1)
+    finally:
+        gpu_lib.omchat_op_set_tuning(29, 0); gpu_lib.omchat_op_set_tuning(4, 1024)
+    assert torch.equal(f32[0][0], f32[1][0])
+    err = {}
+    for name, res in (("default", base), ("fp32", f32)):
+        full = torch.cat([res[0][1], res[1][1]], dim=-1)
+        err[name] = (rel(res[0][0], f1), rel(full, l1))
+        assert err[name][0] < TOL_DEEP[dt] and err[name][1] < TOL_DEEP[dt], (name, err[name])
+    assert err["fp32"][0] <= err["default"][0] * 1.25 + 1e-6 and err["fp32"][1] <= err["default"][1] * 1.25 + 1e-6, err
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_gemm_fp32_output_epilogue(gpu_lib, dt):
+    """EPI_F32OUT: C (float) = A W^T, the raw fp32 accumulators of the 256^2 and the 128^2 kernels, ragged M / N edges"""
+    from gpu_util import DT, CODE, dev, ptr, randn, rnd
+    for M, N, K in ((300, 264, 128), (1100, 3200, 256)):
+        A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2), dt)
+        dA, dW = dev(A, dt), dev(W, dt)
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), N, M, N, K, None, None, None, 0, 6, 0, None))
+        sync()
+        ref = A.double() @ W.double().t()
+        assert torch.isfinite(out).all()
+        assert float((out.double().cpu() - ref).norm() / ref.norm()) < 1e-5
