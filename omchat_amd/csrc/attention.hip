@@ -311,6 +311,9 @@ template <int D, bool IS_V> __device__ __forceinline__ void tile_src(int piece, 
   row = 2 * R + (vc >> 3); ch = vc & 7;
 }
 
+#ifndef OMCHAT_TR_ASM
+#define OMCHAT_TR_ASM 0      // 1: the transposed V reads of the PV phase as inline assembly (A/B twin of round 4, measured 5-8 % slower: below)
+#endif
 template <typename T, int NW, bool GQA, int D = 128>
 __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
@@ -501,6 +504,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int r_lo = kt * 32 + s2 * 16 + v_row_lo, r_hi = r_lo + 8;
+        // hipcc puts an s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 it emits while an LDS-DMA is outstanding (the intrinsic has
+        // no memory operand to tell the stage being read from the stage being filled), so the PV phase of tile t formally waits for the prefetch
+        // of tile t + 1 issued at the top of the iteration.  Round 4 tested whether that wait costs anything: the same reads as inline assembly
+        // (OMCHAT_TR_ASM = 1: four reads + their own lgkmcnt wait per pair of d blocks, no vmcnt wait left in the loop but the one at its
+        // top) run 5-8 % SLOWER on every shape (ViT 3 tiles 78.2 vs 72.3 us, causal S = 3584 164.4 vs 153.4 us, 33 k keys 973 vs 1018 TF:
+        // profiles/r04_y): the K / V tiles come from L2 and have landed by the time the softmax is done, and the compiler's own
+        // read-by-read lgkmcnt interleave with the MFMAs is worth more than the removed wait.  (In the decode ring kernel, whose tiles
+        // come from HBM, the same wait drained the ring and the assembly form is the one that works.)
+#if OMCHAT_TR_ASM
+#pragma unroll
+        for (int db = 0; db < DB; db += 2) {
+          s16x4 lo0, hi0, lo1, hi1;
+          const unsigned a0 = (unsigned)(size_t)(lds_s16x4_ptr)(Vs + tile_off<D, true>(r_lo, 4 * db + v_ch_lo) + v_byte);
+          const unsigned a1 = (unsigned)(size_t)(lds_s16x4_ptr)(Vs + tile_off<D, true>(r_hi, 4 * db + v_ch_lo) + v_byte);
+          const unsigned a2 = (unsigned)(size_t)(lds_s16x4_ptr)(Vs + tile_off<D, true>(r_lo, 4 * (db + 1) + v_ch_lo) + v_byte);
+          const unsigned a3 = (unsigned)(size_t)(lds_s16x4_ptr)(Vs + tile_off<D, true>(r_hi, 4 * (db + 1) + v_ch_lo) + v_byte);
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(lo0), "=&v"(hi0), "=&v"(lo1), "=&v"(hi1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 c0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7);
+          const s16x8 c1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = mfma32(__builtin_bit_cast(frag_t, c0), pf[kt][s2], o[db]);
+          o[db + 1] = mfma32(__builtin_bit_cast(frag_t, c1), pf[kt][s2], o[db + 1]);
+        }
+#else
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
           const s16x4 lo = tr_read(Vs + tile_off<D, true>(r_lo, 4 * db + v_ch_lo) + v_byte);
@@ -509,6 +537,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
           const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[db] = mfma32(__builtin_bit_cast(frag_t, cat), pf[kt][s2], o[db]);
         }
+#endif
       }
   }
 
