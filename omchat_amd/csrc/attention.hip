@@ -332,11 +332,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const int qc = lane & 31, hh = lane >> 5;           // query column of this lane, lane half
 
   const int n_rep = p.q_heads / p.kv_heads;
-  const int nqb = gridDim.x;
-  const int qb = p.causal ? nqb - 1 - (int)blockIdx.x : (int)blockIdx.x;     // heaviest causal blocks first
-  const int b = blockIdx.z;
+  // GQA: the kv head is the FASTEST index of the workgroup id, so that the dispatcher hands out the causal query blocks heaviest first across
+  // ALL kv heads (round 4).  With the kv head on blockIdx.y the 448 workgroups of a single S = 3584 sequence were dealt head by head: the
+  // heaviest blocks of the last head (56 key tiles) started only after a CU had finished one of the light blocks of the first heads -- the
+  // launch ended at ~66 tile steps where 56 (the heaviest block alone) are the bound.  It also keeps one kv head per XCD (id % 8 -> id % 4).
+  // (the sequence is the next index: id = (block rank * batch + sequence) * kv_heads + kv head; p.nsplit carries the batch size)
+  const int nb = GQA ? p.nsplit : 1;
+  const int nqb = GQA ? (int)gridDim.x / (p.kv_heads * nb) : (int)gridDim.x;
+  const int bx = GQA ? (int)blockIdx.x / (p.kv_heads * nb) : (int)blockIdx.x;
+  const int qb = p.causal ? nqb - 1 - bx : bx;        // heaviest causal blocks first
+  const int b = GQA ? ((int)blockIdx.x / p.kv_heads) % nb : (int)blockIdx.z;
   constexpr int QW = GQA ? 32 : NW * 32;              // queries of the workgroup
-  const int kvh = GQA ? (int)blockIdx.y : (int)blockIdx.y / n_rep;
+  const int kvh = GQA ? (int)blockIdx.x % p.kv_heads : (int)blockIdx.y / n_rep;
   const int hq = GQA ? kvh * n_rep + wave : (int)blockIdx.y;
   const int q0b = qb * QW;
   const int q0 = q0b + (GQA ? 0 : wave * 32);
@@ -1274,7 +1281,8 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
     return 0;
   }
   if (g_attn_v2 && n_rep <= 8) {                 // GQA: the n_rep query heads of one kv head x 32 queries share every K / V tile
-    const dim3 g2(cdiv(a.Sq, 32), a.kv_heads, a.batch);
+    const dim3 g2(cdiv(a.Sq, 32) * a.kv_heads * a.batch, 1, 1);      // id = (query block rank * batch + sequence) * kv_heads + kv head (attn2_kernel)
+    p.nsplit = a.batch;
 #define OM_A2(NW_)                                                                                                       \
   do {                                                                                                                   \
     if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);            \
