@@ -1320,11 +1320,17 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   // resident per CU and the split count is chosen so that the launch is one resident round of (nearly) equal splits.  Measured against the
   // kernels above (tools/bench_attn_decode.py, attention + merge, us): b = 4 / 8 / 12 / 32 at 3.7 k keys 12.6 -> 11.9, 19.9 -> 16.3,
   // 27.1 -> 21.2, 52.7 -> 44.0; b = 1 / 4 at 33 k keys 27.1 -> 21.2, 60.2 -> 48.3; a single sequence at 3.7 k keys (464 tiles of 32) stays
-  // with the one-tile kernel, whose few waves keep everything in flight at once.  From ~3 tiles per wave on the ring wins; two resident
-  // waves per CU once every wave has >= 16 tiles, four below.
+  // with the one-tile kernel, whose few waves keep everything in flight at once.  From ~3 tiles per wave on the ring wins.
   const long tiles32 = (long)cdiv(a.L, DMA_TILE) * a.kv_heads * a.batch;
   const bool dma = g_attn_dma && !kv8 && !a.key_mask && a.k_sr == 128 && a.v_sr == 128 && (g_attn_tpw > 1 || (g_attn_tpw == 0 && tiles32 >= 6L * device_cus()));
-  const int dma_slots = g_attn_dma_slots ? g_attn_dma_slots : (tiles32 >= 32L * device_cus() ? 2 : 4);
+  // resident waves per CU: four when that leaves every wave 4 .. 8 tiles and there are many (sequence, kv head) streams (b = 8 / 12 at 3.7 k
+  // keys: 16.3 / 21.2 us against 17.0 / 22.5 with two); otherwise two -- long splits pipeline better (b = 32: 44.0 vs 46.7 us; b = 2 at 8.8 k
+  // keys 13.1 vs 15.3; one sequence at 16 k keys 15.2 vs 17.3)
+  int dma_slots = g_attn_dma_slots;
+  if (!dma_slots) {
+    const int pairs = a.kv_heads * a.batch, tpw4 = cdiv(cdiv(a.L, DMA_TILE), std::max(1, 4 * device_cus() / pairs));
+    dma_slots = (pairs >= 16 && tpw4 >= 4 && tpw4 <= 8 && tiles32 < 32L * device_cus()) ? 4 : 2;
+  }
   int split_keys = KV_TILE * tpw;
   if (dma) {
     const int slots = dma_slots * device_cus(), pairs = a.kv_heads * a.batch;
