@@ -337,13 +337,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   // heaviest blocks of the last head (56 key tiles) started only after a CU had finished one of the light blocks of the first heads -- the
   // launch ended at ~66 tile steps where 56 (the heaviest block alone) are the bound.  It also keeps one kv head per XCD (id % 8 -> id % 4).
   // (the sequence is the next index: id = (block rank * batch + sequence) * kv_heads + kv head; p.nsplit carries the batch size)
+  // Head split (round 4, p.tpw = xs): when the launch is at most one workgroup per CU its length is the heaviest block's, not the mean.  The
+  // xs heaviest block ranks are then issued as TWO workgroups each, one running the first half of the kv group's query heads and one the
+  // rest (the other waves stay idle but still stage their share of every tile): no partial results, no merge.  Ids [0, 2 xs per_rank) are
+  // those pairs, the other ranks follow in order.
   const int nb = GQA ? p.nsplit : 1;
-  const int nqb = GQA ? (int)gridDim.x / (p.kv_heads * nb) : (int)gridDim.x;
-  const int bx = GQA ? (int)blockIdx.x / (p.kv_heads * nb) : (int)blockIdx.x;
+  const int per_rank = GQA ? p.kv_heads * nb : 1;
+  const int xs = GQA ? p.tpw : 0;
+  const int nqb = GQA ? (int)gridDim.x / per_rank - xs : (int)gridDim.x;
+  int h_lo = 0, h_hi = GQA ? n_rep : 1, bx, rest;
+  if (GQA && (int)blockIdx.x < 2 * xs * per_rank) {
+    const int pair = (int)blockIdx.x >> 1;
+    bx = pair / per_rank; rest = pair % per_rank;
+    if (blockIdx.x & 1) h_lo = (n_rep + 1) / 2; else h_hi = (n_rep + 1) / 2;
+  } else if (GQA) {
+    const int j = (int)blockIdx.x - 2 * xs * per_rank;
+    bx = xs + j / per_rank; rest = j % per_rank;
+  } else {
+    bx = (int)blockIdx.x; rest = 0;
+  }
   const int qb = p.causal ? nqb - 1 - bx : bx;        // heaviest causal blocks first
-  const int b = GQA ? ((int)blockIdx.x / p.kv_heads) % nb : (int)blockIdx.z;
+  const int b = GQA ? rest / p.kv_heads : (int)blockIdx.z;
   constexpr int QW = GQA ? 32 : NW * 32;              // queries of the workgroup
-  const int kvh = GQA ? (int)blockIdx.x % p.kv_heads : (int)blockIdx.y / n_rep;
+  const int kvh = GQA ? rest % p.kv_heads : (int)blockIdx.y / n_rep;
   const int hq = GQA ? kvh * n_rep + wave : (int)blockIdx.y;
   const int q0b = qb * QW;
   const int q0 = q0b + (GQA ? 0 : wave * 32);
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 
   const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;
-  const bool wave_active = (GQA ? wave < n_rep : true) && q0 < p.Sq;       // wave-uniform
+  const bool wave_active = (GQA ? (wave >= h_lo && wave < h_hi) : true) && q0 < p.Sq;       // wave-uniform
 
   // ---- Q fragments (B operand of S^T): lane holds Q[query qc][d = 16 s + 8 hh + j]
   frag_t qf[KS];
@@ -426,6 +442,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const int v_ch_lo = 2 * (vg & 1) + (vp >> 1);       // + 4 db
   const int v_byte = 8 * (vp & 1);
 
+  // A deeper ring does not help (round 4): a three-stage form of this loop (tile t + 2 in flight, counted vmcnt, transposed reads as inline
+  // assembly so that the compiler's vmcnt(0) does not drain it) gave the same bits 10 % SLOWER on every shape (S = 3584: 116.7 vs 105.5 us,
+  // 33 k keys 949 vs 1044 TF): the step is bound by the MFMA + softmax chain of the waves on a SIMD (~0.85 of the MFMA pipe busy at two
+  // waves per SIMD), not by the tile's arrival.
   if (t_end > t_begin) issue_tile(t_begin, t_begin & 1);
   for (int t = t_begin; t < t_end; ++t) {
     const int cur = t & 1;
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
         // profiles/r04_y): the K / V tiles come from L2 and have landed by the time the softmax is done, and the compiler's own
         // read-by-read lgkmcnt interleave with the MFMAs is worth more than the removed wait.  (In the decode ring kernel, whose tiles
         // come from HBM, the same wait drained the ring and the assembly form is the one that works.)
-#if OMCHAT_TR_ASM
+        if constexpr (OMCHAT_TR_ASM != 0) {
 #pragma unroll
         for (int db = 0; db < DB; db += 2) {
           s16x4 lo0, hi0, lo1, hi1;
@@ -535,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
           o[db] = mfma32(__builtin_bit_cast(frag_t, c0), pf[kt][s2], o[db]);
           o[db + 1] = mfma32(__builtin_bit_cast(frag_t, c1), pf[kt][s2], o[db + 1]);
         }
-#else
+        } else {
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
           const s16x4 lo = tr_read(Vs + tile_off<D, true>(r_lo, 4 * db + v_ch_lo) + v_byte);
@@ -544,7 +564,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
           const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[db] = mfma32(__builtin_bit_cast(frag_t, cat), pf[kt][s2], o[db]);
         }
-#endif
+        }
       }
   }
 
@@ -1210,6 +1230,8 @@ void attn_set_dma(int v) { g_attn_dma = v; }
 int g_attn_dma_slots = 0;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte; 0 = by the launch's size), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
 int g_attn_dma_stages = 2;
 void attn_set_dma_slots(int v) { g_attn_dma_slots = v & 255; const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
+int g_attn_hsplit = -1;       // key 30: heaviest causal block ranks of a GQA prefill attention launch issued as two head halves (-1 = a quarter of the ranks when the launch is <= one workgroup per CU, 0 = off, n > 0 = n ranks whatever the size)
+void attn_set_hsplit(int v) { g_attn_hsplit = v; }
 int g_attn_dma_rot = 0;       // key 27 (experiment): rotated tile order per wave
 void attn_set_dma_rot(int v) { g_attn_dma_rot = v; }
 int g_attn_klds = 0;    // omchat_op_set_tuning key 12: 1 = batched decode attention loads K as whole rows through LDS (measured neutral: 4.47 ms / step either way at b = 32, profiles/r03_c)
@@ -1281,8 +1303,16 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
     return 0;
   }
   if (g_attn_v2 && n_rep <= 8) {                 // GQA: the n_rep query heads of one kv head x 32 queries share every K / V tile
-    const dim3 g2(cdiv(a.Sq, 32) * a.kv_heads * a.batch, 1, 1);      // id = (query block rank * batch + sequence) * kv_heads + kv head (attn2_kernel)
-    p.nsplit = a.batch;
+    // head split of the heaviest causal blocks (attn2_kernel): only while the launch is at most one workgroup per CU (S <= 2048 for one
+    // Qwen2-7B sequence: 61.2 -> 48.7 us at S = 2048 with a quarter of the ranks split; beyond that the pairs' extra CU time costs more than
+    // the shorter tail saves: S = 3584 106.8 -> 115.0 us with 8 ranks split)
+    const int nqb_ = cdiv(a.Sq, 32), per_rank = a.kv_heads * a.batch;
+    int xs = 0;
+    if (a.causal && n_rep >= 4 && !a.kv_start && (long)nqb_ * per_rank <= device_cus() && nqb_ >= 16)
+      xs = g_attn_hsplit >= 0 ? std::min(g_attn_hsplit, nqb_ / 2) : nqb_ / 4;
+    if (g_attn_hsplit > 0 && a.causal && n_rep >= 4 && !a.kv_start && nqb_ >= 16) xs = std::min(g_attn_hsplit, nqb_ / 2);      // forced (tests, A/B)
+    const dim3 g2((nqb_ + xs) * per_rank, 1, 1);      // id = (query block rank * batch + sequence) * kv_heads + kv head (attn2_kernel)
+    p.nsplit = a.batch; p.tpw = xs;
 #define OM_A2(NW_)                                                                                                       \
   do {                                                                                                                   \
     if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);            \

@@ -285,3 +285,43 @@ def test_batched_decode_attention_dma_ring_in_the_model(gpu_lib, dt):
             a_, r_ = runs[name][step][1], runs["one_tile"][step][1]
             assert torch.isfinite(a_).all()
             assert rel(a_, r_) < TOL_DEEP[dt], (name, step, rel(a_, r_))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GQA prefill attention: dispatch order and the head split of the heaviest causal blocks (attention.hip: attn2_kernel, tuning key 30)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,S,Hq,Hkv", [(1, 1000, 28, 4), (2, 1500, 14, 2), (1, 3584, 28, 4)])
+def test_gqa_prefill_attention_head_split_of_the_heaviest_blocks_same_bits(gpu_lib, dt, b, S, Hq, Hkv):
+    """the heaviest causal query blocks of a one-round launch are issued as two workgroups, each running half of the kv group's query heads:
+    every (head, query block) is still computed by one wave with the same key tiles in the same order, so the output must not change by a
+    bit -- split off (key 30 = 0), the launcher's own choice (-1), half of the ranks (key 30 = 1000), three ranks; ragged S (partial last
+    block), two sequences in one launch; and against the fp32 reference"""
+    from gpu_util import dev, ptr, randn, CODE, TOL
+    import ctypes as C
+    q = rnd(randn((b, S, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, S, 128), 2), dt); v = rnd(randn((b, Hkv, S, 128), 3), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    outs = {}
+    try:
+        for hs in (0, -1, 1000, 3):
+            ring = 0
+            gpu_lib.omchat_op_set_tuning(30, hs)
+            o = torch.full((b, S, Hq, 128), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_attn_prefill(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(o), b, S, S, Hq, Hkv, None, 1, 0, 128 ** -0.5, None))
+            sync()
+            assert torch.isfinite(o.float()).all(), (hs, ring)
+            outs[(hs, ring)] = o.clone()
+    finally:
+        gpu_lib.omchat_op_set_tuning(30, -1)
+    for key in outs:
+        assert torch.equal(outs[(0, 0)], outs[key]), key
+    # reference on a slice of the rows (the full S x S fp32 softmax of 28 heads is slow on the host)
+    rows = torch.tensor(sorted({0, 1, 31, 32, S // 2, S - 33, S - 1}))
+    rep = Hq // Hkv
+    for i in range(b):
+        kk = k[i].float().repeat_interleave(rep, 0); vv = v[i].float().repeat_interleave(rep, 0)          # [Hq, S, 128]
+        sc = torch.einsum("rhd,hnd->hrn", q[i, rows].float(), kk) * 128 ** -0.5
+        mask = torch.arange(S)[None, None, :] > rows[None, :, None]
+        p = torch.softmax(sc.masked_fill(mask, float("-inf")), -1)
+        ref = torch.einsum("hrn,hnd->rhd", p, vv)
+        assert rel(outs[(-1, 0)][i, rows.cuda()], ref) < TOL[dt]

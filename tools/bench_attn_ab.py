@@ -10,7 +10,7 @@ p = lambda t: C.c_void_p(t.data_ptr())
 key = int(sys.argv[1]); vals = [int(v) for v in sys.argv[2].split(",")]
 it = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
-SHAPES = [("vit", 3, 1025, 25, 25, 0), ("vit24", 24, 1025, 25, 25, 0), ("dec", 1, 3584, 28, 4, 1), ("dec_b4", 4, 3584, 28, 4, 1),
+SHAPES = [("dec2048", 1, 2048, 28, 4, 1), ("dec5000", 1, 5000, 28, 4, 1), ("vit", 3, 1025, 25, 25, 0), ("vit24", 24, 1025, 25, 25, 0), ("dec", 1, 3584, 28, 4, 1), ("dec_b4", 4, 3584, 28, 4, 1),
           ("dec_b16", 16, 3584, 28, 4, 1), ("c3_8704", 1, 8704, 28, 4, 1), ("long33k", 1, 33280, 28, 4, 1)]
 for name, b, S, Hq, Hkv, causal in SHAPES:
     if only and name not in only:
