@@ -740,10 +740,10 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
           const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt)
-            if (kfresh[kt]) {
+            if (pp >= key0 + kt * 16 && pp < key0 + kt * 16 + 16) {      // the block that holds row pp (uniform); later blocks are masked
               const frag_t kl = kv[kt * 4 + ds], kh = kv[kt * 4 + ds + 2];
-              kv[kt * 4 + ds] = rope_chunk<T>(kl, kh, cs, false);
-              kv[kt * 4 + ds + 2] = rope_chunk<T>(kh, kl, cs, true);
+              const frag_t rl = rope_chunk<T>(kl, kh, cs, false), rh = rope_chunk<T>(kh, kl, cs, true);
+              if (kfresh[kt]) { kv[kt * 4 + ds] = rl; kv[kt * 4 + ds + 2] = rh; }      // per lane: cached rows of the block are rotated already
             }
         }
 #pragma unroll

@@ -125,6 +125,33 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
   const T* kn = fuse ? (const T*)p.k_new + b * p.new_sb + kvh * 128 : nullptr;
   const T* vn = fuse ? (const T*)p.v_new + b * p.new_sb + kvh * 128 : nullptr;
 
+  // ---- q and the RoPE table row of the new position are requested FIRST (round 4): vector memory returns in order, so behind the tile's 32
+  // K / V loads they could not be used before the whole tile has arrived and the rotation of q (~270 VALU instructions of this single wave)
+  // sat on the critical path behind the HBM round trip; in front of them it runs while the tile is still on its way.  No runtime branch
+  // around the table loads (a conditional block would end in a wait for everything issued inside it): without RoPE they read q's own bytes.
+  frag_t qf[4];
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
+  }
+  // the new token's raw key row, d = 32 ds + 8 fg + j (every tile row >= pp reads it): loaded and rotated ahead of the tile as well, so that
+  // the split that owns the new position only SELECTS it once its tile has arrived (its rotation used to be the tail of the launch)
+  frag_t knr[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) knr[ds] = ld8<T>((fuse ? kn : (const T*)p.Q) + ds * 32 + fg * 8);
+  float csv[2][16];
+  {
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const f32x4* cs = reinterpret_cast<const f32x4*>(fuse ? p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2 : (const float*)p.Q);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) { const f32x4 v = cs[q4]; csv[ds][4 * q4] = v[0]; csv[ds][4 * q4 + 1] = v[1]; csv[ds][4 * q4 + 2] = v[2]; csv[ds][4 * q4 + 3] = v[3]; }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- issue every load of the tile
   frag_t kf[4][4];                            // A operand of S^T: key = key0 + 16*kt + fc, d = 32*ds + 8*fg + j
   bool kfresh[4];
@@ -139,7 +166,9 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = widen8<T>(*reinterpret_cast<const u32x2*>(src + ds * 32 + fg * 8));
     } else {
-      const T* src = kfresh[kt] ? kn : Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr;
+      // (rows >= pp under fused RoPE are replaced by the rotated new key below: their lanes read the last cached row, or row 0 of an empty cache)
+      const int kc = fuse ? (key < pp ? key : (pp > 0 ? pp - 1 : 0)) : (key < kv_len ? key : kv_len - 1);
+      const T* src = Kg + (int64_t)kc * p.k_sr;
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = ld8s<T>(src + ds * 32 + fg * 8);
     }
@@ -170,43 +199,32 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
         ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
       }
   }
-  frag_t qf[4];
-  {
-    const int hh = fc < n_rep ? fc : n_rep - 1;
-    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[ds] = ld8<T>(qp + ds * 32 + fg * 8);
-  }
-  // WAVE_ONLY: the RoPE table row of the new position is loaded with the tile, ahead of the barrier (no runtime branch around the loads:
-  // a conditional block would end in a wait for them, and the barrier would then stand behind the whole memory round trip)
-  float csv[2][16];
   if constexpr (WAVE_ONLY) {
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) {
-      const float* cs = p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) csv[ds][j] = cs[j];
-    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();               // raw: the loads above stay in flight; the workgroup's other waves issue theirs behind them
     __builtin_amdgcn_sched_barrier(0);
   }
   if (fuse) {
-    // rotate-half partner of d = 32*ds + 8*fg + j is fragment ds ^ 2 of the same lane (q and fresh k alike)
+    // rotate-half partner of d = 32*ds + 8*fg + j is fragment ds ^ 2 of the same lane (q and fresh k alike).  q first, all of it: it needs
+    // only the loads issued in front of the tile; the fresh key rows wait for the tile itself
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
-      const float* cs = WAVE_ONLY ? csv[ds] : p.rope + ((size_t)pt * 64 + ds * 32 + fg * 8) * 2;
       const frag_t lo = qf[ds], hi = qf[ds + 2];
-      qf[ds] = rope_chunk<T>(lo, hi, cs, false);
-      qf[ds + 2] = rope_chunk<T>(hi, lo, cs, true);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kfresh[kt]) {
-          const frag_t kl = kf[kt][ds], kh = kf[kt][ds + 2];
-          kf[kt][ds] = rope_chunk<T>(kl, kh, cs, false);
-          kf[kt][ds + 2] = rope_chunk<T>(kh, kl, cs, true);
-        }
+      qf[ds] = rope_chunk<T>(lo, hi, csv[ds], false);
+      qf[ds + 2] = rope_chunk<T>(hi, lo, csv[ds], true);
     }
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      const frag_t kl = knr[ds], kh = knr[ds + 2];
+      knr[ds] = rope_chunk<T>(kl, kh, csv[ds], false);
+      knr[ds + 2] = rope_chunk<T>(kh, kl, csv[ds], true);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // rows >= pp of the tile (per lane) take the rotated new key; the rows in front of it came from the cache, rotated when they were appended
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) kf[kt][ds] = kfresh[kt] ? knr[ds] : kf[kt][ds];
     // append (N14): the lanes that hold the real row pp write it (4 lanes x 4 chunks for k, 16 lanes x 1 chunk for v)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
