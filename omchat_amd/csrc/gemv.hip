@@ -640,6 +640,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   const int g = blockIdx.x * WAVES + wave;
+  // ---- 0. x and the norm weights are requested IN FRONT of the weight rows (round 4).  Vector memory returns in order: behind the weight
+  // loads the 2 x 7 KB of x / norm weights (L2 hits) could not be used before the wave's whole first batch of weights had come in from HBM, and
+  // the norm -- two barriers and two LDS round trips -- then ran with nothing left in flight behind it.  In front, the norm is done while the
+  // weights are still on their way and the dot products start when they land: qkv 7.95-8.33 -> 7.13 us, e4m3 decode 1.83 -> 1.73 ms per token.
+  // (Not in the loop form and not in the long-K kernel: there the same order measured SLOWER, gate|up 42.27 -> 43.00 us, down_proj 23.13 ->
+  // 23.49 us -- every wave of the chip asks for the same 14 KB first, and the weight requests of a CU queue behind that hot spot; with
+  // three buffers in flight the late norm was hidden already.  tools/bench_gemv_b1.py, profiles/r04_al.)
+  static_assert(WAVES >= 4 && NCH <= 8, "sum-of-squares order: four owner waves, up to two chunks each");
+  constexpr int MC = (NCH + WAVES - 1) / WAVES;
+  constexpr int SC = (NCH + 3) / 4;
+  rw_u32x4 xq[MC], nq[MC], sq[SC];
+#pragma unroll
+  for (int i = 0; i < MC; ++i) {
+    const int c = wave + WAVES * i, k = c * 512 + lane * 8;
+    const rw_u32x4 z = {0u, 0u, 0u, 0u};
+    const bool ok = c < NCH && k < p.K;
+    xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
+  }
+#pragma unroll
+  for (int i = 0; i < SC; ++i) {
+    if constexpr (WAVES == 4) {
+      sq[i] = xq[i];
+    } else {
+      const int c = wave + 4 * i, k = c * 512 + lane * 8;
+      const rw_u32x4 z = {0u, 0u, 0u, 0u};
+      sq[i] = (wave < 4 && c < NCH && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    }
+  }
   // ---- 1. this wave's weight rows: every load issued now
   int rows[R];
 #pragma unroll
@@ -669,28 +698,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   // The sum of squares is ALWAYS taken in the four-wave order -- waves 0..3 own chunks w and w + 4, per-lane accumulation over the two
   // chunks, butterfly, ((r0 + r1) + r2) + r3 -- whatever WAVES is, so that every launch form of a projection (4, 7 or 9 waves, the loop
   // form) gives the same bits on every device (the nine-wave form used to sum its nine per-chunk partials: ADVICE r03).
-  static_assert(WAVES >= 4 && NCH <= 8, "sum-of-squares order: four owner waves, up to two chunks each");
-  constexpr int MC = (NCH + WAVES - 1) / WAVES;
-  constexpr int SC = (NCH + 3) / 4;
-  rw_u32x4 xq[MC], nq[MC], sq[SC];
-#pragma unroll
-  for (int i = 0; i < MC; ++i) {
-    const int c = wave + WAVES * i, k = c * 512 + lane * 8;
-    const rw_u32x4 z = {0u, 0u, 0u, 0u};
-    const bool ok = c < NCH && k < p.K;
-    xq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
-    nq[i] = ok ? *reinterpret_cast<const rw_u32x4*>((const T*)p.norm_w + k) : z;
-  }
-#pragma unroll
-  for (int i = 0; i < SC; ++i) {
-    if constexpr (WAVES == 4) {
-      sq[i] = xq[i];
-    } else {
-      const int c = wave + 4 * i, k = c * 512 + lane * 8;
-      const rw_u32x4 z = {0u, 0u, 0u, 0u};
-      sq[i] = (wave < 4 && c < NCH && k < p.K) ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);            // keep every load above the first wait
   float ss = 0.f;
 #pragma unroll
