@@ -1060,12 +1060,19 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
   if (ns <= 64) {
     // short contexts (<= 4096 keys): this launch is pure latency, so every global load is issued before anything is reduced -- one
     // round trip instead of three (split maxima, then weights, then the partial outputs).  Same arithmetic, same summation order.
+    // the (max, sum) pair of split d goes out IN FRONT of the 64 partial-output loads (in-order return: behind them the softmax weights
+    // could not be formed before everything had arrived); no branch around the loads
+    const int sd = d & 63;
+    const float m_ld = w[(size_t)(sd < ns ? sd : 0) * WS_STRIDE + 128];
+    const float l_ld = w[(size_t)(sd < ns ? sd : 0) * WS_STRIDE + 129];
+    __builtin_amdgcn_sched_barrier(0);
     float v[64];
 #pragma unroll
     for (int s = 0; s < 64; ++s) v[s] = w[(size_t)(s < ns ? s : 0) * WS_STRIDE + d];
+    __builtin_amdgcn_sched_barrier(0);
     if (d < 64) {
-      const float m_s = d < ns ? w[(size_t)d * WS_STRIDE + 128] : NEG_BIG;
-      const float l_s = d < ns ? w[(size_t)d * WS_STRIDE + 129] : 0.f;
+      const float m_s = d < ns ? m_ld : NEG_BIG;
+      const float l_s = d < ns ? l_ld : 0.f;
       const float m = wave_max(m_s);
       const float f = d < ns ? exp2f((m_s - m) * c) : 0.f;
       const float lsum = wave_sum(f * l_s);
