@@ -692,6 +692,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
       if constexpr (F8) w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)rows[r] * p.ldw + k));
       else w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)rows[r] * p.ldw + k));
     }
+  // the epilogue's operands (bias, e4m3 row scales) are requested right BEHIND the weight rows: they come back with them instead of costing a
+  // dependent L2 round trip after the reduction.  (In FRONT of the weights they measured slower: a cold 2-byte load at the head of the
+  // in-order queue holds every weight row behind it -- profiles/r04_al.)  No branch around the loads: a null bias reads the norm weights.
+  float e_bias[RR], e_scale[R];
+  {
+    const T* bp = (EPI != EPI_SWIGLU && p.bias) ? (const T*)p.bias : (const T*)p.norm_w;
+    const int nmax = (EPI != EPI_SWIGLU && p.bias) ? n_out - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const int n = g * RR + r;
+      e_bias[r] = tof(bp[n < nmax ? n : nmax]);
+    }
+    if (!(EPI != EPI_SWIGLU && p.bias)) {
+#pragma unroll
+      for (int r = 0; r < RR; ++r) e_bias[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) e_scale[r] = 1.f;
+    if constexpr (F8) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) e_scale[r] = p.w_scale[rows[r]];
+    }
+  }
   // ---- 2. the norm, shared by the workgroup: wave w normalises chunks w, w + WAVES, ... (x and the norm weights are read ONCE per
   // workgroup: 2 x 7 KB instead of 7 KB of xn per wave), the normalised row goes to LDS, every wave reads it back.  The plain loads above
   // stay in flight across the two barriers.
@@ -744,7 +767,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if constexpr (F8) a *= p.w_scale[rows[r]];
+    if constexpr (F8) a *= e_scale[r];
     acc[r] = a;
   }
   if (lane == 0) {
@@ -756,7 +779,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
         const float gt = rnd<T>(acc[r]), up = rnd<T>(acc[r + RR]);
         ((T*)p.Y)[n] = fromf<T>(rnd<T>(silu(gt)) * up);
       } else {
-        const float y = acc[r] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+        const float y = acc[r] + e_bias[r];
         if (p.out_f32) ((float*)p.Y)[n] = y;
         else ((T*)p.Y)[n] = fromf<T>(y);
       }
@@ -1105,6 +1128,13 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   wreg_t wa[8], wb[8], wc[8];
   load_w(wa, 0);
   if (npass > 1) load_w(wb, 1);
+  // the epilogue's operands (bias, residual -- which may alias Y: only this wave writes element n --, the e4m3 row scale) right behind the first
+  // weight passes: they come back with them instead of costing a dependent L2 round trip after the reduction (no branch around the loads)
+  const float e_bias_raw = tof(((const T*)(p.bias ? p.bias : p.X))[p.bias ? row : 0]);
+  const float e_res_raw = tof(((const T*)(p.resid ? p.resid : p.X))[p.resid ? row : 0]);
+  const float e_bias = p.bias ? e_bias_raw : 0.f, e_res = p.resid ? e_res_raw : 0.f;
+  float e_scale = 1.f;
+  if constexpr (F8) e_scale = p.w_scale[row];
   // x -> LDS (zero beyond K up to the last whole pass), once per workgroup, under the first passes' weight loads
   for (int i = threadIdx.x; i < npass * 8 * 64; i += blockDim.x) {
     const rw_u32x4 z = {0u, 0u, 0u, 0u};
@@ -1128,10 +1158,10 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   float a = acc;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  if constexpr (F8) a *= p.w_scale[row];
+  if constexpr (F8) a *= e_scale;
   if (lane == 0 && valid) {
-    const float y = rnd<T>(a + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f));
-    ((T*)p.Y)[n] = fromf<T>((p.resid ? tof(((const T*)p.resid)[n]) : 0.f) + y);
+    const float y = rnd<T>(a + e_bias);
+    ((T*)p.Y)[n] = fromf<T>(e_res + y);
   }
 }
 
