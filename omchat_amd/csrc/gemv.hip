@@ -498,9 +498,17 @@ template <> __device__ __forceinline__ float rw_dot8_fp8<f16>(rw_u32x2 w, rw_u32
   return acc;
 }
 
+// epilogue operands of a one-shot row GEMV, requested right BEHIND the weight rows (they return with them instead of costing a dependent L2
+// round trip after the reduction; in front of the weights a cold 2-byte load would hold the whole in-order queue): two 16-bit vectors
+// (bias, residual; a dummy valid pointer + index 0 when absent -- no branch around the loads)
+template <typename T, int R> struct RwTail { const T* p0; const T* p1; int idx[R]; float v0[R], v1[R]; };
+template <typename T, int R> __device__ __forceinline__ void rw_tail_load(RwTail<T, R>& t) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) { t.v0[r] = tof(t.p0[t.idx[r]]); t.v1[r] = tof(t.p1[t.idx[r]]); }
+}
 template <typename T, int R, int NCH>
 __device__ __forceinline__ void rw_rows_fp8(const unsigned char* W, int ldw, const int (&rows)[R], int k0, int K, int lane, const rw_u32x4 (&xr)[RW_MAXC],
-                                            const float* scale, float (&acc)[R]) {
+                                            const float* scale, float (&acc)[R], RwTail<T, R>& tail) {
   rw_u32x2 w[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -510,6 +518,10 @@ __device__ __forceinline__ void rw_rows_fp8(const unsigned char* W, int ldw, con
       k = k < K ? k : k0;
       w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>(W + (size_t)rows[r] * ldw + k));
     }
+  float sc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) sc[r] = scale[rows[r]];
+  rw_tail_load<T, R>(tail);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float a = 0.f;
@@ -517,23 +529,23 @@ __device__ __forceinline__ void rw_rows_fp8(const unsigned char* W, int ldw, con
     for (int c = 0; c < NCH; ++c) a = rw_dot8_fp8<T>(w[r][c], xr[c], a);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    acc[r] = a * scale[rows[r]];
+    acc[r] = a * sc[r];
   }
 }
 
 template <typename T, int R, int N>
 __device__ __forceinline__ void rw_dispatch_fp8(int nch, const unsigned char* W, int ldw, const int (&rows)[R], int k0, int K, int lane,
-                                                const rw_u32x4 (&xr)[RW_MAXC], const float* scale, float (&acc)[R]) {
+                                                const rw_u32x4 (&xr)[RW_MAXC], const float* scale, float (&acc)[R], RwTail<T, R>& tail) {
   if constexpr (N > 0) {
-    if (nch == N) rw_rows_fp8<T, R, N>(W, ldw, rows, k0, K, lane, xr, scale, acc);
-    else rw_dispatch_fp8<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, scale, acc);
+    if (nch == N) rw_rows_fp8<T, R, N>(W, ldw, rows, k0, K, lane, xr, scale, acc, tail);
+    else rw_dispatch_fp8<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, scale, acc, tail);
   }
 }
 
 // rows r0 .. r0+R-1 (already mapped to weight-row indices by the caller) over NCH chunks starting at element k0
 template <typename T, int R, int NCH>
 __device__ __forceinline__ void rw_rows(const T* W, int ldw, const int (&rows)[R], int k0, int K, int lane, const rw_u32x4 (&xr)[RW_MAXC],
-                                        float (&acc)[R]) {
+                                        float (&acc)[R], RwTail<T, R>& tail) {
   rw_u32x4 w[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -543,6 +555,7 @@ __device__ __forceinline__ void rw_rows(const T* W, int ldw, const int (&rows)[R
       k = k < K ? k : k0;                       // ragged last chunk: clamp (x is zero there)
       w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>(W + (size_t)rows[r] * ldw + k));
     }
+  rw_tail_load<T, R>(tail);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float a = 0.f;
@@ -556,10 +569,10 @@ __device__ __forceinline__ void rw_rows(const T* W, int ldw, const int (&rows)[R
 
 template <typename T, int R, int N>
 __device__ __forceinline__ void rw_dispatch(int nch, const T* W, int ldw, const int (&rows)[R], int k0, int K, int lane,
-                                            const rw_u32x4 (&xr)[RW_MAXC], float (&acc)[R]) {
+                                            const rw_u32x4 (&xr)[RW_MAXC], float (&acc)[R], RwTail<T, R>& tail) {
   if constexpr (N > 0) {
-    if (nch == N) rw_rows<T, R, N>(W, ldw, rows, k0, K, lane, xr, acc);
-    else rw_dispatch<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, acc);
+    if (nch == N) rw_rows<T, R, N>(W, ldw, rows, k0, K, lane, xr, acc, tail);
+    else rw_dispatch<T, R, N - 1>(nch, W, ldw, rows, k0, K, lane, xr, acc, tail);
   }
 }
 
@@ -595,8 +608,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
       }
     }
     float acc[R];
-    if constexpr (F8) rw_dispatch_fp8<T, R, RW_MAXC>(nch, (const unsigned char*)p.W, p.ldw, rows, k0, p.K, lane, xr, p.w_scale, acc);
-    else rw_dispatch<T, R, RW_MAXC>(nch, W, p.ldw, rows, k0, p.K, lane, xr, acc);
+    RwTail<T, R> tail;
+    {
+      constexpr bool plain = EPI != EPI_SWIGLU && EPI != EPI_PARTIAL;
+      const bool hb = plain && p.bias, hr = EPI == EPI_RESID && !p.out_f32;
+      tail.p0 = hb ? (const T*)p.bias : (const T*)p.X;
+      tail.p1 = hr ? (const T*)p.resid : (const T*)p.X;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int n = g * OUT + r;
+        tail.idx[r] = (hb || hr) ? (n < n_out ? n : n_out - 1) : 0;
+      }
+      if (!hb) tail.p0 = tail.p1;      // (one of the two may be absent: read the other's element twice rather than element idx of x)
+      if (!hr) tail.p1 = tail.p0;
+    }
+    if constexpr (F8) rw_dispatch_fp8<T, R, RW_MAXC>(nch, (const unsigned char*)p.W, p.ldw, rows, k0, p.K, lane, xr, p.w_scale, acc, tail);
+    else rw_dispatch<T, R, RW_MAXC>(nch, W, p.ldw, rows, k0, p.K, lane, xr, acc, tail);
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < OUT; ++r) {
@@ -608,11 +635,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
         } else if constexpr (EPI == EPI_PARTIAL) {
           ((float*)p.Y)[(size_t)blockIdx.y * p.ldy + n] = acc[r];        // [ksplit][1][ldy]
         } else {
-          float y = acc[r] + (p.bias ? tof(((const T*)p.bias)[n]) : 0.f);
+          float y = acc[r] + (p.bias ? tail.v0[r] : 0.f);
           if (p.out_f32) ((float*)p.Y)[n] = y;
           else {
             y = rnd<T>(y);
-            if constexpr (EPI == EPI_RESID) y = tof(((const T*)p.resid)[n]) + y;
+            if constexpr (EPI == EPI_RESID) y = tail.v1[r] + y;
             ((T*)p.Y)[n] = fromf<T>(y);
           }
         }
