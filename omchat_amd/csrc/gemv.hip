@@ -1155,6 +1155,7 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   wreg_t wa[8], wb[8], wc[8];
   load_w(wa, 0);
   if (npass > 1) load_w(wb, 1);
+  if (npass > 2) load_w(wc, 2);      // all three buffers are on their way before x is staged (round 4: the third used to wait for the barrier below)
   // the epilogue's operands (bias, residual -- which may alias Y: only this wave writes element n --, the e4m3 row scale) right behind the first
   // weight passes: they come back with them instead of costing a dependent L2 round trip after the reduction (no branch around the loads)
   const float e_bias_raw = tof(((const T*)(p.bias ? p.bias : p.X))[p.bias ? row : 0]);
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   __syncthreads();
   // three register buffers: the weights of passes ps + 1 and ps + 2 are in flight under the dot products of pass ps (24 KB per wave)
   for (int ps = 0; ps < npass; ps += 3) {
-    if (ps + 2 < npass) load_w(wc, ps + 2);
+    if (ps > 0 && ps + 2 < npass) load_w(wc, ps + 2);
     dots(wa, ps);
     if (ps + 1 < npass) {
       if (ps + 3 < npass) load_w(wa, ps + 3);
