@@ -245,7 +245,13 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
   auto tile_of = [&](int j) { return EPI == EPI_SWIGLU ? 2 * ((int)blockIdx.x + (j >> 1) * (int)gridDim.x) + (j & 1) : (int)blockIdx.x + j * (int)gridDim.x; };
   const T* bias = (const T*)p.bias;
   float gate = 0.f;
-  auto finish = [&](frag_t (&wf)[NCH][2], int j) {
+  // plain epilogue with a bias (qkv): the bias element of the output this thread will reduce is requested when the tile's weights are -- loaded
+  // after the reduction it was a dependent L2 round trip per tile (round 4).  No branch around the load: without a bias it reads x[0].
+  const bool has_bias = EPI != EPI_SWIGLU && EPI != EPI_PARTIAL && bias != nullptr;
+  const T* bsrc = has_bias ? bias : (const T*)p.X;
+  auto bias_of = [&](int j) { const int e = threadIdx.x & 255, n = tile_of(j) * 16 + (e >> 4); return tof(bsrc[has_bias ? (n < p.N ? n : p.N - 1) : 0]); };
+  float bias_a = 0.f, bias_b = 0.f;
+  auto finish = [&](frag_t (&wf)[NCH][2], int j, float bias_v) {
     const int tile = tile_of(j), par = j & 1;
     f32x4 acc[NB];
 #pragma unroll
@@ -280,20 +286,20 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
         if (bi < p.b) ((float*)p.Y)[((size_t)slice * p.b + bi) * p.ldy + tile * 16 + nl] = v;      // [ksplit][b][ldy]
       } else if (bi < p.b) {
         const int n = tile * 16 + nl;
-        const float y = v + (bias ? tof(bias[n]) : 0.f);
+        const float y = v + (has_bias ? bias_v : 0.f);
         if (p.out_f32) ((float*)p.Y)[(size_t)bi * p.ldy + n] = y;
         else ((T*)p.Y)[(size_t)bi * p.ldy + n] = fromf<T>(y);
       }
     }
   };
   frag_t wa[NCH][2], wb[NCH][2];
-  if (my_tiles > 0) load_w(wa, tile_of(0));
+  if (my_tiles > 0) { load_w(wa, tile_of(0)); bias_a = bias_of(0); }
   for (int j = 0; j < my_tiles; j += 2) {
-    if (j + 1 < my_tiles) load_w(wb, tile_of(j + 1));
-    finish(wa, j);
+    if (j + 1 < my_tiles) { load_w(wb, tile_of(j + 1)); bias_b = bias_of(j + 1); }
+    finish(wa, j, bias_a);
     if (j + 1 < my_tiles) {
-      if (j + 2 < my_tiles) load_w(wa, tile_of(j + 2));
-      finish(wb, j + 1);
+      if (j + 2 < my_tiles) { load_w(wa, tile_of(j + 2)); bias_a = bias_of(j + 2); }
+      finish(wb, j + 1, bias_b);
     }
   }
 }
