@@ -679,7 +679,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   // weights are still on their way and the dot products start when they land: qkv 7.95-8.33 -> 7.13 us, e4m3 decode 1.83 -> 1.73 ms per token.
   // (Not in the loop form and not in the long-K kernel: there the same order measured SLOWER, gate|up 42.27 -> 43.00 us, down_proj 23.13 ->
   // 23.49 us -- every wave of the chip asks for the same 14 KB first, and the weight requests of a CU queue behind that hot spot; with
-  // three buffers in flight the late norm was hidden already.  tools/bench_gemv_b1.py, profiles/r04_al.)
+  // three buffers in flight the late norm was hidden already; x BETWEEN the first buffer and the other two measured 42.8 us as well.
+  // tools/bench_gemv_b1.py, profiles/r04_al.)
   static_assert(WAVES >= 4 && NCH <= 8, "sum-of-squares order: four owner waves, up to two chunks each");
   constexpr int MC = (NCH + WAVES - 1) / WAVES;
   constexpr int SC = (NCH + 3) / 4;
