@@ -228,6 +228,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 26: low byte = resident waves per CU that form's split count is sized for (0 = by launch size: 2 or 4), next byte = ring stages 2..4;
  * key 27 / 28: experiments (rotated tile order of that form; per-(blockIdx % 8) share deltas of the batch-1 gate|up GEMV, eight nibbles
  * d + 8: measured 1 % at best, profiles/r04_n);
+ * key 30: GQA prefill attention, heaviest causal query-block ranks issued as two workgroups of half the kv group's heads each: -1 (default) =
+ * a quarter of the ranks while the launch is at most one workgroup per CU (S <= 2048 for one Qwen2-7B sequence: 61.2 -> 53.7 us), 0 = off,
+ * n > 0 = n ranks whatever the size (same bits either way);
  * key 29: tensor parallelism, 1 = the row-parallel projections of the ViT / the prefill are all-reduced as fp32 partial sums and the
  * epilogue (bias, layer scale, residual) is applied once to the sum, so TP = N differs from TP = 1 in fp32 summation order only (twice
  * the bytes on the links); 0 (default) = every rank applies the epilogue to its own partial and 16-bit results are summed.  TP = 8 f16
