@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const int nb = GQA ? p.nsplit : 1;
   const int per_rank = GQA ? p.kv_heads * nb : 1;
   const int xs = GQA ? p.tpw : 0;
-  const int nqb = GQA ? (int)gridDim.x / per_rank - xs : (int)gridDim.x;
+  const int nqb = GQA ? (int)gridDim.x / per_rank - xs : (p.tpw == -1 ? (p.nsplit & 0xffff) : (int)gridDim.x);
   int h_lo = 0, h_hi = GQA ? n_rep : 1, bx, rest;
   if (GQA && (int)blockIdx.x < 2 * xs * per_rank) {
     const int pair = (int)blockIdx.x >> 1;
@@ -356,11 +356,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   } else {
     bx = (int)blockIdx.x; rest = 0;
   }
+  // MHA (the ViT), p.tpw = -1: one-dimensional grid in which the query blocks of a (head, sequence) pair sit 8 ids apart, i.e. on ONE XCD under
+  // round-robin placement (round 4).  With the query block as blockIdx.x the nine blocks of a head were dealt to all eight XCDs and every
+  // XCD's L2 fetched that head's K / V for itself: 355 MB per launch by the FETCH_SIZE counter for 79 MB of q, k, v, o (profiles/r04_ah_pmc...).
+  int mha_head = (int)blockIdx.y, mha_b = (int)blockIdx.z;
+  if (!GQA && p.tpw == -1) {
+    const int nq = p.nsplit & 0xffff, nbat = p.nsplit >> 16, grp = (int)blockIdx.x / (8 * nq), r = (int)blockIdx.x % (8 * nq);
+    const int pair = grp * 8 + (r & 7);
+    bx = r >> 3;
+    if (pair >= p.q_heads * nbat) return;      // (the last group of eight is padded; p.nsplit = query blocks | batch << 16)
+    mha_head = pair % p.q_heads; mha_b = pair / p.q_heads;
+  }
   const int qb = p.causal ? nqb - 1 - bx : bx;        // heaviest causal blocks first
-  const int b = GQA ? rest / p.kv_heads : (int)blockIdx.z;
+  const int b = GQA ? rest / p.kv_heads : mha_b;
   constexpr int QW = GQA ? 32 : NW * 32;              // queries of the workgroup
-  const int kvh = GQA ? rest % p.kv_heads : (int)blockIdx.y / n_rep;
-  const int hq = GQA ? kvh * n_rep + wave : (int)blockIdx.y;
+  const int kvh = GQA ? rest % p.kv_heads : mha_head / n_rep;
+  const int hq = GQA ? kvh * n_rep + wave : mha_head;
   const int q0b = qb * QW;
   const int q0 = q0b + (GQA ? 0 : wave * 32);
   const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
@@ -1237,6 +1248,8 @@ void attn_set_dma(int v) { g_attn_dma = v; }
 int g_attn_dma_slots = 0;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte; 0 = by the launch's size), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
 int g_attn_dma_stages = 2;
 void attn_set_dma_slots(int v) { g_attn_dma_slots = v & 255; const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
+int g_attn_mha_xcd = 1;       // key 33: 1 = MHA prefill attention launches keep the query blocks of a head on one XCD (one-dimensional grid)
+void attn_set_mha_xcd(int v) { g_attn_mha_xcd = v; }
 int g_attn_hsplit = -1;       // key 30: heaviest causal block ranks of a GQA prefill attention launch issued as two head halves (-1 = a quarter of the ranks when the launch is <= one workgroup per CU, 0 = off, n > 0 = n ranks whatever the size)
 void attn_set_hsplit(int v) { g_attn_hsplit = v; }
 int g_attn_dma_rot = 0;       // key 27 (experiment): rotated tile order per wave
@@ -1287,9 +1300,13 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
+  // MHA on the second-generation kernel: query blocks of a (head, sequence) pair 8 workgroup ids apart = on one XCD (attn2_kernel; key 33 = 0: the
+  // three-dimensional grid)
+  dim3 grid_x = grid;
+  if (g_attn_mha_xcd && !a.causal && grid.x < 65536 && a.batch < 32768) { p.tpw = -1; p.nsplit = (int)grid.x | (a.batch << 16); grid_x = dim3(cdiv(a.q_heads * a.batch, 8) * 8 * grid.x, 1, 1); }
   if (hd == 64 && g_attn_v2 && a.q_heads == a.kv_heads) {      // InternViT-300M on the second-generation kernel (round 3)
-    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false, 64>), grid, dim3(256), 0, s, p);
-    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false, 64>), grid, dim3(256), 0, s, p);
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false, 64>), grid_x, dim3(256), 0, s, p);
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false, 64>), grid_x, dim3(256), 0, s, p);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();
     return 0;
@@ -1303,8 +1320,8 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   }
   const int n_rep = a.q_heads / a.kv_heads;
   if (g_attn_v2 && n_rep == 1) {                 // MHA (ViT): 4 waves = 128 queries of one head
-    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false>), grid, dim3(256), 0, s, p);
-    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false>), grid, dim3(256), 0, s, p);
+    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false>), grid_x, dim3(256), 0, s, p);
+    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false>), grid_x, dim3(256), 0, s, p);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();
     return 0;

@@ -29,6 +29,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 28) { gemv_set_skew(value); return 0; }
   if (key == 29) { model_set_tp_f32(value); return 0; }
   if (key == 30) { attn_set_hsplit(value); return 0; }
+  if (key == 33) { attn_set_mha_xcd(value); return 0; }
   if (key == 16) { gemv_set_norm_loop(value); return 0; }
   if (key == 17) { gemv_set_rows_balance(value); return 0; }
   if (key == 19) { attn_set_merge_mid_min(value); return 0; }

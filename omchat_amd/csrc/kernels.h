@@ -128,6 +128,7 @@ void attn_set_dma(int v);
 void attn_set_dma_slots(int v);
 void attn_set_dma_rot(int v);
 void attn_set_hsplit(int v);
+void attn_set_mha_xcd(int v);
 void attn_set_merge_mid_min(int v);
 void attn_set_merge_dg(int v);
 void gemv_set_norm_loop(int v);
