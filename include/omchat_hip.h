@@ -231,6 +231,8 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 30: GQA prefill attention, heaviest causal query-block ranks issued as two workgroups of half the kv group's heads each: -1 (default) =
  * a quarter of the ranks while the launch is at most one workgroup per CU (S <= 2048 for one Qwen2-7B sequence: 61.2 -> 53.7 us), 0 = off,
  * n > 0 = n ranks whatever the size (same bits either way);
+ * key 33: 1 (default) = MHA prefill attention launches (the ViT) use a one-dimensional grid that keeps the query blocks of a (head, sequence) pair on
+ * one XCD (K / V fetched once: 355 -> 82 MB per launch at 3 tiles), 0 = (query block, head, sequence) grid (same bits);
  * key 29: tensor parallelism, 1 = the row-parallel projections of the ViT / the prefill are all-reduced as fp32 partial sums and the
  * epilogue (bias, layer scale, residual) is applied once to the sum, so TP = N differs from TP = 1 in fp32 summation order only (twice
  * the bytes on the links); 0 (default) = every rank applies the epilogue to its own partial and 16-bit results are summed.  TP = 8 f16
