@@ -325,3 +325,30 @@ def test_gqa_prefill_attention_head_split_of_the_heaviest_blocks_same_bits(gpu_l
         p = torch.softmax(sc.masked_fill(mask, float("-inf")), -1)
         ref = torch.einsum("hrn,hnd->rhd", p, vv)
         assert rel(outs[(-1, 0)][i, rows.cuda()], ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,S,H,D", [(3, 1025, 25, 128), (2, 300, 5, 128), (8, 1025, 16, 64), (1, 129, 9, 64)])
+def test_mha_prefill_attention_one_xcd_grid_same_bits(gpu_lib, dt, b, S, H, D):
+    """the ViT attention's one-dimensional grid (query blocks of a (head, tile) pair 8 workgroup ids apart, the last group of eight pairs
+    padded with workgroups that exit) against the (query block, head, tile) grid, tuning key 33: the same workgroups compute the same
+    tiles, so not a bit may change -- head counts that are and are not multiples of 8, both head dims, a ragged last query block; and
+    against the fp32 reference"""
+    from gpu_util import dev, ptr, randn, CODE, TOL
+    q = rnd(randn((b, S, H, D), 1), dt); k = rnd(randn((b, H, S, D), 2), dt); v = rnd(randn((b, H, S, D), 3), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    outs = {}
+    try:
+        for k33 in (1, 0):
+            gpu_lib.omchat_op_set_tuning(33, k33)
+            o = torch.full((b, S, H, D), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_attn_prefill_d(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(o), b, S, S, H, H, D, None, 0, 0, D ** -0.5, None))
+            sync()
+            assert torch.isfinite(o.float()).all(), k33
+            outs[k33] = o.clone()
+    finally:
+        gpu_lib.omchat_op_set_tuning(33, 1)
+    assert torch.equal(outs[0], outs[1])
+    p = torch.softmax(torch.einsum("bqhd,bhkd->bhqk", q.float(), k.float()) * D ** -0.5, -1)
+    ref = torch.einsum("bhqk,bhkd->bqhd", p, v.float())
+    assert rel(outs[1], ref) < TOL[dt]
