@@ -155,6 +155,11 @@ class Engine:
     def enable_fp8_kv(self, on=True):
         """fp8 (e4m3 + per-position scale) KV cache for the decode steps that follow the NEXT prefill (BASELINE configs[4])"""
         check(self.lib.omchat_enable_fp8_kv(self.h, int(on)))
+        self._fp8_kv = bool(on)
+
+    def masked_decode_supported(self):
+        """omchat_decode_step_masked (padded-batch decode as omchat_arch.py:61-70 computes it) runs on one GPU; see include/omchat_hip.h"""
+        return self.tp_size == 1 and not getattr(self, "_fp8_kv", False)
 
     def enable_fp8_prefill(self, on=True):
         """fp8 x fp8 MFMA for the qkv and gate|up GEMMs of the prefill (activations quantised per token, weights per output row)"""

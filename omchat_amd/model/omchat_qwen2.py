@@ -139,13 +139,20 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
                 if not right and not left:
                     raise NotImplementedError("attention masks with holes: pad on one side")
                 # a left-padded batch (tokenizer_padding_side='left', omchat_arch.py:176-184) is prefilled exactly as the reference
-                # does it (RoPE on arange(S), padded keys masked, logits of position S - 1); its decode steps are refused by the
-                # engine because the reference positions them inconsistently
+                # does it (RoPE on arange(S), padded keys masked, logits of position S - 1); its decode steps go through the masked
+                # step below (omchat_decode_step_masked), which positions and masks the rows as omchat_arch.py:61-70 does
                 side = "right" if right else "left"
             self._last_lengths = None
             # a batch whose rows differ in (spliced) length, or any left-padded one, is decoded as the reference does it: common cache
-            # slot, position_ids = sum(mask) - 1 and the padded token-level mask as the key mask (omchat_arch.py:61-70)
-            self._padded_batch = b > 1 and (side == "left" and min(lengths) < S or len(set(lengths)) > 1)
+            # slot, position_ids = sum(mask) - 1 and the padded token-level mask as the key mask (omchat_arch.py:61-70).  That step
+            # exists on one GPU only (include/omchat_hip.h: omchat_decode_step_masked): under tensor parallelism a RIGHT-padded ragged
+            # batch keeps the per-sequence step (every row at its own length: same tokens as the reference while no row has ended),
+            # and a left-padded one is refused HERE, before any work is enqueued
+            ragged = b > 1 and (side == "left" and min(lengths) < S or len(set(lengths)) > 1)
+            can_mask = self.engine.masked_decode_supported()
+            if ragged and side == "left" and not can_mask:
+                raise NotImplementedError("left-padded ragged batch: the masked decode step runs at tp_size == 1 only; pad on the right")
+            self._padded_batch = ragged and can_mask
             logits_last, hidden = self.engine.prefill(inputs_embeds, lengths, want_hidden=bool(output_hidden_states), padding_side=side)
             logits_last = self.engine.full_logits(logits_last)        # vocab-parallel lm_head: gather the rank-local shards
             out = CausalLMOutputWithPast(logits_last.unsqueeze(1), KVHandle(self.engine, b))

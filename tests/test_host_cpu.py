@@ -461,3 +461,60 @@ def test_pmc_traffic_picks_the_manifest_file_and_refuses_a_renamed_kernel(tmp_pa
     man = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
     for key in ("pmc_traffic", "pmc_traffic_configs2"):
         assert os.path.exists(os.path.join(ROOT, "profiles", man[key])), man[key]
+
+
+def test_ragged_batch_decode_routing_follows_what_the_engine_can_run():
+    """a ragged batch is routed to the masked decode step (omchat_arch.py:61-70 semantics) only where the engine has it
+    (one GPU, 16-bit cache); under tensor parallelism a right-padded ragged batch keeps the per-sequence step and a left-padded one is
+    refused BEFORE the prefill is enqueued.  Host logic only: a recording stand-in for the Engine, no GPU."""
+    import types
+    import pytest
+    import torch
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+
+    class FakeEngine:
+        def __init__(self, can_mask):
+            self.can_mask, self.calls, self.tp_size = can_mask, [], 1
+            self.device, self.torch_dtype = "cpu", torch.float32
+            self.c = types.SimpleNamespace(v_layers=0, max_seq=64, t_vocab=11)
+
+        def masked_decode_supported(self):
+            return self.can_mask
+
+        def prefill(self, embeds, lengths, want_hidden=False, padding_side="right"):
+            self.calls.append(("prefill", padding_side, list(lengths)))
+            return torch.zeros(embeds.shape[0], 11), None
+
+        def full_logits(self, x):
+            return x
+
+        def decode_step(self, tok, want_logits=False):
+            self.calls.append(("decode_step",))
+            return torch.zeros(tok.shape[0], dtype=torch.int32), torch.zeros(tok.shape[0], 11)
+
+        def decode_step_masked(self, tok, pos, mask, want_logits=False):
+            self.calls.append(("decode_step_masked",))
+            return torch.zeros(tok.shape[0], dtype=torch.int32), torch.zeros(tok.shape[0], 11)
+
+    cfg = types.SimpleNamespace(text={"vocab_size": 11}, mm={})
+    emb = torch.zeros(2, 5, 8)
+    right = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]])
+    left = torch.tensor([[1, 1, 1, 1, 1], [0, 0, 1, 1, 1]])
+    for can_mask in (True, False):
+        e = FakeEngine(can_mask)
+        m = OmChatQwen2ForCausalLM(cfg, e)
+        m.forward(inputs_embeds=emb, attention_mask=right)
+        assert e.calls[-1] == ("prefill", "right", [5, 3]) and m._padded_batch == can_mask
+    # left padding without the masked step: refused before anything is enqueued
+    e = FakeEngine(False)
+    m = OmChatQwen2ForCausalLM(cfg, e)
+    with pytest.raises(NotImplementedError, match="left-padded ragged batch"):
+        m.forward(inputs_embeds=emb, attention_mask=left)
+    assert e.calls == []
+    e = FakeEngine(True)
+    m = OmChatQwen2ForCausalLM(cfg, e)
+    m.forward(inputs_embeds=emb, attention_mask=left)
+    assert e.calls == [("prefill", "left", [5, 3])] and m._padded_batch
+    # equal lengths: never the masked step
+    m.forward(inputs_embeds=emb, attention_mask=torch.ones(2, 5, dtype=torch.long))
+    assert not m._padded_batch
