@@ -33,7 +33,9 @@ torch.set_grad_enabled(False)
 
 N_TILES, N_TEXT, N_FORCED = 3, 512, 3
 # stated tolerances per dtype: (tower, projected features, logits)
-TOL = {"bf16": (3e-2, 3e-2, 6e-2), "f16": (6e-3, 6e-3, 1.2e-2)}
+# measured on MI355X (profiles/r05_a_fulldepth_parity.json): bf16 tower 1.63e-2 / features 1.70e-2 / logits 3.3-3.6e-2,
+# f16 2.03e-3 / 2.13e-3 / 4.1-4.5e-3 -- the bounds leave ~1.4-1.8 x for kernel changes that move summation order
+TOL = {"bf16": (2.5e-2, 2.5e-2, 5e-2), "f16": (4e-3, 4e-3, 8e-3)}
 
 
 def _sample(cfg):

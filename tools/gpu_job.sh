@@ -1,0 +1,34 @@
+#!/bin/bash
+# One parameterised GPU job script (replaces the per-call tools/r0N_gpu_*.sh of earlier rounds):  tools/gpu_job.sh <tag> <job> [args...]
+# Outputs land in gpurun_out/<tag>/.  Jobs:
+#   shardstats N        rocprofv3 kernel stats of rank 0's share of a TP = N group (configs1 gen 32, configs2 gen 16)
+#   bench [args]        bench.py with the given arguments -> bench.json
+#   stats [args]        rocprofv3 --kernel-trace --stats of bench.py with the given arguments
+#   pytest [args]       python -m pytest with the given arguments
+#   py script [args]    python3 script args
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+tag=$1; job=$2; shift 2
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+stats() {   # name, bench args...
+  local name=$1; shift
+  rm -rf $O/prof_$name
+  rocprofv3 --kernel-trace --stats -d $O/prof_$name -o $name --output-format csv -- python3 bench.py "$@" > $O/${name}.json 2> $O/${name}.err
+  f=$(find $O/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/kernel_stats_${name}.csv && head -40 $O/kernel_stats_${name}.csv | cut -c1-200
+  rm -rf $O/prof_$name
+}
+case $job in
+  shardstats)
+    n=$1
+    stats shard${n}_configs1_gen32 --shard-of $n --workload configs1 --steps 1 --warmup 1 --gen 32 --no-cpu-baseline --no-side --no-fp8
+    stats shard${n}_configs2_gen16 --shard-of $n --workload configs2 --steps 1 --warmup 1 --gen 16 --no-cpu-baseline --no-side --no-fp8
+    ;;
+  bench) python3 bench.py "$@" > $O/bench.json 2> $O/bench.err; head -c 3000 $O/bench.json; tail -3 $O/bench.err ;;
+  stats) stats run "$@" ;;
+  pytest) python3 -m pytest "$@" 2>&1 | tail -30 | tee $O/pytest.txt ;;
+  py) python3 "$@" 2>&1 | tee $O/py.txt | tail -60 ;;
+  *) echo "unknown job $job"; exit 2 ;;
+esac
