@@ -236,7 +236,11 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 29: tensor parallelism, 1 = the row-parallel projections of the ViT / the prefill are all-reduced as fp32 partial sums and the
  * epilogue (bias, layer scale, residual) is applied once to the sum, so TP = N differs from TP = 1 in fp32 summation order only (twice
  * the bytes on the links); 0 (default) = every rank applies the epilogue to its own partial and 16-bit results are summed.  TP = 8 f16
- * logit error against TP = 1: 4.97e-3 with, 5.32e-3 without (profiles/r04_w, r04_x)) */
+ * logit error against TP = 1: 4.97e-3 with, 5.32e-3 without (profiles/r04_w, r04_x));
+ * key 34: launch shapes for the SHARD widths of a tensor-parallel rank's decode GEMVs (default 7): bit 0 = the x-stationary form, one tile per
+ * workgroup, for the short qkv shard of a batched step; bit 1 = split-K slices of >= 16 chunks and one chunk per wave per step for short-K
+ * o_proj / down_proj shards; bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up shard (0 = the round-4 shapes; same sums up
+ * to fp32 order where the slice count changes) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -479,6 +479,10 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 // ---------------------------------------------------------------------------------------------------------
 int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B the two forms
 int g_gemv_no_xs = 0;          // tuning knob (key 11): 1 = batched decode never takes the x-stationary persistent kernel (A/B)
+// omchat_op_set_tuning key 34: launch shapes for the SHARD widths of a tensor-parallel rank (round 5; N or K an eighth of the model's):
+// bit 0 = x-stationary form for short EPI_NONE outputs (qkv shard: one tile per workgroup), bit 1 = one-tile / one-chunk-per-wave form for
+// short-K split-K slices (o_proj / down_proj shards), bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up
+int g_gemv_shard = 7;
 constexpr int RW_MAXC = 8;
 // weight-only fp8 (OCP e4m3): 8 weights of a lane = 8 bytes.  gfx950's v_cvt_scalef32_pk_{bf16,f16}_fp8 widens two e4m3
 // values to a packed 16-bit pair in one instruction (exact: 3 mantissa bits), which then feeds the same v_dot2 as the
@@ -1314,6 +1318,9 @@ void launch_rows(const GemvP& p, hipStream_t s) {
     }
   }
   if ((EPI == EPI_NONE || EPI == EPI_RESID) && p.N < 32768) launch_rows_r<T, EPI, 1, false>(p, s);      // short outputs: one row per wave (latency-bound)
+  // a tensor-parallel rank's gate|up shard (2368 pairs at TP = 8): 4 pairs per wave are 148 workgroups on 256 CUs; one pair per wave
+  // gives every CU ~9 waves (round 5)
+  else if (EPI == EPI_SWIGLU && (g_gemv_shard & 4) && p.N / 2 < 16 * device_cus()) launch_rows_r<T, EPI, 1, false>(p, s);
   else launch_rows_r<T, EPI, 4, false>(p, s);
 }
 
@@ -1339,10 +1346,13 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     const int n_cu = device_cus();
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
-        ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu))) {
+        ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu) ||
+         ((g_gemv_shard & 1) && a.epi == EPI_NONE && a.N / 16 < n_cu))) {
       // the fused qkv projection (288 tiles on 256 CUs) cannot give every CU 4 units: it takes HALF as many workgroups as tiles, two tiles
       // each -- x is read 144 times instead of 288 and the second tile's loads run under the first's reduction (13.3 -> 11.7 us at b = 32)
-      const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : a.N / 32);
+      // a tensor-parallel rank's qkv shard (768 rows = 48 tiles at TP = 8) is shorter than one tile per CU: one tile per workgroup, 48
+      // workgroups that each read x once, instead of gemv_pk_kernel's 24 workgroups of two tiles (round 5: 11.4 us -> see DESIGN.md section 6)
+      const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : (a.N / 16 < n_cu ? a.N / 16 : a.N / 32));
       if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
@@ -1373,7 +1383,15 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       }
     }
     if (a.epi == EPI_SWIGLU) OM_PK(2, EPI_SWIGLU, 8, 4);
-    else if (a.epi == EPI_PARTIAL) { if (a.K / ks >= 1536) OM_PK(4, EPI_PARTIAL, 4, 2); else OM_PK(2, EPI_PARTIAL, 8, 4); }
+    else if (a.epi == EPI_PARTIAL) {
+      // short K slices (a tensor-parallel rank's o_proj: K = 512 = 8 chunks; down_proj: 37 chunks in two slices): one chunk per wave per
+      // step so that all eight waves of a workgroup load, and one tile per workgroup so that the grid covers the CUs (round 5)
+      const int cps = cdiv(a.K >> 6, ks);
+      if ((g_gemv_shard & 2) && cps <= 8) OM_PK(1, EPI_PARTIAL, 8, 1);
+      else if ((g_gemv_shard & 2) && cps <= 32) OM_PK(1, EPI_PARTIAL, 8, 2);
+      else if (a.K / ks >= 1536) OM_PK(4, EPI_PARTIAL, 4, 2);
+      else OM_PK(2, EPI_PARTIAL, 8, 4);
+    }
     else if (a.N >= 32768) OM_PK(4, EPI_NONE, 4, 4);
     else OM_PK(2, EPI_NONE, 8, 4);
 #undef OM_PK
@@ -1436,6 +1454,8 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
 void gemv_set_force_mfma(int v) { g_gemv_force_mfma = v; }
 int gemv_get_force_mfma() { return g_gemv_force_mfma; }
 void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
+void gemv_set_shard_shapes(int v) { g_gemv_shard = v; }
+int gemv_get_shard_shapes() { return g_gemv_shard; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
 void gemv_set_dyn(int v) { g_gemv_dyn = v; }
 void gemv_set_skew(int v) { g_gemv_skew = (unsigned)v; }

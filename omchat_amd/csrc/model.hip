@@ -1164,8 +1164,15 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return nch >= 16 ? std::min(DEC_KS_MAX, nch) : std::max(1, std::min(3, nch)); };
   // batched o_proj: K = 3584 cuts into two exact slices for the x-stationary form (40 + 16 chunks, gemv_xs_split_kernel) when the packed
   // replica is in use; otherwise ~2 workgroups per CU for the MFMA form
-  const int ks_o = b == 1 ? ks_rows(qd) : (wpk && qd == 3584 ? 2 : std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16))))));
-  const int ks_d = b == 1 ? ks_rows(It) : std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
+  // shard widths of a tensor-parallel rank (round 5): a K of <= 64 chunks is cut into slices of >= 16 chunks only (o_proj K = 512: one
+  // slice, down_proj K = 2368: two) -- eight slices of 4-5 chunks left seven of a workgroup's eight waves without a chunk, and every slice
+  // is 4 b H bytes that the residual + RMSNorm launch (under TP: the peer exchange) has to read
+  auto ks_short = [&](int K) { return std::max(1, std::min(DEC_KS_MAX, (K / 64) / 16)); };
+  const bool shard_ks = (gemv_get_shard_shapes() & 2) != 0;
+  const int ks_o = b == 1 ? ks_rows(qd) : (wpk && qd == 3584 ? 2 : (shard_ks && qd / 64 <= 64) ? ks_short(qd) :
+                                           std::max(1, std::min(DEC_KS_MAX, std::min(qd / 64, cdiv(512, cdiv(H, 16))))));
+  const int ks_d = b == 1 ? ks_rows(It) : (shard_ks && It / 64 <= 64) ? ks_short(It) :
+                                          std::max(1, std::min(DEC_KS_MAX, std::min(It / 64, 3 * cdiv(512, cdiv(H, 16)))));
   // batch 1, one GPU (round 3): the two residual + RMSNorm launches of a layer disappear.  o_proj and down_proj run without split-K and
   // write x + attn / x + mlp themselves (EPI_RESID, in place; down_proj's K = 18944 through gemv_rows_longk_kernel), and each RMSNorm runs
   // inside the projection that consumes it (gemv_rows_norm_kernel: qkv, gate|up, lm_head): six dependent launches per layer instead of
