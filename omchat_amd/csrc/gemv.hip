@@ -481,8 +481,9 @@ int g_gemv_force_mfma = 0;     // tuning knob (omchat_op_set_tuning key 1): A/B 
 int g_gemv_no_xs = 0;          // tuning knob (key 11): 1 = batched decode never takes the x-stationary persistent kernel (A/B)
 // omchat_op_set_tuning key 34: launch shapes for the SHARD widths of a tensor-parallel rank (round 5; N or K an eighth of the model's):
 // bit 0 = x-stationary form for short EPI_NONE outputs (qkv shard: one tile per workgroup), bit 1 = one-tile / one-chunk-per-wave form for
-// short-K split-K slices (o_proj / down_proj shards), bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up
-int g_gemv_shard = 7;
+// short-K split-K slices (o_proj / down_proj shards), bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up,
+// bit 3 = x-stationary form, one (gate, up) tile pair per workgroup, for a batched gate|up shard of at most one pair per CU
+int g_gemv_shard = 15;
 constexpr int RW_MAXC = 8;
 // weight-only fp8 (OCP e4m3): 8 weights of a lane = 8 bytes.  gfx950's v_cvt_scalef32_pk_{bf16,f16}_fp8 widens two e4m3
 // values to a packed 16-bit pair in one instruction (exact: 3 mantissa bits), which then feeds the same v_dot2 as the
@@ -1347,12 +1348,12 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
         ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu) ||
-         ((g_gemv_shard & 1) && a.epi == EPI_NONE && a.N / 16 < n_cu))) {
+         ((g_gemv_shard & 1) && a.epi == EPI_NONE && a.N / 16 < n_cu) || ((g_gemv_shard & 8) && a.epi == EPI_SWIGLU && a.N / 32 <= n_cu))) {
       // the fused qkv projection (288 tiles on 256 CUs) cannot give every CU 4 units: it takes HALF as many workgroups as tiles, two tiles
       // each -- x is read 144 times instead of 288 and the second tile's loads run under the first's reduction (13.3 -> 11.7 us at b = 32)
       // a tensor-parallel rank's qkv shard (768 rows = 48 tiles at TP = 8) is shorter than one tile per CU: one tile per workgroup, 48
       // workgroups that each read x once, instead of gemv_pk_kernel's 24 workgroups of two tiles (round 5: 11.4 us -> see DESIGN.md section 6)
-      const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : (a.N / 16 < n_cu ? a.N / 16 : a.N / 32));
+      const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : (a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16 < n_cu ? a.N / 16 : a.N / 32));
       if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
