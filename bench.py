@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/f16 MFMA
+MFMA_PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA (reached by the block-scaled opcodes only, MI355X_MICROARCH.md Matrix cores)
 TP1_CHECK_TOKENS = 32
 MARGIN_GUARD = {"bf16": 0.05, "f16": 0.02}      # top-1 / top-2 logit gap below which 16-bit rounding may legitimately flip an id
 
@@ -241,6 +242,20 @@ def pmc_traffic(substrings, which="pmc_traffic", profiles_dir=None, quiet=False)
     if not quiet:
         print(f"bench.py: no kernel matching {substrings} in profiles/{os.path.basename(path)}: PMC traffic not reported", file=sys.stderr)
     return None, f"profiles/{os.path.basename(path)}: no kernel matching {'+'.join(substrings)}"
+
+
+def roofline_vit_block(total_ms, launches, tiles, max_tiles, rows_per_tile, v_mlp_local, v_hidden):
+    """roofline of the ViT fc1 GEMM from its HIP-event brackets.  A pass of `tiles` tiles through a context sized for `max_tiles` runs as
+    ceil(tiles / max_tiles) launches per layer (32 tiles at max_tiles 24: 24 + 8), and `total_ms / launches` averages over ALL of them, so
+    the flops of one launch are priced at the MEAN tiles per launch (round 4 priced every launch at min(max_tiles, tiles) and reported
+    0.68 where 0.45 was true -- VERDICT r04 #9a)."""
+    chunks = -(-tiles // max_tiles)
+    tiles_per_launch = tiles / chunks
+    fl = 2.0 * tiles_per_launch * rows_per_tile * v_mlp_local * v_hidden
+    avg_s = total_ms / launches / 1e3
+    return {"bound": "mfma", "kernel": "gemm_kernel<EPI_GELU> (ViT fc1)", "achieved": fl / avg_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+            "launches": launches, "flops_per_launch": fl, "tiles_per_launch": tiles_per_launch}
 
 
 def algorithmic(cfg):
@@ -593,17 +608,15 @@ def main():
             fl = 2.0 * b * S_ * (2 * ld["t_mlp"]) * t["hidden_size"]
             avg_s = ms / n / 1e3
             tr, src = pmc_traffic(["gemm8_kernel", "Li4E"]) if (plain and b == 1 and not f8) else (None, None)
+            peak = MFMA_PEAK_FP8_TFLOPS if f8 else MFMA_PEAK_TFLOPS      # e4m3 operands are priced against the fp8 peak
             roof_pre = {"bound": "mfma", "kernel": "gemm8_kernel<256x256,EPI_SWIGLU" + (",F8" if f8 else "") + "> (prefill gate|up)", "achieved": fl / avg_s / 1e12,
-                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": tr,
+                        "peak": peak, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / peak, "traffic": tr,
                         "traffic_source": src, "avg_launch_us": avg_s * 1e6, "launches": n, "flops_per_launch": fl}
+            if f8:
+                roof_pre["frac_of_bf16_peak"] = fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS
         ms, n = prof[_lib.PROF_VIT_FC1]
         if n:
-            tiles_per_launch = min(r["max_tiles"], r["tiles"])
-            fl = 2.0 * tiles_per_launch * (cfg_.num_image_tokens + 1) * ld["v_mlp"] * v["hidden_size"]
-            avg_s = ms / n / 1e3
-            roof_vit = {"bound": "mfma", "kernel": "gemm_kernel<EPI_GELU> (ViT fc1)", "achieved": fl / avg_s / 1e12, "peak": MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_s * 1e6,
-                        "launches": n, "flops_per_launch": fl}
+            roof_vit = roofline_vit_block(ms, n, r["tiles"], r["max_tiles"], cfg_.num_image_tokens + 1, ld["v_mlp"], v["hidden_size"])
         return roof, roof_pre, roof_vit
 
     frontend3_ms = None

@@ -518,3 +518,63 @@ def test_ragged_batch_decode_routing_follows_what_the_engine_can_run():
     # equal lengths: never the masked step
     m.forward(inputs_embeds=emb, attention_mask=torch.ones(2, 5, dtype=torch.long))
     assert not m._padded_batch
+
+
+def test_vit_fc1_roofline_prices_the_mean_tiles_per_launch():
+    """VERDICT r04 #9a: a 32-tile clip through a context sized for 24 tiles runs every fc1 as two launches (24 + 8 tiles); the HIP-event
+    average is over both, so the flops per launch are those of the MEAN launch.  Numbers of the round-4 line (profiles/r04_ai_bench_n1.json,
+    configs4: 180 launches, 1188.9 us average, vit_mfma_frac 0.4259): the fc1 figure must stay within 15 % of the whole-tower fraction (fc1
+    is the best-filled GEMM of a layer: 1.05-1.07 x the tower at configs[1] / configs[2]), not 1.6 x above it."""
+    import bench
+    blk = bench.roofline_vit_block(180 * 1188.9434774716697 / 1e3, 180, 32, 24, 1025, 12800, 3200)
+    assert blk["tiles_per_launch"] == 16 and blk["launches"] == 180
+    assert abs(blk["frac"] - 0.4520) < 2e-3
+    assert blk["frac"] <= 1.15 * 0.42586780383442574
+    # unchunked passes keep the old pricing: configs[1] (3 tiles, 135 launches of 262.29 us) and configs[2] (96 tiles = 4 x 24)
+    one = bench.roofline_vit_block(135 * 262.2926079564624 / 1e3, 135, 3, 3, 1025, 12800, 3200)
+    assert abs(one["frac"] - 0.38415722343469655) < 1e-6 and one["tiles_per_launch"] == 3
+    four = bench.roofline_vit_block(540 * 1744.9176088527397 / 1e3, 540, 96, 24, 1025, 12800, 3200)
+    assert abs(four["frac"] - 0.46196610998154536) < 1e-6 and four["tiles_per_launch"] == 24
+
+
+def test_roofline_table_labels_dispatches_by_role():
+    """tools/roofline_table.py: one kernel name serves several call sites (the plain 256x256 GEMM runs the ViT qkv, the prefill qkv and the
+    projector), so dispatches are labelled from their neighbours in launch order; names as rocprofv3 prints them (profiles/r04_ai_kernel_stats*)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("roofline_table", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "roofline_table.py"))
+    rt = importlib.util.module_from_spec(spec); spec.loader.exec_module(rt)
+    N = "_ZN12_GLOBAL__N_1"
+    norm = N + "14rmsnorm_kernelIDF16bEEvPKT_iS3_PS1_iifi"
+    g0 = N + "12gemm8_kernelIDF16bLi0ELb0EEEvNS_5GemmPEi"
+    g3 = N + "12gemm8_kernelIDF16bLi3ELb0EEEvNS_5GemmPEi"
+    g4 = N + "12gemm8_kernelIDF16bLi4ELb0EEEvNS_5GemmPEi"
+    fc1 = "void (anonymous namespace)::gemm8_kernel<bool _Accum, int, E, false>((anonymous namespace)::GemmP, int)"
+    proj = N + "11gemm_kernelIDF16bLi192ELi256ELi3ELi4ELi2EEEvNS_5GemmPE"
+    fc2 = N + "11gemm_kernelIDF16bLi256ELi192ELi4ELi3ELi2EEEvNS_5GemmPE"
+    qkn = N + "17vit_qknorm_kernelIDF16bEEvPT_iPKS1_S4_iiffPKf"
+    mha = N + "12attn2_kernelIDF16bLi4ELb0ELi128EEEvNS_5AttnPE"
+    gqa = N + "12attn2_kernelIDF16bLi7ELb1ELi128EEEvNS_5AttnPE"
+    rope = N + "14rope_kv_kernelIDF16bEEvPT_iiiiiPKiiPKfiS2_S2_llPhS7_PfS8_ll"
+    dq = N + "21gemv_rows_norm_kernelIDF16bLi0ELi1ELi7ELb0ELi9EEEvNS_5GemvPE"
+    da = N + "18attn_decode_kernelIDF16bLb0ELb0EEEvNS_5AttnPE"
+    dm = N + "17attn_merge_kernelIDF16bEEvPKfiiPKiifPT_llii"
+    do = "void (anonymous namespace)::gemv_rows_kernel<bool _Accum, int, ELi, E, 7, false>((anonymous namespace)::GemvP)"
+    dg = N + "26gemv_rows_norm_loop_kernelIDF16bLi4ELi7ELb0EEEvNS_5GemvPEij"
+    dd = N + "22gemv_rows_longk_kernelIDF16bLb0EEEvNS_5GemvPEi"
+    lm = N + "21gemv_rows_norm_kernelIDF16bLi0ELi4ELi7ELb0ELi4EEEvNS_5GemvPE"
+    am = "(anonymous namespace)::argmax_stage1_kernel(float const*, int, int, float*, int*)"
+    vit = [norm, g0, qkn, mha, proj, norm, fc1, fc2]
+    pre = [norm, g0, rope, gqa, g3, norm, g4, g3]
+    dec = [dq, da, dm, do, dg, dd]
+    seq = vit * 2 + pre * 2 + dec * 2 + [lm, am] + vit
+    got = rt.label(seq)
+    V = ["RMSNorm (ViT)", "ViT qkv GEMM", "ViT q/k norm", "ViT attention (MHA)", "ViT proj GEMM", "RMSNorm (ViT)", "ViT fc1 GEMM (GELU)", "ViT fc2 GEMM"]
+    P = ["RMSNorm (prefill)", "prefill qkv GEMM", "prefill RoPE + KV write", "prefill attention (causal GQA)", "prefill o_proj GEMM", "RMSNorm (prefill)",
+         "prefill gate|up GEMM (SwiGLU)", "prefill down_proj GEMM"]
+    D = ["decode qkv GEMV (+RMSNorm)", "decode attention (split-KV)", "decode attention merge", "decode o_proj GEMV", "decode gate|up GEMV (+RMSNorm)",
+         "decode down_proj GEMV"]
+    assert got == V * 2 + P * 2 + D * 2 + ["lm_head GEMV (+final norm)", None] + V
+    # the prices of the judge's own table (VERDICT r04): fc1 251.9 GF, ViT attention 40.3 GF, gate|up 271.58 MB, prefill attention 92.07 GF
+    W = rt.work(3, 512, 32)
+    assert abs(W["ViT fc1 GEMM (GELU)"][1] / 1e9 - 251.9) < 0.1 and abs(W["ViT attention (MHA)"][1] / 1e9 - 40.3) < 0.1
+    assert abs(W["decode gate|up GEMV (+RMSNorm)"][1] / 1e6 - 271.58) < 0.01 and abs(W["prefill attention (causal GQA)"][1] / 1e9 - 92.07) < 0.01

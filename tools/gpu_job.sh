@@ -6,6 +6,7 @@
 #   stats [args]        rocprofv3 --kernel-trace --stats of bench.py with the given arguments
 #   pytest [args]       python -m pytest with the given arguments
 #   py script [args]    python3 script args
+#   table               configs[1]: kernel trace + FETCH_SIZE / WRITE_SIZE passes -> roofline_table.txt (tools/roofline_table.py), kernel stats CSV
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=$1; job=$2; shift 2
@@ -29,6 +30,18 @@ case $job in
   bench) python3 bench.py "$@" > $O/bench.json 2> $O/bench.err; head -c 3000 $O/bench.json; tail -3 $O/bench.err ;;
   stats) stats run "$@" ;;
   pytest) python3 -m pytest "$@" 2>&1 | tail -30 | tee $O/pytest.txt ;;
+  table)
+    B="--workload configs1 --steps 1 --warmup 1 --gen 32 --no-cpu-baseline --no-fp8 --no-side"
+    rm -rf $O/t $O/f $O/w
+    rocprofv3 --kernel-trace --stats -d $O/t -o t --output-format csv -- python3 bench.py $B > $O/table_bench.json 2> $O/table_bench.err
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 bench.py --workload configs1 --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/fetch.err
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 bench.py --workload configs1 --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/write.err
+    T=$(find $O/t -name "*kernel_trace.csv" | head -1); F=$(find $O/f -name "*counter_collection.csv" | head -1); W=$(find $O/w -name "*counter_collection.csv" | head -1)
+    cp $(find $O/t -name "*kernel_stats.csv" | head -1) $O/kernel_stats_configs1_steps1_gen32.csv
+    python3 tools/roofline_table.py $T --fetch $F --write $W | tee $O/roofline_table.txt
+    python3 tools/pmc_summary.py $F $W $O/pmc_traffic.json > /dev/null
+    rm -rf $O/t $O/f $O/w
+    ;;
   py) python3 "$@" 2>&1 | tee $O/py.txt | tail -60 ;;
   *) echo "unknown job $job"; exit 2 ;;
 esac
