@@ -18,17 +18,21 @@ def _stamp(path):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp_file = os.path.join(LIBDIR, "stamp")
-    stamp = _stamp(SRC)
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
+def build(force=False, verbose=True, extra_flags=(), out_dir=None):
+    """extra_flags / out_dir: an A/B twin of the same ABI built with other -D switches into another directory (load it with OMCHAT_LIB=...;
+    `python -m omchat_amd.build --twin ab_lib/f8_nonscaled -DOMCHAT_F8_SCALED=0`)"""
+    libdir = out_dir or LIBDIR
+    lib = os.path.join(libdir, "libomchat_hip.so")
+    os.makedirs(libdir, exist_ok=True)
+    stamp_file = os.path.join(libdir, "stamp")
+    stamp = _stamp(SRC) + " ".join(extra_flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return lib
     objs = []
 
     def cc(src):
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(SRC, src), "-o", obj]
+        obj = os.path.join(libdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(SRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
@@ -36,7 +40,7 @@ def build(force=False, verbose=True):
 
     with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
            "-Wl,-z,defs"]      # an undefined symbol fails the build here, not the first dlopen on the GPU box
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -44,9 +48,13 @@ def build(force=False, verbose=True):
     with open(stamp_file, "w") as f:
         f.write(stamp)
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB)/1e6:.1f} MB)")
-    return LIB
+        print(f"built {lib} ({os.path.getsize(lib)/1e6:.1f} MB)")
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--twin" in sys.argv:
+        i = sys.argv.index("--twin")
+        build(force=True, extra_flags=tuple(a for a in sys.argv[i + 2:] if a.startswith("-D")), out_dir=os.path.abspath(sys.argv[i + 1]))
+    else:
+        build(force="--force" in sys.argv)

@@ -316,6 +316,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
 // together; on return every wave has passed the same number of barriers and no LDS read is outstanding.
 // one 16-byte operand fragment pair -> accumulator: 8 16-bit elements (one 16x16x32 MFMA) or 16 e4m3 bytes (two 16x16x32 fp8 MFMAs: the
 // lane's bytes 0-7 and 8-15 are two K slots; A and B use the same assignment, so the K order inside a 128-byte row is immaterial)
+// fp8 x fp8, block-scaled form (round 5): ONE v_mfma_scale_f32_16x16x128_f8f6f4 takes the 32 e4m3 bytes a lane holds for the whole 128-deep
+// K step -- the two 16-byte chunks (s = 0, 1) that the non-scaled form feeds to four 16x16x32 MFMAs -- at twice the non-scaled rate
+// (MI355X_MICROARCH.md, Matrix cores: the non-scaled fp8 opcodes run at the bf16 rate; only the block-scaled ones reach the fp8 peak).
+// Scales: E8M0 bytes, one per lane and 32-element block; all 127 (= 2^0): the per-token / per-row fp32 scales stay in the epilogue, so the
+// products summed here are exactly those of the non-scaled form.  A and B take the same lane -> K assignment, so the order of K inside the
+// 128-byte row is immaterial (as above).  -DOMCHAT_F8_SCALED=0 builds the non-scaled twin for A/B.
+#ifndef OMCHAT_F8_SCALED
+#define OMCHAT_F8_SCALED 1
+#endif
+template <typename T>
+__device__ __forceinline__ f32x4 mma_frag_f8x128(typename V8<T>::type a0, typename V8<T>::type a1, typename V8<T>::type b0, typename V8<T>::type b1, f32x4 c) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  const i32x4 al = __builtin_bit_cast(i32x4, a0), ah = __builtin_bit_cast(i32x4, a1), bl = __builtin_bit_cast(i32x4, b0), bh = __builtin_bit_cast(i32x4, b1);
+  const i32x8 a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  const i32x8 b = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
 template <typename T, bool F8>
 __device__ __forceinline__ f32x4 mma_frag(typename V8<T>::type a, typename V8<T>::type b, f32x4 c) {
   if constexpr (F8) {
@@ -426,9 +445,14 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   __builtin_amdgcn_s_barrier();                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                                   \
+  if constexpr (F8 && OMCHAT_F8_SCALED) {                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
+        acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag_f8x128<T>(BF[j][0], BF[j][1], af[i][0], af[i][1], acc[(MH) * 4 + i][(NH) * 2 + j]); \
+  } else {                                                                                                         \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
           acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag<T, F8>(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j]);  \
+  }                                                                                                                \
   __builtin_amdgcn_s_setprio(0);                                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_barrier();                                                                                    \
