@@ -337,3 +337,90 @@ def test_fp8_kv_decode_one_full_width_layer_16k_context(gpu_lib):
         assert int(nxt[0]) == int(torch.argmax(lg[0]))
     assert e.kv_lengths(1) == [S + 2]
     e.close()
+
+
+def test_fp8_modes_error_per_layer_over_four_full_width_layers_16k_context(gpu_lib):
+    """where does the fp8 whole-model distance (configs[4]) come from, layer by layer?  Qwen2-7B-width
+    layers 1..4 at 16 k tokens of context with ALL fp8 modes on (fp8 x fp8 qkv / gate|up GEMMs on per-token e4m3 activations and per-row e4m3
+    weights, fp8 KV cache, e4m3 weight replica for the decode GEMVs):
+
+      kernel error   -- post-norm hidden states after L = 1..4 layers against the ORACLE layer (transformers modeling_qwen2.py:269-298 as
+                        restated in oracle/decoder.py) run on the same DE-QUANTISED operands: must stay at the 16-bit multi-layer tolerance;
+      quantisation   -- the same hidden states against the 16-bit HIP run: e4m3's 3 mantissa bits on random synthetic weights, measured per
+                        layer; the whole-model bound of test_full_size_configs4_whole_model_in_the_fp8_modes is derived from its growth;
+      decode         -- two teacher-forced decode steps of the 4-layer model on the e4m3 cache against the oracle on the de-quantised
+                        weights and the de-quantised cache."""
+    from oracle import KVCache, decode_step
+    from oracle.decoder import rope_cos_sin, qwen2_attention, qwen2_mlp
+    from oracle.vit import rms_norm
+    import json, os, time
+    dt, L, S = "bf16", 4, 16400
+    cfg = omchat13b()
+    cfg.text["num_hidden_layers"] = L
+    cfg.text["vocab_size"] = 2048
+    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 0).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(1)) * 0.5).bfloat16().float()
+    # ---- HIP: hidden states after 1..4 layers, fp8 modes on and off
+    hid8, hid16 = [], []
+    eL = None
+    for n in range(1, L + 1):
+        c = omchat13b(); c.text["num_hidden_layers"] = n; c.text["vocab_size"] = 2048
+        e = Engine(c, dtype=dt, max_seq=S + 64, max_batch=1, vision=False)
+        e.load_state_dict({k: v for k, v in sd.items() if ".layers." not in k or int(k.split(".")[2]) < n})
+        _, h16 = e.prefill(x, want_hidden=True, want_logits=False)
+        hid16.append(h16[0].float().cpu())
+        e.enable_fp8_prefill(True); e.enable_fp8_kv(True)
+        _, h8 = e.prefill(x, want_hidden=True, want_logits=False)
+        hid8.append(h8[0].float().cpu()); sync()
+        if n == L:
+            eL = e
+        else:
+            e.close()
+    # ---- oracle on the de-quantised operands, one pass over the four layers
+    t0 = time.time()
+    Q = lambda t: dequant_ref(t.to(torch.bfloat16).float().reshape(-1, t.shape[-1])).reshape(t.shape)      # per-token e4m3 of the 16-bit rows
+    sdq_pre = dict(sd)
+    for k, v in sd.items():
+        if k.endswith("weight") and any(s in k for s in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")):
+            sdq_pre[k] = dequant_ref(rnd(v, dt))
+    cos, sin = rope_cos_sin(torch.arange(S)[None], 128, cfg.text["rope_theta"], torch.float32)
+    cache = KVCache(L)
+    h, kern_err, quant_err = x, [], []
+    for i in range(L):
+        P = f"model.layers.{i}."
+        h = h + qwen2_attention(Q(rms_norm(h, sd[P + "input_layernorm.weight"], 1e-6)), sdq_pre, P, cfg.text, cos, sin, cache, i)
+        h = h + qwen2_mlp(Q(rms_norm(h, sd[P + "post_attention_layernorm.weight"], 1e-6)), sdq_pre, P)
+        ref = rms_norm(h, sd["model.norm.weight"], 1e-6)[0]
+        kern_err.append(rel(hid8[i], ref))
+        quant_err.append(rel(hid8[i], hid16[i]))
+    t_or = time.time() - t0
+    print(f"\nfp8 modes, {L} full-width layers, S = {S} (oracle pass {t_or:.0f} s): kernel error vs oracle on de-quantised operands {['%.3e' % v for v in kern_err]}; "
+          f"distance to the 16-bit HIP run {['%.3e' % v for v in quant_err]}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(dict(S=S, kernel_err=kern_err, quant_err=quant_err, oracle_s=t_or), open("gpurun_out/fp8_per_layer.json", "w"))
+    # The quantiser is discontinuous: a 16-bit rounding difference in a normed activation that sits next to an e4m3 rounding boundary moves that
+    # element by a whole e4m3 step (6 %), so the HIP path and the oracle cannot agree to the 16-bit tolerance once activations are quantised
+    # on both sides -- measured 2.7e-2 after one layer, growing as sqrt(layers) (profiles/r05_h_fp8_per_layer.json), about half of the distance
+    # to the 16-bit run.  A kernel error (a wrong or transposed scale, a stale replica) puts the result FURTHER from this oracle than the
+    # quantisation noise itself.
+    for i in range(L):
+        assert kern_err[i] < 1.5 * TOL_DEEP[dt] * (i + 1) ** 0.5, (i, kern_err[i])
+        assert kern_err[i] < 0.8 * quant_err[i], (i, kern_err[i], quant_err[i])
+    # quantisation noise: about the e4m3 step per layer, growing no faster than sqrt(layers) x the first layer's (independent errors)
+    assert 5e-3 < quant_err[0] < 0.12, quant_err
+    for i in range(1, L):
+        assert quant_err[i] < 1.25 * quant_err[0] * (i + 1) ** 0.5 + 0.01, (i, quant_err)
+    # ---- decode on the e4m3 cache: oracle on de-quantised weights + de-quantised cache rows
+    eL.enable_fp8_decode(True)
+    dq = lambda t: dequant_ref(t.to(torch.bfloat16).float().reshape(-1, 128)).reshape(t.shape)
+    cq = KVCache(L)
+    for i in range(L):
+        cq.update(dq(cache.k[i]), dq(cache.v[i]), i)
+    sdq = _dequant_decoder_weights(sd, dt)
+    for tok in (5, 9):
+        nxt, lg = eL.decode_step(torch.tensor([tok]), want_logits=True); sync()
+        r = decode_step(torch.tensor([[tok]]), sdq, cfg.text, cq)[0, 0]
+        d = rel(lg[0].float().cpu(), r)
+        print(f"decode step on the e4m3 cache, {L} layers: logit distance to the oracle on de-quantised operands {d:.3e}")
+        assert d < 6e-2, d
+    eL.close()

@@ -267,7 +267,10 @@ def test_full_size_configs4_whole_model_in_the_fp8_modes(gpu_lib):
         # closer at the decode steps (measured, profiles/r04_j_pytest_gpu.txt) -- cosine > 0.96.  A broken scale, a transposed scale
         # vector or a stale replica decorrelates the logits (distance >= 1)
         cos = float(torch.dot(q.double(), r.double()) / (q.double().norm() * r.double().norm()))
-        assert errs[-1] < 0.4 and cos > 0.9, (k, errs[-1], cos)
+        # bound: per-layer quantisation distance 5.5e-2 at 16 k keys, growing as sqrt(layers) (tests/test_gpu_fp8.py::
+        # test_fp8_modes_error_per_layer_over_four_full_width_layers_16k_context: 0.055 / 0.078 / 0.095 / 0.110 after 1..4 layers) -> 0.29 after 28
+        # layers; measured 0.26; stated bound 0.33 (round 4: 0.4)
+        assert errs[-1] < 0.33 and cos > 0.94, (k, errs[-1], cos)
         noise = float((q - r).abs().max())
         top2 = torch.topk(r, 2).values
         if float(top2[0] - top2[1]) > 2.5 * noise:
