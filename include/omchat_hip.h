@@ -122,10 +122,19 @@ int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b, float* log
  * rotated to positions[i] (host int32 [b]; the reference's sum(attention_mask) - 1) and attends the cache slots j <= slots with
  * key_mask[i * mask_ld + j] != 0 (host bytes [b][mask_ld], mask_ld >= slots + 1: the token-level mask padded with ones -- it hides real
  * prompt slots and exposes padded ones once images expanded the rows differently).  Valid after omchat_prefill (right padding) and
- * omchat_prefill_left, for all b rows of that prefill, on one GPU with the 16-bit KV cache; omchat_decode_step and this entry cannot be
+ * omchat_prefill_left, for all b rows of that prefill, on one GPU (16-bit or e4m3 KV cache); omchat_decode_step and this entry cannot be
  * mixed after one prefill (they place the cache rows differently).  Synchronises the stream. */
 int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld,
                               float* logits, int32_t* next_tokens, void* stream);
+/* The same step WITHOUT per-step host data, for the loop HF generate drives (single_inference.py:53-62): there the decode branch pads the
+ * token-level mask with ones up to the cache length and every generated token appends another one (omchat_arch.py:63-69), so over the cache
+ * slots the key mask of every step is [the prompt's token-level mask | ones] and position_ids = sum(mask) - 1 grows by one per step.
+ * omchat_masked_decode_begin (once after the prefill; synchronises): key_mask host bytes [b][mask_ld], the first mask_cols columns are taken,
+ * every slot behind them counts as visible; positions host int32 [b] = the FIRST step's position_ids.  omchat_decode_step_masked_next (every
+ * step; no host buffer, no synchronisation): appends at the common slot, rotates to the device-resident positions and advances them.
+ * omchat_kv_rewind takes the positions back with the slots.  A call of omchat_decode_step_masked in between needs a new begin. */
+int omchat_masked_decode_begin(omchat_ctx* ctx, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld, int mask_cols, void* stream);
+int omchat_decode_step_masked_next(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream);
 /* Experimental one-launch forms of the batch-1 decode layer (default OFF, measured slower than the six launches; DESIGN.md section 6,
  * round 4): with tuning key 23 a decoder layer is ONE launch with in-launch hand-offs (csrc/decode_layer.hip), with key 22 attention +
  * merge + o_proj are one launch (csrc/fused_decode.hip); same bits as the separate launches either way.  launches: how many such launches

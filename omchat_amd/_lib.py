@@ -51,6 +51,8 @@ _SIGS = {
     "omchat_kv_lengths": (_i, [_vp, _vp, _i]),
     "omchat_kv_rewind": (_i, [_vp, _i, _i, _vp]),
     "omchat_decode_step_masked": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "omchat_masked_decode_begin": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "omchat_decode_step_masked_next": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "omchat_fused_status": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_uint)]),
     "omchat_set_allreduce_hook": (_i, [_vp, _vp, _vp]),
     "omchat_allreduce_noop": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),

@@ -1399,8 +1399,8 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
           a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh, tpw,
           a.key_mask, a.mask_sb};
-  OM_CHECK(!a.key_mask || (!kv8 && a.rope && a.pos && !a.kv_len && a.mask_sb % 64 == 0 && a.mask_sb >= a.L),
-           "masked decode: 16-bit cache, fused RoPE with explicit positions, uniform length, mask rows padded to a multiple of 64");
+  OM_CHECK(!a.key_mask || (((kv8 && !a.rope) || (!kv8 && a.rope && a.pos)) && !a.kv_len && a.mask_sb % 64 == 0 && a.mask_sb >= a.L),
+           "masked decode: fused RoPE with explicit positions (16-bit cache) or rows appended beforehand (e4m3 cache), uniform length, mask rows padded to a multiple of 64");
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
   OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
@@ -1411,7 +1411,8 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
   if (dtype == OMCHAT_F16) {
-    if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
+    if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true, true>), grid, dim3(64), 0, s, p);
+    else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 2>), grid, dim3(64), dma_lds, s, p);
     else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 3>), grid, dim3(64), dma_lds, s, p);
@@ -1428,7 +1429,8 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     }
     else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
   } else if (dtype == OMCHAT_BF16) {
-    if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
+    if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true, true>), grid, dim3(64), 0, s, p);
+    else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 2>), grid, dim3(64), dma_lds, s, p);
     else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 3>), grid, dim3(64), dma_lds, s, p);

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, int S, int nq, int nkv, const int* pos, int pos0,
                                                       const float* cos_sin, int max_pos, T* kc, T* vc, int64_t c_sb, int64_t c_sh,
-                                                      unsigned char* kq8, unsigned char* vq8, float* ks, float* vs, int64_t s_sb, int64_t s_sh) {
+                                                      unsigned char* kq8, unsigned char* vq8, float* ks, float* vs, int64_t s_sb, int64_t s_sh, int slot0) {
   typedef typename V8<T>::type v8;
   const int nh = nq + 2 * nkv;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, 
   if (item >= (long)rows * nh) return;
   const int row = (int)(item / nh), h = (int)(item % nh);
   const int bi = row / S;
-  int pp = pos ? pos[row] : pos0 + (row % S);
+  const int pr = pos ? pos[row] : pos0 + (row % S);      // RoPE position
+  const int pp = slot0 >= 0 ? slot0 + (row % S) : pr;     // cache slot
   T* src = qkv + (size_t)row * ld + h * 128;
   // fp8 KV cache: the 16-lane group holds the whole 128-element row: s = absmax / 448 (1 for a zero row), bytes = e4m3_rne(x / s) --
   // attention.hip: kv_quant_kernel's arithmetic on the 16-bit values just stored, so the same bytes
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* qkv, int ld, int rows, 
     if (vq8) quant_row(vv, vq8 + bi * c_sb + kvh * c_sh + (int64_t)pp * 128, vs + bi * s_sb + kvh * s_sh + pp);
     return;
   }
-  const int pt = pp < max_pos ? pp : max_pos - 1;
+  const int pt = pr < max_pos ? pr : max_pos - 1;
   const v8 x = ld8<T>(src + c * 8);
   const v8 o = ld8<T>(src + ((c + 8) & 15) * 8);    // partner chunk (d +- 64)
   const float sgn = c < 8 ? -1.f : 1.f;             // rotate_half: first half gets -x2, second half +x1
@@ -590,7 +591,7 @@ int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s) {
   const long items = (long)a.rows * (a.nq + 2 * a.nkv) * 16;
   DISPATCH(dtype, hipLaunchKernelGGL(rope_kv_kernel<T>, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, s, (T*)a.qkv, a.ld, a.rows, a.S,
                                      a.nq, a.nkv, a.pos, a.pos0, a.cos_sin, a.max_pos, (T*)a.kcache, (T*)a.vcache, a.c_sb, a.c_sh,
-                                     (unsigned char*)a.k8, (unsigned char*)a.v8, a.ks, a.vs, a.s_sb, a.s_sh));
+                                     (unsigned char*)a.k8, (unsigned char*)a.v8, a.ks, a.vs, a.s_sb, a.s_sh, a.slot0));
   OM_LAUNCH_CHECK();
   return 0;
 }

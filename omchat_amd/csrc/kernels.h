@@ -226,6 +226,9 @@ struct RopeArgs {
   // of its own): e4m3 bytes into k8 / v8 (same [b, nkv, cap, 128] layout, strides in elements = bytes), one fp32 scale per row into
   // ks / vs [b][nkv][s_sh]
   void* k8 = nullptr; void* v8 = nullptr; float* ks = nullptr; float* vs = nullptr; int64_t s_sb = 0, s_sh = 0;
+  // cache slot of row r when it differs from the RoPE position (masked decode of a padded batch: every row appends at the COMMON slot and
+  // rotates to its own position, omchat_arch.py:61-70): slot0 + (r % S); -1 = the position itself
+  int slot0 = -1;
 };
 int launch_rope_kv(int dtype, const RopeArgs& a, hipStream_t s);
 

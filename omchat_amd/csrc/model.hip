@@ -26,6 +26,10 @@ __global__ void cast_from_f32_f16(const float* s, f16* d, int64_t n) {
 __global__ void cast_from_f32_bf16(const float* s, bf16* d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (bf16)s[i];
 }
+__global__ void add_positions_kernel(int* pos, int b, int d) {
+  const int i = threadIdx.x;
+  if (i < b) pos[i] += d;
+}
 __global__ void advance_lens_kernel(int* pos, int* len, int b) {
   const int i = threadIdx.x;
   if (i < b) { pos[i] += 1; len[i] += 1; }
@@ -158,6 +162,7 @@ struct omchat_ctx {
   // dec_mode: 0 = no decode step since the prefill, 1 = omchat_decode_step (per-sequence lengths), 2 = omchat_decode_step_masked
   int pre_S = 0, pre_b = 0, masked_steps = 0, dec_mode = 0;
   unsigned char* d_mask = nullptr; int64_t mask_sb = 0;
+  bool mask_on_device = false;      // d_mask holds [prompt mask | ones] for the whole cache (omchat_masked_decode_begin)
   void *kcache = nullptr, *vcache = nullptr;   // [layers][max_batch][kv_heads][max_seq][128]
   std::vector<int> h_len;
   // optional per-kernel-class HIP-event timing (bench.py roofline): category -> event pairs recorded on the launch stream
@@ -968,7 +973,7 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     klen[i] = left ? S : lengths[i]; kstart[i] = left ? S - lengths[i] : 0;
   }
   ctx->left_padded = left;
-  ctx->pre_S = S; ctx->pre_b = b; ctx->masked_steps = 0; ctx->dec_mode = 0;
+  ctx->pre_S = S; ctx->pre_b = b; ctx->masked_steps = 0; ctx->dec_mode = 0; ctx->mask_on_device = false;
   // d_len holds the valid key range end during prefill; switched to (len + 1, pos = len) for the decode steps at the end
   OM_HIP(hipMemcpyAsync(ctx->d_len, klen.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
   if (left) OM_HIP(hipMemcpyAsync(ctx->d_start, kstart.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
@@ -1192,7 +1197,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (!fused) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, b, H, c.t_eps, s));
     // batch 1, one GPU (round 4): the whole layer as ONE launch with in-launch hand-offs (decode_layer.hip; the same bits as the six
     // launches below).  Eager steps only: the launch is tagged with a per-launch counter, which a captured graph would freeze.
-    if (g_decode_layer && n1 && exact_len && !f8 && !(ctx->fp8_kv && ctx->kv8_valid) && ctx->dl_ws) {
+    if (g_decode_layer && n1 && exact_len && !masked && !f8 && !(ctx->fp8_kv && ctx->kv8_valid) && ctx->dl_ws) {      // (the layer kernel has no key mask)
       DecodeLayerArgs d{L.ln1, L.ln2, L.wqkv, L.bqkv, L.wo, L.wgu, L.wd, kc, vc, ctx->cache_sh(), x, H, qd, ctx->t_kvdim, It, c.t_heads, c.t_kv_heads, Lmax,
                         ctx->rope, c.max_seq, c.t_eps, 0.08838834764831845f, ctx->dl_ws, ++ctx->fd_epoch, ctx->fd_err, 2000};
       if (decode_layer_ok(d)) {
@@ -1233,7 +1238,8 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       RopeArgs r{ctx->tw_qkv, qkvd, b, 1, c.t_heads, c.t_kv_heads, ctx->d_pos, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
       r.k8 = (char*)ctx->k8cache + off; r.v8 = (char*)ctx->v8cache + off; r.ks = ctx->ks8 + so; r.vs = ctx->vs8 + so;
       r.s_sb = (int64_t)c.t_kv_heads * c.max_seq; r.s_sh = c.max_seq;
-      if (exact_len) { r.pos = nullptr; r.pos0 = Lmax - 1; }      // the position by value: one dependent load less in front of the table read
+      if (masked) r.slot0 = Lmax - 1;                              // padded batch: common cache slot, per-row RoPE positions from d_pos
+      else if (exact_len) { r.pos = nullptr; r.pos0 = Lmax - 1; }      // the position by value: one dependent load less in front of the table read
       TRY(launch_rope_kv(ctx->dt, r, s));
       a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
       a.K = (char*)ctx->k8cache + off; a.V = (char*)ctx->v8cache + off;
@@ -1405,35 +1411,76 @@ extern "C" int omchat_decode_step(omchat_ctx* ctx, const int32_t* tokens, int b,
 // which hides real prompt slots and exposes padded ones once images expanded the rows differently.  After a right-padded prefill the
 // padded slots hold the K / V of causally un-masked padded query rows (what every backend of the reference computes); after a
 // left-padded one those of fully masked rows, which the prefill filled as the reference's eager (CPU) attention does.
-extern "C" int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask,
-                                         int mask_ld, float* logits, int32_t* next_tokens, void* stream) {
-  OM_CHECK(ctx && tokens && positions && key_mask, "null argument");
+static int masked_common_checks(omchat_ctx* ctx, int b) {
   const omchat_config& c = ctx->c;
   OM_CHECK(c.t_layers > 0, "context has no decoder");
   OM_CHECK(ctx->pre_S >= 1 && b == ctx->pre_b, "masked decode: the batch of the last prefill, all rows");
   OM_CHECK(ctx->dec_mode != 1, "omchat_decode_step_masked after omchat_decode_step on the same prefill: the two place the cache rows differently");
-  OM_CHECK(ctx->tp_size == 1 && !(ctx->fp8_kv && ctx->kv8_valid), "masked decode: one GPU, 16-bit KV cache");
-  const int Lc = ctx->pre_S + ctx->masked_steps;          // slots every row holds; the new token goes to slot Lc
-  OM_CHECK(Lc + 1 <= c.max_seq, "KV cache full (max_seq)");
-  OM_CHECK(mask_ld >= Lc + 1, "key_mask rows must cover the cache and the new token (slots + 1 columns)");
-  hipStream_t s = (hipStream_t)stream;
+  OM_CHECK(ctx->tp_size == 1, "masked decode: one GPU (under tensor parallelism right-padded batches take the per-sequence step)");
+  OM_CHECK(ctx->pre_S + ctx->masked_steps + 1 <= c.max_seq, "KV cache full (max_seq)");
   if (!ctx->d_mask) {
     ctx->mask_sb = (int64_t)cdiv(c.max_seq, 64) * 64;
     TRY(ctx->alloc((void**)&ctx->d_mask, (size_t)c.max_batch * ctx->mask_sb));
   }
-  std::vector<int> pos(b);
+  // replicas first: a failure here must not leave host-to-device copies of caller / stack memory in flight
+  if (b > 1 && b <= 32) TRY(ensure_packed(ctx));
+  if (ctx->fp8_decode && ctx->fp8_stale) TRY(ensure_fp8_weights(ctx));
+  return 0;
+}
+
+extern "C" int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, const int32_t* positions, const uint8_t* key_mask,
+                                         int mask_ld, float* logits, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && tokens && positions && key_mask, "null argument");
+  const omchat_config& c = ctx->c;
+  TRY(masked_common_checks(ctx, b));
+  const int Lc = ctx->pre_S + ctx->masked_steps;          // slots every row holds; the new token goes to slot Lc
+  OM_CHECK(mask_ld >= Lc + 1, "key_mask rows must cover the cache and the new token (slots + 1 columns)");
+  hipStream_t s = (hipStream_t)stream;
   for (int i = 0; i < b; ++i) {
     OM_CHECK(positions[i] >= 0 && positions[i] < c.max_seq, "position outside the RoPE table");
     OM_CHECK(key_mask[(size_t)i * mask_ld + Lc] != 0, "the new token must see itself");
-    pos[i] = positions[i];
   }
+  ctx->mask_on_device = false;      // the device copy holds THIS step's mask, zero-padded: omchat_decode_step_masked_next needs a new begin
   OM_HIP(hipMemsetAsync(ctx->d_mask, 0, (size_t)b * ctx->mask_sb, s));
   OM_HIP(hipMemcpy2DAsync(ctx->d_mask, (size_t)ctx->mask_sb, key_mask, (size_t)mask_ld, (size_t)Lc + 1, (size_t)b, hipMemcpyHostToDevice, s));
-  OM_HIP(hipMemcpyAsync(ctx->d_pos, pos.data(), (size_t)b * 4, hipMemcpyHostToDevice, s));
-  if (b > 1 && b <= 32) TRY(ensure_packed(ctx));
-  if (ctx->fp8_decode && ctx->fp8_stale) TRY(ensure_fp8_weights(ctx));
+  OM_HIP(hipMemcpyAsync(ctx->d_pos, positions, (size_t)b * 4, hipMemcpyHostToDevice, s));
   const int rc = decode_body(ctx, tokens, b, Lc + 1, logits, next_tokens, s, false, true, true);
-  OM_HIP(hipStreamSynchronize(s));     // pos is a stack vector; the caller's mask may be reused
+  OM_HIP(hipStreamSynchronize(s));     // the caller's mask / positions may be reused as soon as this returns
+  if (rc) return rc;
+  ctx->masked_steps += 1;
+  ctx->dec_mode = 2;
+  return 0;
+}
+
+// The same step without per-step host data (round 5).  In the loop HF generate drives (single_inference.py:53-62 on a padded batch) the decode
+// branch of prepare_inputs_labels_for_multimodal (omchat_arch.py:61-70) pads the token-level mask with ONES up to the cache length, and every
+// generated token appends another one: over the cache slots the key mask of step k is [token-level mask of the PROMPT | ones], the same for
+// every k, and position_ids = sum(mask) - 1 grows by one per step.  So the mask goes to the device once (begin: `mask_cols` columns from the
+// caller, ones behind them) with the first step's positions, and every following step (next) takes its positions from the device, where the
+// greedy pick of the previous step advanced them: no host buffer, no stream synchronisation, and the caller may enqueue step k + 1 before it
+// has read token k (OmChatQwen2ForCausalLM.generate).  Arbitrary per-step masks keep omchat_decode_step_masked.
+extern "C" int omchat_masked_decode_begin(omchat_ctx* ctx, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld, int mask_cols,
+                                          void* stream) {
+  OM_CHECK(ctx && positions && key_mask, "null argument");
+  const omchat_config& c = ctx->c;
+  TRY(masked_common_checks(ctx, b));
+  OM_CHECK(mask_cols >= 1 && mask_cols <= mask_ld && mask_cols <= c.max_seq, "mask_cols: 1 .. min(mask_ld, max_seq)");
+  for (int i = 0; i < b; ++i) OM_CHECK(positions[i] >= 0 && positions[i] < c.max_seq, "position outside the RoPE table");
+  hipStream_t s = (hipStream_t)stream;
+  OM_HIP(hipMemsetAsync(ctx->d_mask, 1, (size_t)b * ctx->mask_sb, s));
+  OM_HIP(hipMemcpy2DAsync(ctx->d_mask, (size_t)ctx->mask_sb, key_mask, (size_t)mask_ld, (size_t)mask_cols, (size_t)b, hipMemcpyHostToDevice, s));
+  OM_HIP(hipMemcpyAsync(ctx->d_pos, positions, (size_t)b * 4, hipMemcpyHostToDevice, s));
+  OM_HIP(hipStreamSynchronize(s));     // once per generation: the caller's buffers are free again
+  ctx->mask_on_device = true;
+  return 0;
+}
+
+extern "C" int omchat_decode_step_masked_next(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream) {
+  OM_CHECK(ctx && tokens, "null argument");
+  TRY(masked_common_checks(ctx, b));
+  OM_CHECK(ctx->mask_on_device, "omchat_decode_step_masked_next: call omchat_masked_decode_begin after the prefill (and after any omchat_decode_step_masked)");
+  const int Lc = ctx->pre_S + ctx->masked_steps;
+  const int rc = decode_body(ctx, tokens, b, Lc + 1, logits, next_tokens, (hipStream_t)stream, false, true, true);
   if (rc) return rc;
   ctx->masked_steps += 1;
   ctx->dec_mode = 2;
@@ -1511,6 +1558,9 @@ extern "C" int omchat_kv_rewind(omchat_ctx* ctx, int b, int n, void* stream) {
   if (ctx->dec_mode == 2) {
     OM_CHECK(n <= ctx->masked_steps, "rewind beyond the prefill");
     ctx->masked_steps -= n;
+    // the device-resident positions (omchat_decode_step_masked_next) go back with the slots; the host-mask form passes its positions every step
+    hipLaunchKernelGGL(add_positions_kernel, dim3(1), dim3(64 > b ? 64 : b), 0, (hipStream_t)stream, ctx->d_pos, b, -n);
+    OM_LAUNCH_CHECK();
     return 0;
   }
   std::vector<int> pos(b), len1(b);

@@ -159,7 +159,7 @@ class Engine:
 
     def masked_decode_supported(self):
         """omchat_decode_step_masked (padded-batch decode as omchat_arch.py:61-70 computes it) runs on one GPU; see include/omchat_hip.h"""
-        return self.tp_size == 1 and not getattr(self, "_fp8_kv", False)
+        return self.tp_size == 1
 
     def enable_fp8_prefill(self, on=True):
         """fp8 x fp8 MFMA for the qkv and gate|up GEMMs of the prefill (activations quantised per token, weights per output row)"""
@@ -282,6 +282,27 @@ class Engine:
         logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
         nxt = torch.empty(b, dtype=torch.int32, device=self.device)
         check(self.lib.omchat_decode_step_masked(self.h, ptr(tk), b, ptr(pos), ptr(m), m.shape[1], ptr(logits), ptr(nxt), cur_stream()))
+        return nxt, logits
+
+    def masked_decode_begin(self, position_ids, attention_mask):
+        """Once after the prefill of a padded batch that HF-style generate will decode: `attention_mask` [b, cols] is the key mask of the
+        FIRST decode step as the reference builds it (token-level mask, any ones padding may be left off: slots behind `cols` count as
+        visible), `position_ids` [b] its sum(mask) - 1.  decode_step_masked_next then needs no host data (include/omchat_hip.h)."""
+        torch = _torch()
+        pos = position_ids.detach().to("cpu", torch.int32).contiguous().view(-1)
+        m = attention_mask.detach().to("cpu").ne(0).to(torch.uint8).contiguous()
+        if m.dim() != 2 or pos.shape[0] != m.shape[0]:
+            raise ValueError("masked_decode_begin: position_ids [b], attention_mask [b, cols]")
+        cols = min(m.shape[1], self.c.max_seq)
+        check(self.lib.omchat_masked_decode_begin(self.h, m.shape[0], ptr(pos), ptr(m), m.shape[1], cols, cur_stream()))
+
+    def decode_step_masked_next(self, tokens, want_logits=False):
+        torch = _torch()
+        tk = tokens.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+        b = tk.shape[0]
+        logits = torch.empty(b, self.c.t_vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        nxt = torch.empty(b, dtype=torch.int32, device=self.device)
+        check(self.lib.omchat_decode_step_masked_next(self.h, ptr(tk), b, ptr(logits), ptr(nxt), cur_stream()))
         return nxt, logits
 
     def fused_status(self):

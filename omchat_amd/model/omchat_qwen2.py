@@ -179,6 +179,15 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
 
     __call__ = forward
 
+    def _stage_buffer(self, steps, b):
+        """pinned staging rows for the generated ids + the event that guards them: allocated once and grown on demand (a hipHostMalloc per
+        generate() call was measurable)"""
+        cur = getattr(self, "_stage", None)
+        if cur is None or cur.shape[0] < steps or cur.shape[1] != b:
+            self._stage = torch.empty((max(steps, 64), b), dtype=torch.int32).pin_memory()
+            self._stage_event = torch.cuda.Event()
+        return self._stage
+
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
         """omchat_qwen2.py:92-111."""
         if past_key_values:
@@ -224,24 +233,35 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             max_new_tokens = max(room, 1)
         new = []
         done = torch.zeros(b, dtype=torch.bool)
-        # padded batch (rows of different spliced length, or left padding): every step goes through forward() with the token-level mask
-        # grown by one 1 per generated token and `images` passed -- exactly the calls HF generate makes on the reference, so that the
-        # decode branch of prepare_inputs_labels_for_multimodal (omchat_arch.py:61-70) positions and masks the rows
+        # padded batch (rows of different spliced length, or left padding): decoded as the reference does it (omchat_arch.py:61-70).  HF generate
+        # passes the token-level mask grown by one 1 per generated token and `images` on every step; the decode branch pads it with ones to the
+        # cache length and takes position_ids = sum(mask) - 1.  Over the cache slots that key mask is the same at every step -- [prompt mask |
+        # ones] -- and the positions grow by one, so the branch is evaluated ONCE here (this class's mirror of it) and handed to the engine
+        # (masked_decode_begin); the steps then need no host data and run ahead of the host exactly like the unpadded ones.
         padded = getattr(self, "_padded_batch", False)
-        tok_mask = None
         if padded:
             tok_mask = (attention_mask if attention_mask is not None else torch.ones_like(input_ids)).to("cpu", torch.long)
+            m1 = torch.cat([tok_mask, torch.ones(b, 1, dtype=torch.long)], dim=1)
+            _, pos1, mask1, _, _, _ = self.prepare_inputs_labels_for_multimodal(torch.zeros(b, 1, dtype=torch.long), None, m1, out.past_key_values,
+                                                                                None, images)
+            if pos1 is None:          # text-only: Qwen2Model positions every row at the common cache length (modeling_qwen2.py:368-373)
+                pos1 = torch.full((b, 1), out.past_key_values.get_seq_length(), dtype=torch.long)
+            self.engine.masked_decode_begin(pos1, mask1)
+        step_fn = self.engine.decode_step_masked_next if padded else self.engine.decode_step
         # The host looks at every token (EOS, streamer, stopping criteria) as the reference's HF loop does -- but not with the GPU idle:
         # token k is copied to pinned host memory behind an event, step k + 1 is enqueued, and only then the host waits for the event.
         # When token k ends the generation the step that was already enqueued is taken back (omchat_kv_rewind).
-        stage = torch.empty((max_new_tokens, b), dtype=torch.int32).pin_memory()
+        stage = self._stage_buffer(max_new_tokens, b)
+        evt = self._stage_event
         for step in range(max_new_tokens):
             last = step == max_new_tokens - 1
             stage[step].copy_(tok.to(torch.int32), non_blocking=True)
-            evt = torch.cuda.Event(); evt.record()
+            evt.record()
             ahead = None
-            if not last and not padded:
-                ahead, _ = self.engine.decode_step(tok)               # runs while the host handles token `step`
+            if not last:
+                # rows that already ended are fed the pad id, as HF's loop does (their cache content then equals the reference's too)
+                feed = tok if (pad is None or not bool(done.any())) else torch.where(done.to(tok.device), torch.full_like(tok, pad), tok)
+                ahead, _ = step_fn(feed)                              # runs while the host handles token `step`
             evt.synchronize()
             t_cpu = stage[step].to(torch.int64)
             if pad is not None:
@@ -258,12 +278,7 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
                 if ahead is not None:
                     self.engine.kv_rewind(b, 1)
                 break
-            if padded:
-                tok_mask = torch.cat([tok_mask, torch.ones(b, 1, dtype=torch.long)], dim=1)
-                o = self.forward(input_ids=t_cpu[:, None], attention_mask=tok_mask, past_key_values=out.past_key_values, images=images, use_cache=True)
-                tok = o.next_tokens
-            else:
-                tok = ahead
+            tok = ahead
         if streamer is not None:
             streamer.end()
         return torch.cat([input_ids.cpu(), torch.stack(new, dim=1)], dim=1)

@@ -104,3 +104,154 @@ def test_decode_step_at_the_tp8_rank_widths_vs_oracle(gpu_lib, dt, b):
             assert rel(res[key][0][i], o1) < TOL_DEEP[dt], (key, i, rel(res[key][0][i], o1))
         assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
     assert rel(res[7][0], res[0][0]) < TOL_DEEP[dt]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# padded-batch decode (omchat_arch.py:61-70): device-resident mask / positions, e4m3 cache, full width
+# ---------------------------------------------------------------------------------------------------------------------
+def _tiny_padded(dt, g, fp8_kv=False):
+    import numpy as np
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+    cfg = tiny()
+    e = Engine(cfg, dtype=dt, max_seq=128, max_batch=2, max_tiles=3)
+    e.load_state_dict(synth.state_dict(cfg, int(g["seed"])))
+    if fp8_kv:
+        e.enable_fp8_kv(True)
+    m = OmChatQwen2ForCausalLM(cfg.clone(), e)
+    feats = rnd(torch.from_numpy(np.ascontiguousarray(g["feats"])).float(), dt)
+    m.encode_images = lambda images: feats.to(DT[dt]).cuda()
+    return cfg, e, m
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_masked_steps_without_host_data_give_the_bits_of_the_host_mask_steps(gpu_lib, dt, side):
+    """omchat_masked_decode_begin + omchat_decode_step_masked_next (mask and positions resident on the device, no synchronisation) against
+    omchat_decode_step_masked fed with the reference's own per-step masks / positions (tests/golden/leftpad_decode.npz): identical logits, both
+    padding sides; omchat_kv_rewind takes a speculative step back (slots AND positions)."""
+    from conftest import golden
+    g = golden("leftpad_decode")
+    ids, mask = torch.from_numpy(g["ids"]).long(), torch.from_numpy(g["mask"]).long()
+    dummy = torch.zeros(3, 3, 56, 56)
+    toks = [torch.from_numpy(g[f"{side}_tok_{k}"]).long() for k in range(int(g["steps"]))]
+    # (a) the host-mask form
+    cfg, e, m = _tiny_padded(dt, g)
+    m.config.mm["tokenizer_padding_side"] = side
+    kv = m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True).past_key_values
+    want = []
+    for k, t in enumerate(toks):
+        nxt, lg = e.decode_step_masked(t, torch.from_numpy(g[f"{side}_dec_pos_{k}"]), torch.from_numpy(g[f"{side}_dec_mask_{k}"]), want_logits=True)
+        want.append(lg.clone())
+    e.close()
+    # (b) the device-resident form: begin with the FIRST step's mask / positions only
+    cfg, e, m = _tiny_padded(dt, g)
+    m.config.mm["tokenizer_padding_side"] = side
+    m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
+    e.masked_decode_begin(torch.from_numpy(g[f"{side}_dec_pos_0"]), torch.from_numpy(g[f"{side}_dec_mask_0"]))
+    got = []
+    for k, t in enumerate(toks):
+        nxt, lg = e.decode_step_masked_next(t, want_logits=True)
+        got.append(lg.clone())
+        if k == 1:      # a speculative step that is taken back: the repeated step must give the same logits again
+            e.decode_step_masked_next(toks[2])
+            e.kv_rewind(2, 1)
+    sync()
+    for k in range(len(toks)):
+        assert torch.equal(got[k], want[k]), (side, k, rel(got[k], want[k]))
+    assert e.kv_lengths(2) == [int(g[side + "_S"]) + len(toks)] * 2
+    # the per-step mask form after `next` needs no begin; `next` after it does
+    e.decode_step_masked(toks[0], torch.from_numpy(g[f"{side}_dec_pos_0"]) + 3, torch.ones(2, int(g[side + "_S"]) + len(toks) + 1, dtype=torch.long))
+    with pytest.raises(ValueError, match="omchat_masked_decode_begin"):
+        e.decode_step_masked_next(toks[0])
+    e.close()
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_masked_decode_on_the_e4m3_cache(gpu_lib, side):
+    """round 4 refused the fp8 KV cache in the masked step; now the new rows are rotated to their own positions, appended AND quantised at the
+    common slot (rope_kv slot0) and the split-KV kernel applies the key mask on the e4m3 cache: logits within the e4m3 cache tolerance of the
+    16-bit masked steps (which match the reference), every step"""
+    from conftest import golden
+    g = golden("leftpad_decode")
+    dt = "bf16"
+    ids, mask = torch.from_numpy(g["ids"]).long(), torch.from_numpy(g["mask"]).long()
+    dummy = torch.zeros(3, 3, 56, 56)
+    res = {}
+    for f8 in (False, True):
+        cfg, e, m = _tiny_padded(dt, g, fp8_kv=f8)
+        m.config.mm["tokenizer_padding_side"] = side
+        m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
+        e.masked_decode_begin(torch.from_numpy(g[f"{side}_dec_pos_0"]), torch.from_numpy(g[f"{side}_dec_mask_0"]))
+        out = []
+        for k in range(int(g["steps"])):
+            _, lg = e.decode_step_masked_next(torch.from_numpy(g[f"{side}_tok_{k}"]).long(), want_logits=True)
+            out.append(lg.float().cpu())
+        sync(); e.close()
+        res[f8] = out
+    for k in range(int(g["steps"])):
+        ref = torch.from_numpy(g[f"{side}_logits_{k}"]).float()
+        d8, d16 = rel(res[True][k], ref), rel(res[False][k], ref)
+        assert d16 < TOL_DEEP[dt] and 1e-4 < rel(res[True][k], res[False][k]) < 0.08 and d8 < 0.08, (side, k, d8, d16)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_full_width_masked_decode_vs_the_oracle_restatement(gpu_lib, dt, side):
+    """the padded-batch decode at the REAL widths (Qwen2-7B: 3584 hidden, 28 query / 4 kv heads, MLP 18944; 2 layers, 1024
+    image tokens per sentinel): three rows of different spliced length (2 images + 12 ids, 1 image + 30 ids, 0 images + 9 ids), padded prefill,
+    three teacher-forced decode steps through generate()'s own path (begin + next) against the oracle's restatement of omchat_arch.py:61-70
+    (oracle.splice_inputs / decode_step_inputs / qwen2_model with the mask and position_ids the decode branch returns)."""
+    import numpy as np
+    import oracle
+    from omchat_amd.config import omchat13b
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+    cfg = omchat13b()
+    cfg.text["num_hidden_layers"] = 2
+    cfg.text["vocab_size"] = 2048
+    cfg.mm["tokenizer_padding_side"] = side
+    keep = lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k
+    sd = {k: v for k, v in synth.state_dict(cfg, 11).items() if keep(k)}
+    sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items()}
+    e = Engine(cfg, dtype=dt, max_seq=2200, max_batch=3, max_tiles=1, vision=False)
+    e.load_state_dict(sd)
+    m = OmChatQwen2ForCausalLM(cfg.clone(), e)
+    m.get_vision_tower = lambda: object()
+    feats = rnd(torch.randn(3, 1024, 3584, generator=torch.Generator().manual_seed(4)) * 0.3, dt)
+    m.encode_images = lambda images: feats.to(DT[dt]).cuda()
+    T = 32
+    rows = [[5, -200, 6, -200] + list(range(10, 20)), [-200] + list(range(30, 60)), list(range(100, 109))]
+    ids = torch.zeros(3, T, dtype=torch.long); mask = torch.zeros(3, T, dtype=torch.long)
+    for i, r in enumerate(rows):
+        if side == "left":
+            ids[i, T - len(r):] = torch.tensor(r); mask[i, T - len(r):] = 1
+        else:
+            ids[i, :len(r)] = torch.tensor(r); mask[i, :len(r)] = 1
+    dummy = torch.zeros(3, 3, 448, 448)
+    out = m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
+    kv = out.past_key_values
+    # oracle: splice, padded prefill, decode branch
+    emb_o, mask_sp, lengths = oracle.splice_inputs(ids, mask, [f for f in feats], sdt["model.embed_tokens.weight"], side, None)
+    assert lengths == [2 * 1024 + 12, 1024 + 30, 9] and kv.get_seq_length() == emb_o.shape[1] == 2060
+    cache = oracle.KVCache(2)
+    h = oracle.qwen2_model(emb_o, sdt, cfg.text, cache, None, mask_sp)
+    last = [n - 1 for n in lengths] if side == "right" else [emb_o.shape[1] - 1] * 3
+    ref0 = torch.stack([oracle.lm_head(h[i:i + 1, last[i]:last[i] + 1], sdt)[0, 0] for i in range(3)])
+    for i in range(3):
+        assert rel(out.logits[i, 0], ref0[i]) < TOL_DEEP[dt], (side, "prefill", i, rel(out.logits[i, 0], ref0[i]))
+    tok = torch.argmax(ref0, dim=-1)
+    tok_mask = torch.cat([mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
+    _, pos1, mask1, _, _, _ = m.prepare_inputs_labels_for_multimodal(tok[:, None], None, tok_mask, kv, None, dummy)
+    e.masked_decode_begin(pos1, mask1)
+    for k in range(3):
+        mo, po = oracle.decode_step_inputs(tok_mask, cache.get_seq_length())
+        if k == 0:
+            assert np.array_equal(mo.numpy(), mask1.numpy()) and np.array_equal(po.numpy(), pos1.numpy())
+        ho = oracle.qwen2_model(sdt["model.embed_tokens.weight"][tok][:, None], sdt, cfg.text, cache, po, mo)
+        ref = oracle.lm_head(ho, sdt)[:, -1]
+        nxt, lg = e.decode_step_masked_next(tok, want_logits=True); sync()
+        for i in range(3):
+            assert rel(lg[i], ref[i]) < TOL_DEEP[dt], (side, k, i, rel(lg[i], ref[i]))
+        tok = torch.argmax(ref, dim=-1)
+        tok_mask = torch.cat([tok_mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
+    assert e.kv_lengths(3) == [2063] * 3
+    e.close()
