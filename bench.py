@@ -766,6 +766,32 @@ def main():
                            "note": "OmChatQwen2ForCausalLM.generate(input_ids, images=...) wall time per call (host-side splice plan, one pinned "
                                    "token copy + event wait per generated token, step k + 1 enqueued before token k is read); NOT `value`"}
         res["generate_tokens_per_sec"] = a.gen / whole
+        if B2 >= 2 and n_tiles >= 2:
+            # a PADDED batch through the same entry: two rows of different spliced length (n_tiles tiles vs 1 tile + the same text), the
+            # shorter one right-padded -> the reference's decode branch (omchat_arch.py:61-70: common cache slot, sum(mask) - 1 positions, token-level
+            # key mask), which the engine runs from device-resident masks / positions (omchat_decode_step_masked_next: no per-step synchronisation)
+            ids_a = make_ids(cfg, n_tiles, 1)[0].tolist()
+            ids_b = make_ids(cfg, 1, 1)[0].tolist()
+            T2 = max(len(ids_a), len(ids_b))
+            ids2 = torch.zeros(2, T2, dtype=torch.int64); mask2 = torch.zeros(2, T2, dtype=torch.int64)
+            for i, r in enumerate((ids_a, ids_b)):
+                ids2[i, :len(r)] = torch.tensor(r); mask2[i, :len(r)] = 1
+            px2, _ = make_inputs(1, nt=n_tiles + 1)
+            model.generate(ids2, images=px2, attention_mask=mask2, max_new_tokens=8, eos_token_id=None, pad_token_id=0)      # warm
+            tp, tp1 = [], []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                model.generate(ids2, images=px2, attention_mask=mask2, max_new_tokens=1, eos_token_id=None, pad_token_id=0)
+                torch.cuda.synchronize(); tp1.append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                o2 = model.generate(ids2, images=px2, attention_mask=mask2, max_new_tokens=a.gen, eos_token_id=None, pad_token_id=0)
+                torch.cuda.synchronize(); tp.append(time.perf_counter() - t0)
+            assert o2.shape == (2, T2 + a.gen) and getattr(model, "_padded_batch", False)
+            wp, fp = sorted(tp)[1], sorted(tp1)[1]
+            res["generate_padded_batch"] = {"rows": 2, "spliced_lengths": [n_tiles * ntok + a.text_tokens, ntok + a.text_tokens], "tokens_per_sec": 2 * a.gen / wp,
+                                            "decode_ms_per_step": (wp - fp) / max(a.gen - 1, 1) * 1e3, "ms_per_call": wp * 1e3,
+                                            "note": "generate() on a ragged right-padded batch: masked decode steps as the reference computes them "
+                                                    "(omchat_arch.py:61-70), mask and positions resident on the device, step k + 1 enqueued before token k is read"}
     if world == 1 and not shard:
         n_f, bits = eng.fused_status()
         res["fused_decode"] = {"launches": n_f, "timeout_bits": bits,

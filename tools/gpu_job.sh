@@ -6,6 +6,8 @@
 #   stats [args]        rocprofv3 --kernel-trace --stats of bench.py with the given arguments
 #   pytest [args]       python -m pytest with the given arguments
 #   py script [args]    python3 script args
+#   suite               the driver's round-end sequence: pytest -m gpu (durations recorded), smoke(), bench.py default line
+#   ab key v1 v2 [args] bench.py once per value of tuning key `key` (same box), decode / ViT / prefill figures side by side
 #   table               configs[1]: kernel trace + FETCH_SIZE / WRITE_SIZE passes -> roofline_table.txt (tools/roofline_table.py), kernel stats CSV
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -30,6 +32,22 @@ case $job in
   bench) python3 bench.py "$@" > $O/bench.json 2> $O/bench.err; head -c 3000 $O/bench.json; tail -3 $O/bench.err ;;
   stats) stats run "$@" ;;
   pytest) python3 -m pytest "$@" 2>&1 | tail -30 | tee $O/pytest.txt ;;
+  suite)
+    timeout 1500 python3 -m pytest tests -m gpu -q --durations=40 > $O/pytest_gpu.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/pytest_gpu.txt
+    timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+    timeout 1200 python3 bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench rc=$?"; head -c 1500 $O/bench_final.json
+    ;;
+  ab)
+    key=$1; shift; vals="$1 $2"; shift 2
+    for v in $vals; do
+      python3 bench.py --no-cpu-baseline --no-side --no-fp8 --tuning $key=$v "$@" > $O/ab_${key}_$v.json 2> $O/ab_${key}_$v.err
+      python3 - <<PY
+import json
+d = json.load(open("$O/ab_${key}_$v.json")); c = d.get("configs2") or {}
+print("key $key = $v:", {k: round(d[k], 4) for k in ("value", "decode_ms_per_token_p50", "vit_ms_p50", "prefill_ms_p50") if d.get(k)}, {k: round(c[k], 4) for k in ("decode_ms_per_step_p50",) if c.get(k)})
+PY
+    done
+    ;;
   table)
     B="--workload configs1 --steps 1 --warmup 1 --gen 32 --no-cpu-baseline --no-fp8 --no-side"
     rm -rf $O/t $O/f $O/w
