@@ -307,6 +307,7 @@ def main():
 
     for kv in filter(None, a.tuning.split(",")):
         k, v = kv.split("=")
+        os.environ["OMCHAT_ALLOW_TUNING"] = "1"      # measurement hook: this process opts in (include/omchat_hip.h)
         _lib.check(_lib.lib().omchat_op_set_tuning(int(k), int(v)))
     do3 = a.workload == "configs3"
     do4 = a.workload == "configs4"

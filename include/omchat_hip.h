@@ -206,7 +206,8 @@ int omchat_mha_fwd_varlen(const void* qkv, int B, int S, int H, int D, const int
 int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                    const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream);
 /* same with the stream-K tail enabled: ws from omchat_op_gemm_sk_ws() bytes of device memory; stream_k 0 = auto, 1 = required */
-/* experiment knobs (key 0: start skew of the 256x256 GEMM workgroups, in units of ~1024 cycles; key 1: 1 = skinny GEMM
+/* experiment knobs -- PROCESS-GLOBAL test / measurement hooks shared by every context of the process: refused (error return) unless the
+ * process environment has OMCHAT_ALLOW_TUNING=1; nothing in the product sets a key.  (key 0: start skew of the 256x256 GEMM workgroups, in units of ~1024 cycles; key 1: 1 = skinny GEMM
  * always takes the MFMA form, 0 = batch 1 takes the whole-row streaming form; key 4: row count from which a tensor-parallel
  * row-parallel projection is pipelined against its all-reduce in 2 chunks (3x: 4 chunks), default 1024; key 5: 0 = GEMM tile
  * shapes from the cost model instead of the first-use measurement; key 6: 0 = batched decode steps (2 <= b <= 32) read the

@@ -1,5 +1,6 @@
 // Op-level C ABI entry points (unit parity tests / micro benches) and the FlashAttention-shaped seam.
 #include "kernels.h"
+#include <stdlib.h>
 #include "../../include/omchat_hip.h"
 #include <math.h>
 #include <vector>
@@ -12,7 +13,15 @@ extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, 
   return launch_gemm(dtype, g, S(stream));
 }
 
+// The tuning keys are PROCESS-GLOBAL switches for tests and measurements (A/B of kernel forms, launch shapes): they mutate state shared by
+// every context of the process, so production callers must not touch them -- the call is refused unless the process opted in with
+// OMCHAT_ALLOW_TUNING=1 in its environment (tests/conftest.py, bench.py --tuning and tools/gpu_job.sh set it).  Nothing in omchat_amd/ sets a key.
 extern "C" int omchat_op_set_tuning(int key, int value) {
+  const char* allow = getenv("OMCHAT_ALLOW_TUNING");
+  if (!allow || allow[0] != '1') {
+    omchat_set_error("omchat_op_set_tuning: process-global test / measurement hook; set OMCHAT_ALLOW_TUNING=1 to use it (see include/omchat_hip.h)");
+    return 1;
+  }
   if (key == 0) { gemm_set_skew(value); return 0; }
   if (key == 1) { gemv_set_force_mfma(value); return 0; }
   if (key == 5) { gemm_set_autotune(value); return 0; }

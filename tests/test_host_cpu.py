@@ -578,3 +578,27 @@ def test_roofline_table_labels_dispatches_by_role():
     W = rt.work(3, 512, 32)
     assert abs(W["ViT fc1 GEMM (GELU)"][1] / 1e9 - 251.9) < 0.1 and abs(W["ViT attention (MHA)"][1] / 1e9 - 40.3) < 0.1
     assert abs(W["decode gate|up GEMV (+RMSNorm)"][1] / 1e6 - 271.58) < 0.01 and abs(W["prefill attention (causal GQA)"][1] / 1e9 - 92.07) < 0.01
+
+
+def test_tuning_keys_are_refused_without_the_opt_in():
+    """the ~35 tuning keys are process-global state shared by every context; they are test / measurement hooks and are refused
+    unless the process opted in (OMCHAT_ALLOW_TUNING=1: conftest.py, bench.py --tuning, tools/gpu_job.sh).  No GPU needed: the call only sets globals."""
+    from omchat_amd import _lib
+    lib = _lib.lib()
+    saved = os.environ.pop("OMCHAT_ALLOW_TUNING", None)
+    try:
+        assert lib.omchat_op_set_tuning(34, 15) != 0
+        assert b"OMCHAT_ALLOW_TUNING" in lib.omchat_last_error()
+        os.environ["OMCHAT_ALLOW_TUNING"] = "1"
+        assert lib.omchat_op_set_tuning(34, 15) == 0
+        assert lib.omchat_op_set_tuning(9999, 1) != 0          # unknown key
+    finally:
+        if saved is None:
+            os.environ.pop("OMCHAT_ALLOW_TUNING", None)
+        else:
+            os.environ["OMCHAT_ALLOW_TUNING"] = saved
+    # nothing in the product package sets a key
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = subprocess.run(["grep", "-rn", "omchat_op_set_tuning(", os.path.join(root, "omchat_amd"), "--include=*.py"], capture_output=True, text=True).stdout
+    assert hits.strip() == "", hits

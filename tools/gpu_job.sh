@@ -10,6 +10,7 @@
 #   ab key v1 v2 [args] bench.py once per value of tuning key `key` (same box), decode / ViT / prefill figures side by side
 #   table               configs[1]: kernel trace + FETCH_SIZE / WRITE_SIZE passes -> roofline_table.txt (tools/roofline_table.py), kernel stats CSV
 cd /tmp && export TMPDIR=/tmp
+export OMCHAT_ALLOW_TUNING=1      # tools/*.py set tuning keys (process-global measurement hooks)
 R=$GRAFT_REPO_ROOT
 tag=$1; job=$2; shift 2
 O=$R/gpurun_out/$tag
