@@ -135,12 +135,15 @@ int omchat_decode_step_masked(omchat_ctx* ctx, const int32_t* tokens, int b, con
  * omchat_kv_rewind takes the positions back with the slots.  A call of omchat_decode_step_masked in between needs a new begin. */
 int omchat_masked_decode_begin(omchat_ctx* ctx, int b, const int32_t* positions, const uint8_t* key_mask, int mask_ld, int mask_cols, void* stream);
 int omchat_decode_step_masked_next(omchat_ctx* ctx, const int32_t* tokens, int b, float* logits, int32_t* next_tokens, void* stream);
-/* Experimental one-launch forms of the batch-1 decode layer (default OFF, measured slower than the six launches; DESIGN.md section 6,
- * round 4): with tuning key 23 a decoder layer is ONE launch with in-launch hand-offs (csrc/decode_layer.hip), with key 22 attention +
+/* Experimental one-launch forms of the batch-1 decode layer (NOT in the product build since round 5: compile with -DOMCHAT_EXPERIMENTS=1;
+ * measured slower than the six launches): with tuning key 23 a decoder layer is ONE launch with in-launch hand-offs (csrc/decode_layer.hip), with key 22 attention +
  * merge + o_proj are one launch (csrc/fused_decode.hip); same bits as the separate launches either way.  launches: how many such launches
  * this context has issued; timeout_bits: sticky bits of hand-offs that gave up after their wall-clock budget (0 = none; otherwise the
  * affected steps' results are wrong).  Synchronises. */
 int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* timeout_bits);
+/* 1 when the library was built with -DOMCHAT_EXPERIMENTS=1 (those one-launch forms and the work-stealing gate|up GEMV compiled in), 0 for
+ * the product build, in which tuning keys 22 / 23 / 24 select nothing. */
+int omchat_has_experiments(void);
 /* lm_head on arbitrary hidden rows (Qwen2ForCausalLM.forward :462-465): hidden [n, t_hidden] -> fp32 [n, t_vocab] */
 int omchat_lm_head(omchat_ctx* ctx, const void* hidden, int n, float* logits, void* stream);
 /* greedy pick (HF generate with do_sample=False: argmax of the last position, first index wins): logits fp32

@@ -54,6 +54,7 @@ _SIGS = {
     "omchat_masked_decode_begin": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "omchat_decode_step_masked_next": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "omchat_fused_status": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_uint)]),
+    "omchat_has_experiments": (_i, []),
     "omchat_set_allreduce_hook": (_i, [_vp, _vp, _vp]),
     "omchat_allreduce_noop": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
     "omchat_op_gemv_norm": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _vp, _f, _vp, _i, _i, _vp]),

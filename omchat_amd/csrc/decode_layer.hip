@@ -29,6 +29,8 @@
 // values, attention partials, merged attention row, x + attn row, activation row), so one tag per launch serves all.  Every spin is
 // bounded by the wall clock and reports through a sticky error word; the launch needs all its workgroups resident at once (grid = CUs,
 // 84 KB of LDS per workgroup = one per CU) and nothing else of this kind beside it.
+#include "kernels.h"
+#if OMCHAT_EXPERIMENTS
 #include "attn_common.h"
 #include "rowdot.h"
 
@@ -804,3 +806,5 @@ int launch_decode_layer(int dtype, const DecodeLayerArgs& a, hipStream_t s) {
   omchat_set_error("launch_decode_layer: bad dtype");
   return 1;
 }
+
+#endif  // OMCHAT_EXPERIMENTS

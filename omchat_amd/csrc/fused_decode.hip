@@ -20,6 +20,8 @@
 // of granules on a quiet chip.  Every spin is bounded by the wall clock (s_memrealtime) and reports through a sticky error word
 // (omchat_fused_status); the launch needs all its workgroups resident at once: grid = number of CUs, one workgroup per CU (84 KB of LDS
 // requested), nothing else of this kind running beside it.
+#include "kernels.h"
+#if OMCHAT_EXPERIMENTS
 #include "attn_common.h"
 #include "rowdot.h"
 
@@ -292,3 +294,5 @@ int launch_attn_oproj_fused(int dtype, const AttnDecodeArgs& a, const FusedDecod
   omchat_set_error("launch_attn_oproj_fused: bad dtype");
   return 1;
 }
+
+#endif  // OMCHAT_EXPERIMENTS

@@ -1240,10 +1240,12 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
     const bool want = EPI == EPI_SWIGLU ? (g_gemv_norm_loop & (F8 ? 4 : 1)) : (p.N < 32768 ? (g_gemv_norm_loop & 2) : (g_gemv_norm_loop & 8));
     const int n_cu = device_cus();
     // dynamic form: the outputs dealt by atomic counters instead of equal shares (the XCDs do not stream at the same rate); tuning key 24
+#if OMCHAT_EXPERIMENTS
     if (want && p.dyn && g_gemv_dyn && n_out >= 8 * n_cu) {
       hipLaunchKernelGGL((gemv_rows_norm_dyn_kernel<T, EPI, NCH, F8>), dim3(2 * n_cu), dim3(256), 0, s, p);
       return;
     }
+#endif
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
       const unsigned skew = (g_gemv_skew && n_out == per * 2 * n_cu && (2 * n_cu) % 8 == 0) ? g_gemv_skew : 0u;

@@ -1,6 +1,13 @@
 // Internal launcher interface (C++) shared by the op-level C ABI (capi.cpp) and the model loops (model.cpp).
 // Every launcher enqueues on `stream` and returns 0 / sets omchat_last_error().  dtype: OMCHAT_F16 | OMCHAT_BF16.
 #pragma once
+// Round-4 one-launch forms of the batch-1 decode layer (decode_layer.hip, fused_decode.hip) and the work-stealing gate|up GEMV: measured
+// SLOWER than the launches they replace and kept for the record only.  They are compiled in with
+// -DOMCHAT_EXPERIMENTS=1 (`python -m omchat_amd.build --twin ab_lib/experiments -DOMCHAT_EXPERIMENTS=1`); the product library has stubs
+// that refuse, tuning keys 22 / 23 / 24 then do nothing, and omchat_has_experiments() reports which build is loaded.
+#ifndef OMCHAT_EXPERIMENTS
+#define OMCHAT_EXPERIMENTS 0
+#endif
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ GEMM

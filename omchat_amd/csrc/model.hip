@@ -73,6 +73,16 @@ struct Route {
 
 }  // namespace
 
+#if !OMCHAT_EXPERIMENTS
+// product build: the round-4 one-launch experiments are not compiled in (kernels.h); their entry points refuse
+size_t fused_decode_ws_bytes(int) { return 0; }
+bool attn_oproj_fused_ok(const AttnDecodeArgs&, int, int) { return false; }
+int launch_attn_oproj_fused(int, const AttnDecodeArgs&, const FusedDecodeArgs&, hipStream_t) { omchat_set_error("fused decode launch: build with -DOMCHAT_EXPERIMENTS=1"); return 1; }
+size_t decode_layer_ws_bytes(int, int, int, int, int) { return 0; }
+bool decode_layer_ok(const DecodeLayerArgs&) { return false; }
+int launch_decode_layer(int, const DecodeLayerArgs&, hipStream_t) { omchat_set_error("one-launch decode layer: build with -DOMCHAT_EXPERIMENTS=1"); return 1; }
+#endif
+extern "C" int omchat_has_experiments(void) { return OMCHAT_EXPERIMENTS; }
 int g_decode_layer = 0;          // omchat_op_set_tuning key 23: 1 = batch-1 decode on one GPU runs each decoder layer as ONE launch (decode_layer.hip); 0 = six launches (same bits)
 void model_set_decode_layer(int v) { g_decode_layer = v; }
 int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
@@ -381,7 +391,7 @@ int build(omchat_ctx* ctx) {
     ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
     TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
     TRY(ctx->alloc((void**)&ctx->tw_part, (size_t)DEC_KS_MAX * c.max_batch * H * 4));
-    if (ctx->tp_size == 1) {
+    if (ctx->tp_size == 1 && OMCHAT_EXPERIMENTS) {
       const size_t fb = fused_decode_ws_bytes(c.t_heads);
       TRY(ctx->alloc(&ctx->fd_ws, fb));
       TRY(ctx->alloc((void**)&ctx->fd_err, 64));

@@ -36,3 +36,23 @@ def sync():
 def randn(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
+
+
+def synth_state_dict(cfg, seed=0, keep=None):
+    """omchat_amd.synth.state_dict evaluated on the DEVICE (omchat_op_fill_uniform: the same counter-based generator, bit-identical --
+    tests/test_gpu_ops.py::test_fill_uniform_bit_exact_with_host_generator) and copied to the host as fp32 numpy arrays.  The numpy generator
+    takes ~80 s for one full-width decoder layer; this takes ~1 s.  keep: predicate on the key."""
+    import math
+    from omchat_amd import synth
+    lib = _lib.lib()
+    out = {}
+    for key, shape, std, off in synth.tensor_specs(cfg):
+        if keep is not None and not keep(key):
+            continue
+        n = int(np.prod(shape))
+        t = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        scale = float(np.float32(std)) * math.sqrt(3.0)
+        _lib.check(lib.omchat_op_fill_uniform(_lib.BF16, ptr(t), n, (synth.fnv1a64(key) ^ seed) & 0xFFFFFFFFFFFFFFFF, scale, off, None))
+        torch.cuda.synchronize()
+        out[key] = t.float().cpu().view(*shape).numpy()
+    return out

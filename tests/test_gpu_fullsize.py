@@ -12,7 +12,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from gpu_util import rel, sync
+from gpu_util import rel, sync, synth_state_dict
 from omchat_amd import synth
 from omchat_amd.config import omchat13b
 from omchat_amd.engine import Engine
@@ -194,7 +194,7 @@ def test_long_context_decode_16k_one_full_width_layer(gpu_lib):
     cfg.text["vocab_size"] = 2048
     S = 16400
     e = Engine(cfg, dtype="bf16", max_seq=S + 64, max_batch=1, vision=False)
-    sd = {k: T32(v) for k, v in synth.state_dict(cfg, 0).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    sd = {k: T32(v) for k, v in synth_state_dict(cfg, 0, lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k).items()}
     e.load_state_dict(sd)
     x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(1)) * 0.5).bfloat16().float()
     logits, _ = e.prefill(x); torch.cuda.synchronize()

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 from conftest import golden
-from gpu_util import DT, TOL, TOL_DEEP, dev, rnd, rel, sync
+from gpu_util import DT, TOL, TOL_DEEP, dev, rnd, rel, sync, synth_state_dict
 from omchat_amd import synth, _lib
 from omchat_amd.config import tiny, omchat13b, OmChatConfig
 from omchat_amd.engine import Engine
@@ -223,7 +223,7 @@ def test_full_width_decoder_layer(gpu_lib, dt):
     cfg.text["num_hidden_layers"] = 1
     cfg.text["vocab_size"] = 2048
     e = Engine(cfg, dtype=dt, max_seq=512, max_batch=1, vision=False)
-    sd = {k: v for k, v in synth.state_dict(cfg, 0).items() if not k.startswith(synth.TOWER) and "mm_projector" not in k}
+    sd = synth_state_dict(cfg, 0, lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k)
     e.load_state_dict(sd)
     x = rnd(torch.randn(1, 300, 3584, generator=torch.Generator().manual_seed(1)) * 0.5, dt)
     logits, hidden = e.prefill(x, want_hidden=True); sync()
