@@ -118,7 +118,7 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
   const int key0 = split * KV_TILE;
   const bool fuse = WAVE_ONLY ? true : p.rope != nullptr;      // the fused launch always rotates and appends (its launcher checks)
   const int pp = kv_len - 1;                  // position of the token being appended (fuse)
-  const int pr = MASKED ? p.pos[b] : pp;      // RoPE position of the new token (MASKED: given, omchat_arch.py:70 sum(mask) - 1)
+  const int pr = (MASKED && p.pos) ? p.pos[b] : pp;      // RoPE position of the new token (MASKED: given, omchat_arch.py:70 sum(mask) - 1; none with the e4m3 cache: rope_kv ran before)
   const int pt = pr < p.rope_max ? (pr > 0 ? pr : 0) : p.rope_max - 1;
   const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
   const T* Vg = (const T*)p.V + b * p.v_sb + kvh * p.v_sh;

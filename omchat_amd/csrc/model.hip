@@ -1053,12 +1053,13 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     TRY(lm_head_rows(ctx, ctx->tw_last, b, logits_last, s));
   }
   ctx->kv8_valid = false;
-  if (ctx->fp8_kv && !left) {      // fp8 KV cache for the decode steps: quantise what this prefill wrote (d_len still holds the valid lengths)
+  if (ctx->fp8_kv) {      // fp8 KV cache for the decode steps: quantise what this prefill wrote -- ALL S slots of every row: the masked decode
+                          // of a padded batch exposes padded slots too (omchat_arch.py:61-70), and the per-sequence step overwrites them as it appends
     for (int i = 0; i < c.t_layers; ++i) {
       const size_t off = (size_t)i * ctx->cache_layer_stride(), so = (size_t)i * ctx->scale_layer_stride();
       TRY(launch_kv_quant(ctx->dt, (char*)ctx->kcache + off * 2, (char*)ctx->vcache + off * 2, (char*)ctx->k8cache + off, (char*)ctx->v8cache + off,
                           ctx->ks8 + so, ctx->vs8 + so, b, c.t_kv_heads, ctx->cache_sb(), ctx->cache_sh(), (int64_t)c.t_kv_heads * c.max_seq, c.max_seq,
-                          nullptr, 0, ctx->d_len, S, s));
+                          nullptr, 0, nullptr, S, s));
     }
     ctx->kv8_valid = true;
   }

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from gpu_util import DT, CODE, TOL, TOL_DEEP, dev, rnd, rel, ptr, sync, randn
+from gpu_util import DT, CODE, TOL, TOL_DEEP, dev, rnd, rel, ptr, sync, randn, synth_state_dict
 from omchat_amd import synth, _lib
 from omchat_amd.config import tiny
 from omchat_amd.engine import Engine
@@ -210,13 +210,14 @@ def test_full_width_masked_decode_vs_the_oracle_restatement(gpu_lib, dt, side):
     cfg.text["vocab_size"] = 2048
     cfg.mm["tokenizer_padding_side"] = side
     keep = lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k
-    sd = {k: v for k, v in synth.state_dict(cfg, 11).items() if keep(k)}
+    sd = synth_state_dict(cfg, 11, keep)          # generated on the device (bit-identical to synth.state_dict, ~100 x faster at these widths)
     sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items()}
     e = Engine(cfg, dtype=dt, max_seq=2200, max_batch=3, max_tiles=1, vision=False)
     e.load_state_dict(sd)
     m = OmChatQwen2ForCausalLM(cfg.clone(), e)
     m.get_vision_tower = lambda: object()
-    feats = rnd(torch.randn(3, 1024, 3584, generator=torch.Generator().manual_seed(4)) * 0.3, dt)
+    # four feature entries: a row WITHOUT a sentinel still consumes one, as a zero-length slice (omchat_arch.py:122-129)
+    feats = rnd(torch.randn(4, 1024, 3584, generator=torch.Generator().manual_seed(4)) * 0.3, dt)
     m.encode_images = lambda images: feats.to(DT[dt]).cuda()
     T = 32
     rows = [[5, -200, 6, -200] + list(range(10, 20)), [-200] + list(range(30, 60)), list(range(100, 109))]
@@ -226,7 +227,7 @@ def test_full_width_masked_decode_vs_the_oracle_restatement(gpu_lib, dt, side):
             ids[i, T - len(r):] = torch.tensor(r); mask[i, T - len(r):] = 1
         else:
             ids[i, :len(r)] = torch.tensor(r); mask[i, :len(r)] = 1
-    dummy = torch.zeros(3, 3, 448, 448)
+    dummy = torch.zeros(4, 3, 448, 448)
     out = m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
     kv = out.past_key_values
     # oracle: splice, padded prefill, decode branch
