@@ -753,8 +753,14 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     case 7: return launch_cfg<T, 256, 192, 4, 3, EPI>(a, stream);     // 12 waves of 64x64: 3 waves per SIMD
     case 8: return launch_cfg<T, 256, 256, 4, 4, EPI>(a, stream);     // 16 waves of 64x64: 4 waves per SIMD
     case 9: return launch_cfg<T, 192, 256, 3, 4, EPI>(a, stream);
+    // round 5: the N = 3200 outputs of the 3-tile ViT (proj, fc2; M = 3075) are 17 x 13 = 221 tiles of 192 x 256 -- 86 % of ONE round, so the launch
+    // lasts one tile whatever the fill; 192 x 224 tiles are 17 x 15 = 255 tiles (99.6 % of the round) of 7 / 8 the size.  8 waves of 48 x 112
+    // (3 x 7 fragments: 10 operand reads per 21 MFMAs) or 12 waves of 32 x 112
+    case 10: if constexpr (EPI != EPI_SWIGLU) return launch_cfg<T, 192, 224, 4, 2, EPI>(a, stream); else break;
+    case 11: if constexpr (EPI != EPI_SWIGLU) return launch_cfg<T, 192, 224, 6, 2, EPI>(a, stream); else break;
     default: return launch_cfg8<T, EPI>(a, stream);
   }
+  return launch_cfg8<T, EPI>(a, stream);      // (a SwiGLU launch asked for a tile whose wave columns would split gate|up pairs)
 }
 
 template <typename T>
@@ -804,7 +810,7 @@ int gemm_tune_load(const char* path) {
   char line[256];
   while (fgets(line, sizeof line, f)) {
     if (line[0] == '#') continue;
-    if (sscanf(line, "%d %d %d %d %d %d", &a, &b, &c, &d, &e, &t) == 6 && t >= 1 && t <= 9) { g_tuned[{a, b, c, d, e}] = t; ++n; }
+    if (sscanf(line, "%d %d %d %d %d %d", &a, &b, &c, &d, &e, &t) == 6 && t >= 1 && t <= 11) { g_tuned[{a, b, c, d, e}] = t; ++n; }
   }
   fclose(f);
   return n;
@@ -862,11 +868,11 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   ++g_tune_runs;
-  int cands[5] = {2, 8, 9, 7, 3};
+  int cands[7] = {2, 8, 9, 7, 3, 10, 11};
   int best = heuristic;
   float best_ms = 1e30f;
   for (int c : cands) {
-    if (c == 3 && a.epi == EPI_SWIGLU) continue;                                  // 48 columns per wave would split gate|up pairs
+    if ((c == 3 || c == 10 || c == 11) && a.epi == EPI_SWIGLU) continue;           // 48 / 112 columns per wave would split gate|up pairs
     t.force_tile = c;
     bool ok = true;
     auto run = [&]() {
