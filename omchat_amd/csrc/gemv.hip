@@ -22,6 +22,7 @@ struct GemvP {
   int y_packed;
   const void* norm_w; float norm_eps;      // whole-row batch-1 form: X is the RAW hidden row, normalised in registers (gemv_rows_norm_kernel)
   unsigned* dyn;                           // gemv_rows_norm_dyn_kernel: 8 pool counters + 1 completion counter (one 256-byte line each), zero before the first launch
+  void* y_pack;                            // gemv_xs_kernel<EPI_RESID>: packed copy of the result rows
 };
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 // (there: groups of UNROLL consecutive chunks per wave), so results agree to fp32 rounding of the K sum, not bit for bit.
 // ---------------------------------------------------------------------------------------------------------
 // c_base: first K chunk of this workgroup's slice (the slice is exactly 8 * NCH chunks), slice: its index for the split-K output
-template <typename T, int EPI, int NB, int NCH>
+// NORM (round 5, the batched twin of the batch-1 norm-in-GEMV forms): X holds the RAW residual rows in the packed layout and the RMSNorm that
+// precedes the projection (transformers modeling_qwen2.py:247-252) runs here, on the registers that keep x for the whole launch: per-row sum
+// of squares over the wave's chunks, over the four lanes of a row and over the eight waves (LDS), then T(T(x * rstd) * w) with the reference's
+// two roundings.  Every workgroup repeats it (x is read by every workgroup anyway); the residual + RMSNorm launch in front of gate|up goes away.
+template <typename T, int EPI, int NB, int NCH, bool NORM = false>
 __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][NB][256], int c_base, int slice) {
   typedef typename V8<T>::type frag_t;
   constexpr int WAVES = 8;
@@ -231,6 +236,44 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
         xf[i][nb][h] = nb * 16 + fr < p.b ? ld8<T>((const T*)p.X + ((size_t)(c * 2 + h) * NB + nb) * 512 + lane * 8) : z;
       }
   }
+  if constexpr (NORM) {
+    float ss[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float v = tof(xf[i][nb][h][j]); a = fmaf(v, v, a); }
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      ss[nb] = a;
+      if (fg == 0) red[1][wave][nb][fr] = a;          // parity 1: finish(0) writes parity 0 and every wave has passed its barrier before parity 1 is reused
+    }
+    __syncthreads();
+    const T* nw = (const T*)p.norm_w;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot += red[1][w][nb][fr];      // fixed order
+      const float rstd = rsqrtf(tot / (float)p.K + p.norm_eps);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = c_base + wave + WAVES * i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const frag_t wv = ld8<T>(nw + (size_t)c * 64 + h * 32 + fg * 8);
+          frag_t o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = fromf<T>(rnd<T>(tof(xf[i][nb][h][j]) * rstd) * tof(wv[j]));
+          xf[i][nb][h] = o;
+        }
+      }
+    }
+  }
   auto load_w = [&](frag_t (&wf)[NCH][2], int tile) {
     const T* base = W + ((size_t)tile * nchunk_all + c_base) * 1024 + lane * 8;
 #pragma unroll
@@ -250,6 +293,14 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
   const bool has_bias = EPI != EPI_SWIGLU && EPI != EPI_PARTIAL && bias != nullptr;
   const T* bsrc = has_bias ? bias : (const T*)p.X;
   auto bias_of = [&](int j) { const int e = threadIdx.x & 255, n = tile_of(j) * 16 + (e >> 4); return tof(bsrc[has_bias ? (n < p.N ? n : p.N - 1) : 0]); };
+  // EPI_RESID (un-split o_proj of a batched step, round 5): the residual element this thread will add is requested with the tile's weights, like
+  // the bias; it rides in the same two registers (a launch has a bias or a residual, never both)
+  const bool has_res = EPI == EPI_RESID;
+  const T* rsrc = has_res ? (const T*)p.resid : (const T*)p.X;
+  auto res_of = [&](int j) {
+    const int i = threadIdx.x & (NB * 256 - 1), nb = i >> 8, e = i & 255, n = tile_of(j) * 16 + (e >> 4), bi = nb * 16 + (e & 15);
+    return tof(rsrc[has_res ? (size_t)(bi < p.b ? bi : 0) * p.ldr + (n < p.N ? n : p.N - 1) : 0]);
+  };
   float bias_a = 0.f, bias_b = 0.f;
   auto finish = [&](frag_t (&wf)[NCH][2], int j, float bias_v) {
     const int tile = tile_of(j), par = j & 1;
@@ -284,6 +335,13 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
         }
       } else if constexpr (EPI == EPI_PARTIAL) {
         if (bi < p.b) ((float*)p.Y)[((size_t)slice * p.b + bi) * p.ldy + tile * 16 + nl] = v;      // [ksplit][b][ldy]
+      } else if constexpr (EPI == EPI_RESID) {
+        if (bi < p.b) {                                   // T(resid + T(acc)) as gemm_epilogue's EPI_RESID; row-major (may alias resid) and packed
+          const int n = tile * 16 + nl;
+          const T y = fromf<T>(bias_v + rnd<T>(v));
+          ((T*)p.Y)[(size_t)bi * p.ldy + n] = y;
+          if (p.y_pack) ((T*)p.y_pack)[packed_x_index(bi, n, NB)] = y;
+        }
       } else if (bi < p.b) {
         const int n = tile * 16 + nl;
         const float y = v + (has_bias ? bias_v : 0.f);
@@ -293,21 +351,22 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
     }
   };
   frag_t wa[NCH][2], wb[NCH][2];
-  if (my_tiles > 0) { load_w(wa, tile_of(0)); bias_a = bias_of(0); }
+  auto pre_of = [&](int j) { if constexpr (EPI == EPI_RESID) return res_of(j); else return bias_of(j); };
+  if (my_tiles > 0) { load_w(wa, tile_of(0)); bias_a = pre_of(0); }
   for (int j = 0; j < my_tiles; j += 2) {
-    if (j + 1 < my_tiles) { load_w(wb, tile_of(j + 1)); bias_b = bias_of(j + 1); }
+    if (j + 1 < my_tiles) { load_w(wb, tile_of(j + 1)); bias_b = pre_of(j + 1); }
     finish(wa, j, bias_a);
     if (j + 1 < my_tiles) {
-      if (j + 2 < my_tiles) { load_w(wa, tile_of(j + 2)); bias_a = bias_of(j + 2); }
+      if (j + 2 < my_tiles) { load_w(wa, tile_of(j + 2)); bias_a = pre_of(j + 2); }
       finish(wb, j + 1, bias_b);
     }
   }
 }
 
-template <typename T, int EPI, int NB, int NCH>
+template <typename T, int EPI, int NB, int NCH, bool NORM = false>
 __global__ __launch_bounds__(512) void gemv_xs_kernel(GemvP p) {
   __shared__ float red[2][8][NB][256];
-  gemv_xs_body<T, EPI, NB, NCH>(p, red, 0, 0);
+  gemv_xs_body<T, EPI, NB, NCH, NORM>(p, red, 0, 0);
 }
 
 // split-K form (down_proj): the K = 64 * 8 * q chunks are cut into slices that deal evenly to the 8 waves -- n5 slices of 40 chunks
@@ -1333,8 +1392,15 @@ template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed, a.norm_w, a.norm_eps,
-          (unsigned*)a.dyn_ctr};
-  if (a.norm_w && a.x_packed) { omchat_set_error("launch_gemv: the in-register RMSNorm is a batch-1 form (row-major x)"); return 1; }
+          (unsigned*)a.dyn_ctr, a.y_pack};
+  if (a.norm_w && a.x_packed && !(a.w_packed && ks == 1 && (a.K >> 6) == 56 && a.epi == EPI_SWIGLU && a.N % 32 == 0 && !g_gemv_no_xs)) {
+    omchat_set_error("launch_gemv: the in-register RMSNorm on packed x exists for the x-stationary gate|up form only (packed W, K = 3584, no split-K)");
+    return 1;
+  }
+  if (a.epi == EPI_RESID && a.x_packed && !(a.w_packed && ks == 1 && (a.K >> 6) == 56 && a.N % 16 == 0 && a.N / 16 <= device_cus() && !g_gemv_no_xs)) {
+    omchat_set_error("launch_gemv: the batched residual epilogue exists for the x-stationary form only (packed W, K = 3584, N / 16 <= CUs, no split-K)");
+    return 1;
+  }
   if (a.x_packed) {
     // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
 #define OM_PK(NT_, EPI_, WV_, UN_)                                                                                                  \
@@ -1348,6 +1414,13 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     // long launches with K = 64 * 8 * 7 (= 3584: gate|up, lm_head): x-stationary persistent form, one workgroup per CU, >= 4 units each
     const int n_cu = device_cus();
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
+    if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.epi == EPI_RESID) {      // un-split o_proj (+ residual): one tile per workgroup
+      const dim3 grid(a.N / 16);
+      if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_RESID, 2, 7>), grid, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_RESID, 1, 7>), grid, dim3(512), 0, s, p);
+      OM_LAUNCH_CHECK();
+      return 0;
+    }
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
         ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu) ||
          ((g_gemv_shard & 1) && a.epi == EPI_NONE && a.N / 16 < n_cu) || ((g_gemv_shard & 8) && a.epi == EPI_SWIGLU && a.N / 32 <= n_cu))) {
@@ -1356,7 +1429,10 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       // a tensor-parallel rank's qkv shard (768 rows = 48 tiles at TP = 8) is shorter than one tile per CU: one tile per workgroup, 48
       // workgroups that each read x once, instead of gemv_pk_kernel's 24 workgroups of two tiles (round 5: 11.4 us -> see DESIGN.md section 6)
       const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : (a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16 < n_cu ? a.N / 16 : a.N / 32));
-      if (a.epi == EPI_SWIGLU) {
+      if (a.epi == EPI_SWIGLU && a.norm_w) {
+        if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7, true>), grid, dim3(512), 0, s, p);
+      } else if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
       } else {
@@ -1385,6 +1461,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
         return 0;
       }
     }
+    if (a.norm_w) { omchat_set_error("launch_gemv: packed-x RMSNorm form: gate|up shape outside the x-stationary launch (N / 32 >= 4 CUs)"); return 1; }
     if (a.epi == EPI_SWIGLU) OM_PK(2, EPI_SWIGLU, 8, 4);
     else if (a.epi == EPI_PARTIAL) {
       // short K slices (a tensor-parallel rank's o_proj: K = 512 = 8 chunks; down_proj: 37 chunks in two slices): one chunk per wave per

@@ -70,6 +70,9 @@ struct GemvArgs {
   // optional: 65 x 64 unsigned (65 lines of 256 bytes) of ZEROED device memory owned by the caller and used by no other launch at the same time (the kernel leaves them
   // zero): the loop form of a norm GEMV then takes its outputs from atomic work counters (gemv_rows_norm_dyn_kernel) instead of equal shares
   void* dyn_ctr = nullptr;
+  // batched x-stationary form, EPI_RESID (round 5): the result rows are ALSO written in the packed x layout here (same NB), un-normalised --
+  // the consuming gate|up GEMV normalises them in registers (norm_w with x_packed)
+  void* y_pack = nullptr;
 };
 // row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);

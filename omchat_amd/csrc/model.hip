@@ -574,7 +574,7 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
-int g_norm_in_gemv = 3;       // omchat_op_set_tuning key 14: bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final norm
+int g_norm_in_gemv = 7;       // omchat_op_set_tuning key 14: bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final norm
                               // inside qkv / lm_head with down_proj un-split (0 = batch-1 decode keeps both residual + RMSNorm launches: A/B)
 void model_set_norm_in_gemv(int v) { g_norm_in_gemv = v; }
 int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
@@ -1197,6 +1197,10 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // the step keeps its residual + RMSNorm launches)
   const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096 && !gemv_get_force_mfma();
   const bool n1 = n2 && (g_norm_in_gemv & 2) && It <= 32768 && It % 8 == 0;
+  // batched steps on one GPU (round 5, key 14 bit 2): o_proj un-split in the x-stationary form writes x + attn itself (row-major in place AND the
+  // packed raw copy), and the post-attention RMSNorm runs in the registers of the gate|up GEMV: seven launches per layer instead of eight
+  const bool nb2 = (g_norm_in_gemv & 4) && fused && wpk && ctx->tp_size == 1 && !f8 && (qd >> 6) == 56 && (H >> 6) == 56 && qd % 64 == 0 &&
+                   H / 16 <= device_cus() && (2 * It) / 32 >= 4 * device_cus();
   if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
@@ -1273,6 +1277,10 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       // x + attn is already in place
     } else if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
+    } else if (nb2) {
+      GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, b, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, P.wo, false);
+      g.y_pack = ctx->tw_xn;
+      TRY(launch_gemv(ctx->dt, g, s));
     } else if (fused) {
       TRY(gemv_partial(ctx->tw_ao, qd, L.wo, qd, ks_o, Q.wo, Q.so, P.wo));
       TRY(ctx->reduce_resid_rmsnorm(x, H, ctx->tw_part, ks_o, L.ln2, ctx->tw_xn, H, b, H, c.t_eps, pk, s));
@@ -1292,6 +1300,10 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       GemvArgs g = gemv_args(x, H, L.wgu, H, ctx->tw_act, It, 1, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, Q.wgu, Q.sgu, nullptr, false);
       g.norm_w = L.ln2; g.norm_eps = c.t_eps;
       if (ctx->dyn_ctr && !ctx->graph_on) g.dyn_ctr = ctx->dyn_ctr + (size_t)i * 65 * 64;
+      TRY(launch_gemv(ctx->dt, g, s));
+    } else if (nb2) {
+      GemvArgs g = gemv_args(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, b, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, nullptr, nullptr, P.wgu, true);
+      g.norm_w = L.ln2; g.norm_eps = c.t_eps;
       TRY(launch_gemv(ctx->dt, g, s));
     } else {
       TRY(gemv(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, 2 * It, nullptr, nullptr, EPI_SWIGLU, Q.wgu, Q.sgu, P.wgu, true));

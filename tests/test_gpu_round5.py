@@ -94,7 +94,7 @@ def test_decode_step_at_the_tp8_rank_widths_vs_oracle(gpu_lib, dt, b):
             e.close()
     finally:
         gpu_lib.omchat_op_set_tuning(34, 7)
-        gpu_lib.omchat_op_set_tuning(14, 3)
+        gpu_lib.omchat_op_set_tuning(14, 7)
     for i in sorted({0, 1 % b, b // 2, b - 1}):
         cache = oracle.KVCache(cfg.text["num_hidden_layers"])
         oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
@@ -256,3 +256,50 @@ def test_full_width_masked_decode_vs_the_oracle_restatement(gpu_lib, dt, side):
         tok_mask = torch.cat([tok_mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
     assert e.kv_lengths(3) == [2063] * 3
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched decode, seven launches per layer: un-split o_proj with the residual in its epilogue, the post-attention RMSNorm
+# in the registers of the x-stationary gate|up GEMV (tuning key 14 bit 2)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b", [32, 16, 3])
+def test_batched_decode_with_the_norm_in_the_gate_up_gemv_vs_eight_launches_and_oracle(gpu_lib, dt, b):
+    """one Qwen2-7B-width layer pair (3584, 28 / 4 heads, MLP 18944: the widths at which the x-stationary forms run), ragged batch: two decode
+    steps with key 14 = 7 (seven launches) and 14 = 3 (o_proj split-K + residual + RMSNorm launch) against each other and against the
+    oracle (transformers modeling_qwen2.py:269-298 restated in oracle/decoder.py)"""
+    import oracle
+    from omchat_amd.config import omchat13b
+    cfg = omchat13b()
+    cfg.text["num_hidden_layers"] = 2
+    cfg.text["vocab_size"] = 2048
+    keep = lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k
+    sd = synth_state_dict(cfg, 9, keep)
+    sdt = {k: rnd(torch.from_numpy(v), dt) for k, v in sd.items()}
+    S = 40
+    x = rnd(torch.randn(b, S, 3584, generator=torch.Generator().manual_seed(b)) * 0.5, dt)
+    lens = [S - (i % 7) for i in range(b)]
+    toks = torch.arange(b) % 2000 + 5
+    res = {}
+    try:
+        for key in (7, 3):
+            gpu_lib.omchat_op_set_tuning(14, key)
+            e = Engine(cfg, dtype=dt, max_seq=S + 8, max_batch=b, max_tiles=1, vision=False)
+            e.load_state_dict(sd)
+            e.prefill(x, lens)
+            nxt, lg = e.decode_step(toks, want_logits=True)
+            nxt2, lg2 = e.decode_step(nxt, want_logits=True); sync()
+            res[key] = (lg.cpu(), lg2.cpu(), nxt.cpu())
+            e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(14, 7)
+    for i in sorted({0, b // 2, b - 1}):
+        cache = oracle.KVCache(2)
+        oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
+        o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+        o2 = oracle.decode_step(res[7][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+        for key in (7, 3):
+            assert rel(res[key][0][i], o1) < TOL_DEEP[dt], (key, i, rel(res[key][0][i], o1))
+        assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
+    # the two structures sum o_proj's K in different orders (one slice against two) and form the variance in different orders
+    assert rel(res[7][0], res[3][0]) < TOL[dt]
