@@ -265,6 +265,7 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
         const int c = c_base + wave + WAVES * i;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_sched_barrier(0);      // one norm-weight fragment live at a time: hoisting all 2 NCH of them spilled 120 VGPRs
           const frag_t wv = ld8<T>(nw + (size_t)c * 64 + h * 32 + fg * 8);
           frag_t o;
 #pragma unroll
@@ -1414,6 +1415,12 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     // long launches with K = 64 * 8 * 7 (= 3584: gate|up, lm_head): x-stationary persistent form, one workgroup per CU, >= 4 units each
     const int n_cu = device_cus();
     // (units = what one workgroup walks: (gate, up) tile pairs or single tiles; fewer than 4 per workgroup leaves the last round too empty)
+#if !OMCHAT_EXPERIMENTS
+    // the seven-launch batched layer (un-split o_proj + residual, RMSNorm in the gate|up GEMV's registers; round 5) measured SLOWER than the eight
+    // launches (configs[2] decode 4.57-4.87 vs 4.28 ms per step: the norm delays the weight stream by ~3 us in every workgroup and the NB = 2
+    // form spills 35-120 VGPRs next to the 168 registers that hold x and two weight tiles): compiled with -DOMCHAT_EXPERIMENTS=1 only
+    if (a.norm_w || a.epi == EPI_RESID) { omchat_set_error("launch_gemv: the batched norm-in-GEMV / residual forms need a -DOMCHAT_EXPERIMENTS=1 build"); return 1; }
+#else
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.epi == EPI_RESID) {      // un-split o_proj (+ residual): one tile per workgroup
       const dim3 grid(a.N / 16);
       if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_RESID, 2, 7>), grid, dim3(512), 0, s, p);
@@ -1421,6 +1428,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       OM_LAUNCH_CHECK();
       return 0;
     }
+#endif
     if (a.w_packed && ks == 1 && !g_gemv_no_xs && (a.K >> 6) == 56 && a.N % 32 == 0 && (a.epi == EPI_SWIGLU || a.epi == EPI_NONE) &&
         ((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu || (a.epi == EPI_NONE && a.N / 16 >= n_cu && a.N / 16 <= 2 * n_cu) ||
          ((g_gemv_shard & 1) && a.epi == EPI_NONE && a.N / 16 < n_cu) || ((g_gemv_shard & 8) && a.epi == EPI_SWIGLU && a.N / 32 <= n_cu))) {
@@ -1429,10 +1437,13 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
       // a tensor-parallel rank's qkv shard (768 rows = 48 tiles at TP = 8) is shorter than one tile per CU: one tile per workgroup, 48
       // workgroups that each read x once, instead of gemv_pk_kernel's 24 workgroups of two tiles (round 5: 11.4 us -> see DESIGN.md section 6)
       const dim3 grid((a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16) >= 4 * n_cu ? n_cu : (a.epi == EPI_SWIGLU ? a.N / 32 : a.N / 16 < n_cu ? a.N / 16 : a.N / 32));
+#if OMCHAT_EXPERIMENTS
       if (a.epi == EPI_SWIGLU && a.norm_w) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7, true>), grid, dim3(512), 0, s, p);
-      } else if (a.epi == EPI_SWIGLU) {
+      } else
+#endif
+      if (a.epi == EPI_SWIGLU) {
         if (a.b > 16) hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 2, 7>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemv_xs_kernel<T, EPI_SWIGLU, 1, 7>), grid, dim3(512), 0, s, p);
       } else {
@@ -1608,7 +1619,7 @@ int launch_pack_w(int dtype, const void* W, int ldw, int N, int K, void* out, hi
 
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 32, "batch must be 1..32 per call");
-  OM_CHECK(!a.x_packed || (!a.w_scale && a.epi != EPI_RESID), "packed x: 16-bit weights, epilogue NONE / SWIGLU / PARTIAL");
+  OM_CHECK(!a.x_packed || !a.w_scale, "packed x: 16-bit weights");      // (EPI_RESID: x-stationary form only, checked in launch_t)
   OM_CHECK(!a.w_packed || (a.x_packed && a.N % 16 == 0), "packed W needs packed x and N % 16 == 0");
   OM_CHECK(!a.y_packed || (a.x_packed && a.epi == EPI_SWIGLU), "packed y: SwiGLU epilogue of the packed kernel only");
   OM_CHECK(a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldx % 8 == 0, "K % 64, ldw % 8, ldx % 8");

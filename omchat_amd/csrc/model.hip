@@ -1197,9 +1197,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // the step keeps its residual + RMSNorm launches)
   const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096 && !gemv_get_force_mfma();
   const bool n1 = n2 && (g_norm_in_gemv & 2) && It <= 32768 && It % 8 == 0;
-  // batched steps on one GPU (round 5, key 14 bit 2): o_proj un-split in the x-stationary form writes x + attn itself (row-major in place AND the
+  // batched steps on one GPU (round 5, key 14 bit 2; -DOMCHAT_EXPERIMENTS=1 builds only: measured slower, gemv.hip): o_proj un-split in the x-stationary form writes x + attn itself (row-major in place AND the
   // packed raw copy), and the post-attention RMSNorm runs in the registers of the gate|up GEMV: seven launches per layer instead of eight
-  const bool nb2 = (g_norm_in_gemv & 4) && fused && wpk && ctx->tp_size == 1 && !f8 && (qd >> 6) == 56 && (H >> 6) == 56 && qd % 64 == 0 &&
+  const bool nb2 = OMCHAT_EXPERIMENTS && (g_norm_in_gemv & 4) && fused && wpk && ctx->tp_size == 1 && !f8 && (qd >> 6) == 56 && (H >> 6) == 56 && qd % 64 == 0 &&
                    H / 16 <= device_cus() && (2 * It) / 32 >= 4 * device_cus();
   if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
   for (int i = 0; i < c.t_layers; ++i) {

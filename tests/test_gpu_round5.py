@@ -270,6 +270,8 @@ def test_batched_decode_with_the_norm_in_the_gate_up_gemv_vs_eight_launches_and_
     oracle (transformers modeling_qwen2.py:269-298 restated in oracle/decoder.py)"""
     import oracle
     from omchat_amd.config import omchat13b
+    if not gpu_lib.omchat_has_experiments():
+        pytest.skip("measured slower than the eight launches (4.57-4.87 vs 4.28 ms per batch-32 step, DESIGN.md section 6): -DOMCHAT_EXPERIMENTS=1 builds only")
     cfg = omchat13b()
     cfg.text["num_hidden_layers"] = 2
     cfg.text["vocab_size"] = 2048
