@@ -223,19 +223,22 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
   // measured 8 % SLOWER than gemv_pk_kernel.
   const T* W = (const T*)p.W;
   frag_t xf[NCH][NB][2];
+  auto load_x = [&]() {
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = c_base + wave + WAVES * i;
+    for (int i = 0; i < NCH; ++i) {
+      const int c = c_base + wave + WAVES * i;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        frag_t z;
+        for (int h = 0; h < 2; ++h) {
+          frag_t z;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = fromf<T>(0.f);
-        xf[i][nb][h] = nb * 16 + fr < p.b ? ld8<T>((const T*)p.X + ((size_t)(c * 2 + h) * NB + nb) * 512 + lane * 8) : z;
-      }
-  }
+          for (int j = 0; j < 8; ++j) z[j] = fromf<T>(0.f);
+          xf[i][nb][h] = nb * 16 + fr < p.b ? ld8<T>((const T*)p.X + ((size_t)(c * 2 + h) * NB + nb) * 512 + lane * 8) : z;
+        }
+    }
+  };
+  if constexpr (NORM) load_x();
   if constexpr (NORM) {
     float ss[NB];
 #pragma unroll
@@ -353,7 +356,10 @@ __device__ __forceinline__ void gemv_xs_body(const GemvP& p, float (&red)[2][8][
   };
   frag_t wa[NCH][2], wb[NCH][2];
   auto pre_of = [&](int j) { if constexpr (EPI == EPI_RESID) return res_of(j); else return bias_of(j); };
+  // the first tile's weights are requested IN FRONT of x (round 5): x comes from L2 and used to hold the first HBM request of every workgroup
+  // back by its own 229 KB; vector memory returns in order, so the tile still cannot be used before x has arrived
   if (my_tiles > 0) { load_w(wa, tile_of(0)); bias_a = pre_of(0); }
+  if constexpr (!NORM) load_x();
   for (int j = 0; j < my_tiles; j += 2) {
     if (j + 1 < my_tiles) { load_w(wb, tile_of(j + 1)); bias_b = pre_of(j + 1); }
     finish(wa, j, bias_a);
