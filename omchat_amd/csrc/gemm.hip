@@ -758,9 +758,35 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     // (3 x 7 fragments: 10 operand reads per 21 MFMAs) or 12 waves of 32 x 112
     case 10: if constexpr (EPI != EPI_SWIGLU) return launch_cfg<T, 192, 224, 4, 2, EPI>(a, stream); else break;
     case 11: if constexpr (EPI != EPI_SWIGLU) return launch_cfg<T, 192, 224, 6, 2, EPI>(a, stream); else break;
+    // round 5: two launches over disjoint column ranges.  M = 3075 x N = 12800 (ViT fc1) is 650 tiles of 256^2 = 2.54 rounds on 256 CUs: the
+    // launch lasts THREE tile times.  The leading columns that make whole rounds of 256^2 tiles (39 column tiles x 13 row tiles = 507 <= 512) go to
+    // the staggered 256^2 kernel, the remaining 2816 columns to ONE round of 192 x 224 tiles (13 x 17 = 221): ~2.7 tile times.  No extra bytes:
+    // both launches read A once more through L2 only; outputs, bias and residual are column slices of the same buffers.
+    case 12: case 13:
+      if constexpr (EPI != EPI_SWIGLU) {
+        const int G = device_cus(), rt = cdiv(a.M, 256), ct = cdiv(a.N, 256);
+        const int full = (rt * ct) / G;                                     // whole rounds of 256^2 tiles
+        const int ct_main = full >= 1 ? std::min(ct, (full * G) / rt) : 0;
+        const int n_main = ct_main * 256, n_tail = a.N - n_main;
+        if (n_main > 0 && n_tail > 0 && (long)cdiv(a.M, 192) * cdiv(n_tail, 224) <= G) {
+          GemmArgs m = a, t = a;
+          m.N = n_main; m.force_tile = 2;
+          const size_t es = 2;
+          t.N = n_tail; t.force_tile = a.force_tile == 12 ? 10 : 11;
+          t.W = (const char*)a.W + (size_t)n_main * a.ldw * es;
+          t.C = (char*)a.C + (size_t)n_main * es;
+          if (a.bias) t.bias = (const char*)a.bias + (size_t)n_main * es;
+          if (a.ls) t.ls = (const char*)a.ls + (size_t)n_main * es;
+          if (a.resid) t.resid = (const char*)a.resid + (size_t)n_main * es;
+          const int rc = launch_cfg8<T, EPI>(m, stream);
+          if (rc) return rc;
+          return t.force_tile == 10 ? launch_cfg<T, 192, 224, 4, 2, EPI>(t, stream) : launch_cfg<T, 192, 224, 6, 2, EPI>(t, stream);
+        }
+      }
+      break;
     default: return launch_cfg8<T, EPI>(a, stream);
   }
-  return launch_cfg8<T, EPI>(a, stream);      // (a SwiGLU launch asked for a tile whose wave columns would split gate|up pairs)
+  return launch_cfg8<T, EPI>(a, stream);      // (a tile that does not apply to this problem / epilogue: the 256^2 kernel)
 }
 
 template <typename T>
@@ -810,7 +836,7 @@ int gemm_tune_load(const char* path) {
   char line[256];
   while (fgets(line, sizeof line, f)) {
     if (line[0] == '#') continue;
-    if (sscanf(line, "%d %d %d %d %d %d", &a, &b, &c, &d, &e, &t) == 6 && t >= 1 && t <= 11) { g_tuned[{a, b, c, d, e}] = t; ++n; }
+    if (sscanf(line, "%d %d %d %d %d %d", &a, &b, &c, &d, &e, &t) == 6 && t >= 1 && t <= 13) { g_tuned[{a, b, c, d, e}] = t; ++n; }
   }
   fclose(f);
   return n;
@@ -868,11 +894,11 @@ static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   ++g_tune_runs;
-  int cands[7] = {2, 8, 9, 7, 3, 10, 11};
+  int cands[9] = {2, 8, 9, 7, 3, 10, 11, 12, 13};
   int best = heuristic;
   float best_ms = 1e30f;
   for (int c : cands) {
-    if ((c == 3 || c == 10 || c == 11) && a.epi == EPI_SWIGLU) continue;           // 48 / 112 columns per wave would split gate|up pairs
+    if ((c == 3 || c >= 10) && a.epi == EPI_SWIGLU) continue;           // 48 / 112 columns per wave would split gate|up pairs
     t.force_tile = c;
     bool ok = true;
     auto run = [&]() {

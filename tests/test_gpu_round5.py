@@ -305,3 +305,32 @@ def test_batched_decode_with_the_norm_in_the_gate_up_gemv_vs_eight_launches_and_
         assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
     # the two structures sum o_proj's K in different orders (one slice against two) and form the variance in different orders
     assert rel(res[7][0], res[3][0]) < TOL[dt]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GEMM as two launches over disjoint column ranges (tile ids 12 / 13): whole rounds of 256^2 tiles + one round of 192 x 224 tiles
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("M,N,K", [(3075, 12800, 192), (3075, 9600, 128), (1025, 3200, 256)])
+def test_gemm_split_into_whole_rounds_and_a_tail_launch(gpu_lib, dt, tile, M, N, K):
+    """the ViT fc1 shape (650 tiles = 2.54 rounds: 507 tiles of 256^2 + 221 of 192 x 224), the qkv shape, and a shape too small to split (falls back
+    to the 256^2 kernel): every epilogue against the fp32 restatement, and bit-identical to the one-launch 256^2 kernel (each output element is
+    accumulated over K in the same order by every tile shape)"""
+    from test_gpu_ops import _gemm_ref
+    A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2, 0.05), dt)
+    bias = rnd(randn((N,), 3, 0.1), dt); ls = rnd(randn((N,), 4, 0.1) + 0.1, dt); resid = rnd(randn((M, N), 5), dt)
+    dA, dW, db, dl, dr = dev(A, dt), dev(W, dt), dev(bias, dt), dev(ls, dt), dev(resid, dt)
+    for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_LS_RESID, _lib.EPI_RESID):
+        use_bias = epi != _lib.EPI_RESID
+        outs = []
+        for t in (tile, 2):
+            out = torch.full((M, N), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), N, M, N, K, ptr(db) if use_bias else None,
+                                              ptr(dl), ptr(dr), N, epi, t, None))
+            sync()
+            outs.append(out)
+        ref = _gemm_ref(A, W, bias if use_bias else None, ls, resid, epi, dt)
+        assert torch.isfinite(outs[0].float()).all(), (epi, "non-finite / unwritten outputs")
+        assert rel(outs[0], ref) < TOL[dt], (epi, tile, rel(outs[0], ref))
+        assert torch.equal(outs[0], outs[1]), (epi, tile)
