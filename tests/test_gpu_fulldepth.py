@@ -176,3 +176,27 @@ def test_full_depth_first_greedy_id_bf16_run_is_what_was_forced(runs):
     g = runs["bf16"]
     assert g["fed"] == runs["forced"] == g["ids"][:N_FORCED]
     assert runs["f16"]["fed"] == runs["forced"]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_full_depth_internvit300m_tower_and_projector_vs_streamed_oracle(gpu_lib, dt):
+    """BASELINE configs[3] (OmChat-2.1-8B): the InternViT-300M tower at FULL depth (24 layers, LayerNorm, 16 heads x 64, no q/k norm) on the
+    8 tiles of the benchmarked sample + the projector, against the layer-streamed fp32 oracle (intern_vit_300m/modeling_intern_vit.py:205-222,
+    internVIT300m_encoder.py:45-56, multimodal_projector/builder.py:54-61)."""
+    from oracle import stream
+    from omchat_amd.config import omchat8b_21
+    cfg = omchat8b_21()
+    n = 8
+    e = Engine(cfg, dtype=dt, max_seq=64, max_batch=1, max_tiles=n, text=False)
+    e.fill_synthetic(0)
+    px = torch.from_numpy(synth.pixels(n, 448, 3))
+    tower = e.vit_forward(px).float().cpu()
+    feats = e.encode_images(px).float().cpu(); sync()
+    e.close()
+    get, _ = _device_weight_source(cfg)
+    o_tower, o_feats = stream.encode_images_streamed(px, get, cfg.vision, cfg.mm["mm_vision_select_layer"])
+    e_t, e_f = rel(tower, o_tower), rel(feats, o_feats)
+    print(f"\n{dt}: InternViT-300M 24-layer tower rel err {e_t:.3e}, projected features {e_f:.3e}")
+    _report(f"{dt}_tower300m", e_t); _report(f"{dt}_feats300m", e_f)
+    assert torch.isfinite(tower).all() and torch.isfinite(feats).all()
+    assert e_t < TOL[dt][0] and e_f < TOL[dt][1], (e_t, e_f)
