@@ -49,6 +49,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 23) { model_set_decode_layer(value); return 0; }
   if (key == 24) { gemv_set_dyn(value); return 0; }
   if (key == 34) { gemv_set_shard_shapes(value); return 0; }
+  if (key == 35) { model_set_shard_as_tp1(value); return 0; }
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }

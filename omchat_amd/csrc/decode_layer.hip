@@ -750,6 +750,7 @@ int launch_one(const DecLayerP& P, int grid, hipStream_t s) {
 template <typename T>
 int launch_geo(const DecLayerP& P, const Geo& g, int grid, hipStream_t s) {
   if (g.nch == 7 && g.ncq == 7 && g.rq == 3 && g.ro == 2) return launch_one<T, 7, 7, 3, 2>(P, grid, s);
+  if (g.nch == 7 && g.ncq == 1 && g.rq == 1 && g.ro == 2) return launch_one<T, 7, 1, 1, 2>(P, grid, s);      // a TP = 8 rank's widths (round 5 measurement)
   if (g.nch == 1 && g.ncq == 1 && g.rq == 1 && g.ro == 1) return launch_one<T, 1, 1, 1, 1>(P, grid, s);
   if (g.nch == 1 && g.ncq == 2 && g.rq == 1 && g.ro == 1) return launch_one<T, 1, 2, 1, 1>(P, grid, s);
   omchat_set_error("launch_decode_layer: geometry without an instantiation");
@@ -760,7 +761,8 @@ bool geo_of(const DecodeLayerArgs& a, Geo* g, int G) {
   const int qkvd = a.qd + 2 * a.kvd;
   const int r_qkv = cdiv(qkvd, G), r_o = cdiv(a.H, G);
   g->nch = cdiv(a.H, 512); g->ncq = cdiv(a.qd, 512); g->rq = cdiv(r_qkv, 7); g->ro = cdiv(r_o, 7);
-  return (g->nch == 7 && g->ncq == 7 && g->rq == 3 && g->ro == 2) || (g->nch == 1 && g->ncq == 1 && g->rq == 1 && g->ro == 1) ||
+  return (g->nch == 7 && g->ncq == 7 && g->rq == 3 && g->ro == 2) || (g->nch == 7 && g->ncq == 1 && g->rq == 1 && g->ro == 2) ||
+         (g->nch == 1 && g->ncq == 1 && g->rq == 1 && g->ro == 1) ||
          (g->nch == 1 && g->ncq == 2 && g->rq == 1 && g->ro == 1);
 }
 

@@ -197,6 +197,7 @@ bool attn_oproj_fused_ok(const AttnDecodeArgs& a, int H, int qd);
 int launch_attn_oproj_fused(int dtype, const AttnDecodeArgs& a, const FusedDecodeArgs& f, hipStream_t s);
 void model_set_fuse_attn_oproj(int v);
 void model_set_decode_layer(int v);
+void model_set_shard_as_tp1(int v);      // tuning key 35
 
 // batch-1 decode on one GPU (decode_layer.hip, round 4): ONE decoder layer -- the six launches qkv GEMV (+ input RMSNorm), split-KV
 // attention (+ RoPE, cache append), merge, o_proj (+ residual), gate|up GEMV (+ post-attention RMSNorm, SwiGLU), down_proj (+ residual) -- as

@@ -83,6 +83,8 @@ bool decode_layer_ok(const DecodeLayerArgs&) { return false; }
 int launch_decode_layer(int, const DecodeLayerArgs&, hipStream_t) { omchat_set_error("one-launch decode layer: build with -DOMCHAT_EXPERIMENTS=1"); return 1; }
 #endif
 extern "C" int omchat_has_experiments(void) { return OMCHAT_EXPERIMENTS; }
+int g_shard_as_tp1 = 0;          // omchat_op_set_tuning key 35 (experiments build): see decode_body
+void model_set_shard_as_tp1(int v) { g_shard_as_tp1 = v; }
 int g_decode_layer = 0;          // omchat_op_set_tuning key 23: 1 = batch-1 decode on one GPU runs each decoder layer as ONE launch (decode_layer.hip); 0 = six launches (same bits)
 void model_set_decode_layer(int v) { g_decode_layer = v; }
 int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
@@ -391,7 +393,7 @@ int build(omchat_ctx* ctx) {
     ctx->tw_attn_ws_bytes = attn_decode_ws_bytes(c.max_batch, c.t_heads, c.max_seq);
     TRY(ctx->alloc((void**)&ctx->tw_attn_ws, ctx->tw_attn_ws_bytes));
     TRY(ctx->alloc((void**)&ctx->tw_part, (size_t)DEC_KS_MAX * c.max_batch * H * 4));
-    if (ctx->tp_size == 1 && OMCHAT_EXPERIMENTS) {
+    if (OMCHAT_EXPERIMENTS) {
       const size_t fb = fused_decode_ws_bytes(c.t_heads);
       TRY(ctx->alloc(&ctx->fd_ws, fb));
       TRY(ctx->alloc((void**)&ctx->fd_err, 64));
@@ -1195,7 +1197,10 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   // eight.  n2 = the post-attention norm (tuning key 14 bit 0), n1 = the input norm of the next layer / the final norm (bit 1).
   // (only while the whole-row GEMV form is in use: with tuning key 1 -- force the MFMA form -- the norm has no registers to live in and
   // the step keeps its residual + RMSNorm launches)
-  const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && ctx->tp_size == 1 && qd <= 4096 && H <= 4096 && !gemv_get_force_mfma();
+  // measurement only (experiments build, bench.py --shard-of N --tuning 35=1): a rank context whose exchanges are no-ops takes the ONE-GPU launch
+  // structures on its shard widths -- what removing launches could buy a tensor-parallel rank if its two exchanges per layer were free
+  const bool tp1_like = ctx->tp_size == 1 || (OMCHAT_EXPERIMENTS && g_shard_as_tp1 && ctx->hook == omchat_allreduce_noop);
+  const bool n2 = (g_norm_in_gemv & 1) && fused && b == 1 && tp1_like && qd <= 4096 && H <= 4096 && !gemv_get_force_mfma();
   const bool n1 = n2 && (g_norm_in_gemv & 2) && It <= 32768 && It % 8 == 0;
   // batched steps on one GPU (round 5, key 14 bit 2; -DOMCHAT_EXPERIMENTS=1 builds only: measured slower, gemv.hip): o_proj un-split in the x-stationary form writes x + attn itself (row-major in place AND the
   // packed raw copy), and the post-attention RMSNorm runs in the registers of the gate|up GEMV: seven launches per layer instead of eight
