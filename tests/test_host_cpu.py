@@ -431,6 +431,20 @@ def test_tp_projection_tool_reproduces_the_committed_curve():
     assert "| 1 | 1.18 | 1.61 | **2.04** | 2.08 |" in design and "| 1 | 1.17 | 1.93 | **2.85** | **3.53** |" in design
 
 
+def test_tp_projection_of_round_5_shard_lines():
+    """the round-5 closing curve (profiles/r05_q_*: shard-width launch shapes of a tensor-parallel rank's decode GEMVs): configs[2] 3.12 x at N = 8
+    (round 4: 2.79 x), 3.94 x with the data-parallel tower; the arithmetic is tools/tp_projection.py on the committed lines"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "profiles", f"r05_q_bench_{n}.json") for n in ("n1", "shard2", "shard4", "shard8")]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tp_projection.py")] + files, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == open(os.path.join(root, "profiles", "r05_q_tp_projection.txt")).read().strip()
+    rows = {(l.split()[0], int(l.split()[1])): l for l in out.splitlines() if l.startswith("configs")}
+    c2 = rows[("configs2", 8)]
+    assert abs(float(c2.split("|")[2].split()[1]) - 3.12) < 0.01 and "3.94" in c2
+    assert abs(float(rows[("configs2", 8)].split("|")[0].split()[4]) - 1.578) < 1e-3          # rank decode ms per step (round 4: 2.026)
+
+
 def test_pmc_traffic_picks_the_manifest_file_and_refuses_a_renamed_kernel(tmp_path, capsys):
     """bench.py::pmc_traffic (VERDICT r03 weak #11): the PMC pass behind `roofline.traffic` is the one profiles/MANIFEST.json names, not
     "the last file in lexicographic order" (which put r03_s after r03_ai); without a manifest the newest by (round, tag) order; and a
