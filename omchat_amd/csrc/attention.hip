@@ -314,10 +314,16 @@ template <int D, bool IS_V> __device__ __forceinline__ void tile_src(int piece, 
 #ifndef OMCHAT_TR_ASM
 #define OMCHAT_TR_ASM 0      // 1: the transposed V reads of the PV phase as inline assembly (A/B twin of round 4, measured 5-8 % slower: below)
 #endif
-template <typename T, int NW, bool GQA, int D = 128>
+// KG = 2 (MHA only, round 5): the workgroup is EIGHT waves on the same 128 queries -- two groups of four, each walking one half of the key tiles with
+// its own two-stage K / V ring -- and the halves meet through LDS at the end (flash-decoding inside one workgroup: no partials in memory, no
+// second launch).  Why: a wave's unit of work is 32 queries x ALL keys, the 3-tile ViT has 2475 such units for 2048 wave slots, so the launch
+// lasts two units whatever the block shape; halved units are 4950 on 2048 slots = three halves (1.5 units).  The bits differ from KG = 1 only by
+// where the online softmax is cut (one more rescale per query); launch_attn_prefill chooses per shape.
+template <typename T, int NW, bool GQA, int D = 128, int KG = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
-  constexpr int NT = NW * 64;
+  static_assert(KG == 1 || (!GQA && NW == 8), "key groups: MHA, eight waves");
+  constexpr int NT = NW * 64 / KG;                    // threads that stage one tile (a key group)
   constexpr int RB = 2 * D;                           // bytes per key row
   constexpr int TILE = KV_TILE * RB;                  // bytes of one K (or V) tile
   constexpr int BUF = 2 * TILE;
@@ -325,10 +331,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   constexpr int ROUNDS = (NPIECE + NT - 1) / NT;
   constexpr int KS = D / 16;                          // k-steps of S^T = K Q^T
   constexpr int DB = D / 32;                          // 32-row blocks of O^T
-  __shared__ __attribute__((aligned(256))) char smem[2 * BUF];
+  extern __shared__ __attribute__((aligned(256))) char smem_all[];      // KG x 2 x BUF bytes (dynamic: 128 KB at D = 128, KG = 2)
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x % NT, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int kg = KG == 1 ? 0 : wave_all / (NW / KG);                    // key group of this wave
+  const int wave = KG == 1 ? wave_all : wave_all % (NW / KG);           // wave inside its group
+  char* const smem = smem_all + kg * 2 * BUF;
   const int qc = lane & 31, hh = lane >> 5;           // query column of this lane, lane half
 
   const int n_rep = p.q_heads / p.kv_heads;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   }
   const int qb = p.causal ? nqb - 1 - bx : bx;        // heaviest causal blocks first
   const int b = GQA ? rest / p.kv_heads : mha_b;
-  constexpr int QW = GQA ? 32 : NW * 32;              // queries of the workgroup
+  constexpr int QW = GQA ? 32 : (NW / KG) * 32;       // queries of the workgroup
   const int kvh = GQA ? rest % p.kv_heads : mha_head / n_rep;
   const int hq = GQA ? kvh * n_rep + wave : mha_head;
   const int q0b = qb * QW;
@@ -457,15 +466,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   // assembly so that the compiler's vmcnt(0) does not drain it) gave the same bits 10 % SLOWER on every shape (S = 3584: 116.7 vs 105.5 us,
   // 33 k keys 949 vs 1044 TF): the step is bound by the MFMA + softmax chain of the waves on a SIMD (~0.85 of the MFMA pipe busy at two
   // waves per SIMD), not by the tile's arrival.
-  if (t_end > t_begin) issue_tile(t_begin, t_begin & 1);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int cur = t & 1;
+  // key group kg walks tiles [g_begin, g_end); both groups take the same number of steps (the barriers are the workgroup's)
+  const int n_tiles = t_end > t_begin ? t_end - t_begin : 0;
+  const int steps = KG == 1 ? n_tiles : (n_tiles + 1) / 2;
+  const int g_begin = KG == 1 ? t_begin : t_begin + kg * steps;
+  const int g_end = KG == 1 ? t_end : (kg == 0 ? t_begin + steps : t_end);
+  if (g_end > g_begin) issue_tile(g_begin, 0);
+  for (int it = 0; it < steps; ++it) {
+    const int t = g_begin + it;
+    const int cur = it & 1;
     const char* const Ks = smem + cur * BUF;
     const char* const Vs = Ks + TILE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < t_end) issue_tile(t + 1, cur ^ 1);
-    if (!wave_active) continue;
+    if (t + 1 < g_end) issue_tile(t + 1, cur ^ 1);
+    if (!wave_active || t >= g_end) continue;
 
     // ---- S^T = K Q^T: two 32-key tiles
     f32x16 sc[2];
@@ -579,6 +594,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
       }
   }
 
+  if constexpr (KG == 2) {
+    // the second key group hands its running state to the first through LDS (the rings are dead: every read is behind the barrier)
+    constexpr int ST = DB * 16 + 2;
+    float* const mg = reinterpret_cast<float*>(smem_all) + (size_t)(wave * 64 + lane) * ST;
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mg[d * 16 + r] = o[d][r];
+      mg[DB * 16] = m_run; mg[DB * 16 + 1] = l_run;
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    const float m1 = mg[DB * 16], l1 = mg[DB * 16 + 1];
+    const float m = max2(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.c), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.c);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = o[d][r] * a0 + mg[d * 16 + r] * a1;
+  }
   // ---- finalize.  o[db][r] = O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hh][query qc]
   const float l = sum_xor32(l_run);
   if (wave_active && qrow < p.Sq) {
@@ -1248,6 +1286,20 @@ void attn_set_dma(int v) { g_attn_dma = v; }
 int g_attn_dma_slots = 0;     // key 26: resident one-wave workgroups per CU the split count of that form is sized for (low byte; 0 = by the launch's size), ring stages per wave (next byte, 2..4; 16 KiB of LDS each)
 int g_attn_dma_stages = 2;
 void attn_set_dma_slots(int v) { g_attn_dma_slots = v & 255; const int st = (v >> 8) & 255; g_attn_dma_stages = st < 2 ? 2 : (st > 4 ? 4 : st); }
+int g_attn_kg = 0;            // key 36: key groups of the MHA prefill kernel (attn2_kernel KG): 0 = by the launch's fill, 1 / 2 = forced
+void attn_set_kg(int v) { g_attn_kg = v; }
+// attn2_kernel takes its K / V rings as dynamic LDS (128 KB with two key groups at head dim 128): the attribute is set once per instantiation
+template <typename K>
+static int launch_attn2(K kern, dim3 grid, int threads, int lds, hipStream_t s, const AttnP& p, bool* attr_done) {
+  if (!*attr_done) {
+    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
+  return 0;
+}
+#define OM_LAUNCH_ATTN2(KERN, GRID, THREADS, LDS)                                     \
+  do { static bool done_ = false; const int rc_ = launch_attn2((KERN), (GRID), (THREADS), (LDS), s, p, &done_); if (rc_) return rc_; } while (0)
 int g_attn_mha_xcd = 1;       // key 33: 1 = MHA prefill attention launches keep the query blocks of a head on one XCD (one-dimensional grid)
 void attn_set_mha_xcd(int v) { g_attn_mha_xcd = v; }
 int g_attn_hsplit = -1;       // key 30: heaviest causal block ranks of a GQA prefill attention launch issued as two head halves (-1 = a quarter of the ranks when the launch is <= one workgroup per CU, 0 = off, n > 0 = n ranks whatever the size)
@@ -1304,9 +1356,25 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   // three-dimensional grid)
   dim3 grid_x = grid;
   if (g_attn_mha_xcd && !a.causal && grid.x < 65536 && a.batch < 32768) { p.tpw = -1; p.nsplit = (int)grid.x | (a.batch << 16); grid_x = dim3(cdiv(a.q_heads * a.batch, 8) * 8 * grid.x, 1, 1); }
+  constexpr int LDS128 = 2 * 2 * KV_TILE * 256;      // two stages of a K + V tile pair at head dim 128
+  // two key groups per workgroup (attn2_kernel KG = 2) when the launch's workgroups fill their resident rounds badly: `wgs` workgroups on
+  // CUs x per_cu1 slots in whole rounds against twice the rounds of half length on CUs x per_cu2 slots (3-tile ViT: 675 workgroups = 2 rounds
+  // of 512 slots against 3 half rounds of 256; 24 tiles: 11 rounds either way -> one group)
+  auto use_kg2 = [&](int per_cu1, int per_cu2) {
+    if (a.causal || a.kv_start || a.q_heads != a.kv_heads) return false;
+    if (g_attn_kg) return g_attn_kg == 2;
+    const long wgs = (long)grid.x * a.q_heads * a.batch, G = device_cus();
+    const long r1 = (wgs + G * per_cu1 - 1) / (G * per_cu1), r2 = (wgs + G * per_cu2 - 1) / (G * per_cu2);
+    return 2 * r1 > r2 + (r1 > 4 ? 1 : 0) && cdiv(a.Skv, KV_TILE) >= 4;      // strictly fewer half rounds (and not a marginal gain on long launches)
+  };
   if (hd == 64 && g_attn_v2 && a.q_heads == a.kv_heads) {      // InternViT-300M on the second-generation kernel (round 3)
-    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false, 64>), grid_x, dim3(256), 0, s, p);
-    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false, 64>), grid_x, dim3(256), 0, s, p);
+    // (head dim 64: 124 VGPRs, four 4-wave workgroups per CU, or two 8-wave ones with the keys split)
+    const bool kg2 = use_kg2(4, 2);
+    constexpr int LDS64 = 2 * 2 * KV_TILE * 128;
+    if (kg2 && dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 8, false, 64, 2>), grid_x, 512, 2 * LDS64);
+    else if (kg2 && dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 8, false, 64, 2>), grid_x, 512, 2 * LDS64);
+    else if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false, 64>), grid_x, 256, LDS64);
+    else if (dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 4, false, 64>), grid_x, 256, LDS64);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();
     return 0;
@@ -1320,8 +1388,12 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   }
   const int n_rep = a.q_heads / a.kv_heads;
   if (g_attn_v2 && n_rep == 1) {                 // MHA (ViT): 4 waves = 128 queries of one head
-    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, 4, false>), grid_x, dim3(256), 0, s, p);
-    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, 4, false>), grid_x, dim3(256), 0, s, p);
+    // (248 VGPRs: two 4-wave workgroups per CU, or ONE 8-wave workgroup with the keys split between its wave groups)
+    const bool kg2 = use_kg2(2, 1);
+    if (kg2 && dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 8, false, 128, 2>), grid_x, 512, 2 * LDS128);
+    else if (kg2 && dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 8, false, 128, 2>), grid_x, 512, 2 * LDS128);
+    else if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false>), grid_x, 256, LDS128);
+    else if (dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 4, false>), grid_x, 256, LDS128);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();
     return 0;
@@ -1339,8 +1411,8 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
     p.nsplit = a.batch; p.tpw = xs;
 #define OM_A2(NW_)                                                                                                       \
   do {                                                                                                                   \
-    if (dtype == OMCHAT_F16) hipLaunchKernelGGL((attn2_kernel<f16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);            \
-    else if (dtype == OMCHAT_BF16) hipLaunchKernelGGL((attn2_kernel<bf16, NW_, true>), g2, dim3(NW_ * 64), 0, s, p);     \
+    if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, NW_, true>), g2, NW_ * 64, LDS128);                      \
+    else if (dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, NW_, true>), g2, NW_ * 64, LDS128);               \
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }                                               \
   } while (0)
     switch (n_rep) { case 2: OM_A2(2); break; case 3: OM_A2(3); break; case 4: OM_A2(4); break; case 5: OM_A2(5); break;

@@ -334,3 +334,38 @@ def test_gemm_split_into_whole_rounds_and_a_tail_launch(gpu_lib, dt, tile, M, N,
         assert torch.isfinite(outs[0].float()).all(), (epi, "non-finite / unwritten outputs")
         assert rel(outs[0], ref) < TOL[dt], (epi, tile, rel(outs[0], ref))
         assert torch.equal(outs[0], outs[1]), (epi, tile)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ViT attention with the keys split between two wave groups of one workgroup (attn2_kernel KG = 2, tuning key 36)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,S,H,D,lens", [(3, 1025, 25, 128, None), (2, 300, 5, 128, None), (8, 1025, 16, 64, None), (1, 129, 9, 64, None), (2, 64, 3, 128, None),
+                                        (3, 257, 4, 128, [257, 100, 33]), (1, 2000, 2, 128, None)])
+def test_mha_prefill_attention_with_two_key_groups_vs_reference_and_one_group(gpu_lib, dt, b, S, H, D, lens):
+    """eight waves on the same 128 queries, each half walking half of the key tiles, merged through LDS: against the fp32 softmax(QK^T)V and
+    against the one-group kernel (same values up to where the online softmax is cut: one rescale more per query); odd tile counts (17, 5, 3),
+    a single key tile (the second group has nothing), padded key lengths, both head dims, both grid forms (key 33)"""
+    q = rnd(randn((b, S, H, D), 1), dt); k = rnd(randn((b, H, S, D), 2), dt); v = rnd(randn((b, H, S, D), 3), dt)
+    dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens else None
+    outs = {}
+    try:
+        for kg in (2, 1):
+            for k33 in (1, 0):
+                gpu_lib.omchat_op_set_tuning(36, kg); gpu_lib.omchat_op_set_tuning(33, k33)
+                o = torch.full((b, S, H, D), float("nan"), dtype=DT[dt], device="cuda")
+                _lib.check(gpu_lib.omchat_op_attn_prefill_d(CODE[dt], ptr(dq), ptr(dk), ptr(dv), ptr(o), b, S, S, H, H, D, ptr(dl), 0, 0, D ** -0.5, None))
+                sync()
+                assert torch.isfinite(o.float()).all(), (kg, k33)
+                outs[(kg, k33)] = o.clone()
+    finally:
+        gpu_lib.omchat_op_set_tuning(36, 0); gpu_lib.omchat_op_set_tuning(33, 1)
+    assert torch.equal(outs[(2, 0)], outs[(2, 1)]) and torch.equal(outs[(1, 0)], outs[(1, 1)])
+    sc = torch.einsum("bqhd,bhkd->bhqk", q.float(), k.float()) * D ** -0.5
+    if lens:
+        for i, n in enumerate(lens):
+            sc[i, :, :, n:] = float("-inf")
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), v.float())
+    assert rel(outs[(2, 1)], ref) < TOL[dt] and rel(outs[(1, 1)], ref) < TOL[dt]
+    assert rel(outs[(2, 1)], outs[(1, 1)]) < TOL[dt] / 4
