@@ -1361,6 +1361,11 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   // CUs x per_cu1 slots in whole rounds against twice the rounds of half length on CUs x per_cu2 slots (3-tile ViT: 675 workgroups = 2 rounds
   // of 512 slots against 3 half rounds of 256; 24 tiles: 11 rounds either way -> one group)
   auto use_kg2 = [&](int per_cu1, int per_cu2) {
+    // measured (round 5, profiles/r05_r_attn_two_key_groups.txt): SLOWER -- 3 tiles 73.4 vs 68.0 us, 24 tiles 510.8 vs 436.4 us.  The eight waves share
+    // every barrier, so the two waves of a SIMD sit in the same phase (both in their MFMAs, then both in the softmax), where two independent
+    // four-wave workgroups drift apart and overlap one's MFMAs with the other's VALU: a step costs 17 % more and eats what the better fill
+    // gives.  Kept for the experiments build only (forced with key 36 = 2).
+    if (!OMCHAT_EXPERIMENTS || g_attn_kg != 2) return false;
     if (a.causal || a.kv_start || a.q_heads != a.kv_heads) return false;
     if (g_attn_kg) return g_attn_kg == 2;
     const long wgs = (long)grid.x * a.q_heads * a.batch, G = device_cus();
@@ -1369,11 +1374,14 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   };
   if (hd == 64 && g_attn_v2 && a.q_heads == a.kv_heads) {      // InternViT-300M on the second-generation kernel (round 3)
     // (head dim 64: 124 VGPRs, four 4-wave workgroups per CU, or two 8-wave ones with the keys split)
-    const bool kg2 = use_kg2(4, 2);
+    const bool kg2 = use_kg2(4, 2); (void)kg2;
     constexpr int LDS64 = 2 * 2 * KV_TILE * 128;
+#if OMCHAT_EXPERIMENTS
     if (kg2 && dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 8, false, 64, 2>), grid_x, 512, 2 * LDS64);
     else if (kg2 && dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 8, false, 64, 2>), grid_x, 512, 2 * LDS64);
-    else if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false, 64>), grid_x, 256, LDS64);
+    else
+#endif
+    if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false, 64>), grid_x, 256, LDS64);
     else if (dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 4, false, 64>), grid_x, 256, LDS64);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();
@@ -1389,10 +1397,13 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   const int n_rep = a.q_heads / a.kv_heads;
   if (g_attn_v2 && n_rep == 1) {                 // MHA (ViT): 4 waves = 128 queries of one head
     // (248 VGPRs: two 4-wave workgroups per CU, or ONE 8-wave workgroup with the keys split between its wave groups)
-    const bool kg2 = use_kg2(2, 1);
+    const bool kg2 = use_kg2(2, 1); (void)kg2;
+#if OMCHAT_EXPERIMENTS
     if (kg2 && dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 8, false, 128, 2>), grid_x, 512, 2 * LDS128);
     else if (kg2 && dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 8, false, 128, 2>), grid_x, 512, 2 * LDS128);
-    else if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false>), grid_x, 256, LDS128);
+    else
+#endif
+    if (dtype == OMCHAT_F16) OM_LAUNCH_ATTN2((attn2_kernel<f16, 4, false>), grid_x, 256, LDS128);
     else if (dtype == OMCHAT_BF16) OM_LAUNCH_ATTN2((attn2_kernel<bf16, 4, false>), grid_x, 256, LDS128);
     else { omchat_set_error("launch_attn_prefill: bad dtype"); return 1; }
     OM_LAUNCH_CHECK();

@@ -346,6 +346,8 @@ def test_mha_prefill_attention_with_two_key_groups_vs_reference_and_one_group(gp
     """eight waves on the same 128 queries, each half walking half of the key tiles, merged through LDS: against the fp32 softmax(QK^T)V and
     against the one-group kernel (same values up to where the online softmax is cut: one rescale more per query); odd tile counts (17, 5, 3),
     a single key tile (the second group has nothing), padded key lengths, both head dims, both grid forms (key 33)"""
+    if not gpu_lib.omchat_has_experiments():
+        pytest.skip("measured slower than two independent four-wave workgroups (73.4 vs 68.0 us at 3 tiles, DESIGN.md section 6): -DOMCHAT_EXPERIMENTS=1 builds only")
     q = rnd(randn((b, S, H, D), 1), dt); k = rnd(randn((b, H, S, D), 2), dt); v = rnd(randn((b, H, S, D), 3), dt)
     dq, dk, dv = dev(q, dt), dev(k, dt), dev(v, dt)
     dl = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens else None
