@@ -60,6 +60,13 @@ PY
     python3 tools/roofline_table.py $T --fetch $F --write $W | tee $O/roofline_table.txt
     python3 tools/pmc_summary.py $F $W $O/pmc_traffic.json > /dev/null
     rm -rf $O/t $O/f $O/w
+    # configs[2] (batch 32): kernel stats + the two PMC passes -> pmc_traffic_configs2.json (bench.py reads it for the side block's traffic)
+    rocprofv3 --kernel-trace --stats -d $O/t2 -o t --output-format csv -- python3 bench.py --workload configs2 --steps 1 --warmup 1 --gen 16 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/stats2.err
+    cp $(find $O/t2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_configs2_steps1_gen16.csv
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f2 -o f --output-format csv -- python3 bench.py --workload configs2 --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/fetch2.err
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w2 -o w --output-format csv -- python3 bench.py --workload configs2 --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/write2.err
+    python3 tools/pmc_summary.py $(find $O/f2 -name "*counter_collection.csv" | head -1) $(find $O/w2 -name "*counter_collection.csv" | head -1) $O/pmc_traffic_configs2.json > /dev/null
+    rm -rf $O/t2 $O/f2 $O/w2
     ;;
   py) python3 "$@" 2>&1 | tee $O/py.txt | tail -60 ;;
   *) echo "unknown job $job"; exit 2 ;;
