@@ -284,3 +284,52 @@ def test_gemm_fp32_output_epilogue(gpu_lib, dt):
         ref = A.double() @ W.double().t()
         assert torch.isfinite(out).all()
         assert float((out.double().cpu() - ref).norm() / ref.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("b,dims", [(5, dict(q_heads=4, kv_heads=2)), (20, dict(q_heads=4, kv_heads=2)),
+                                    (20, dict(q_heads=8, kv_heads=2, hidden_t=1024, mlp_t=1024))])
+def test_tp2_batched_decode_equals_the_oracle(gpu_lib, dt, b, dims):
+    """round 5: BASELINE configs[2] decodes a BATCH under tensor parallelism (packed activations, split-K slices summed over the ranks inside the
+    residual + RMSNorm step, the shard-width launch shapes of tuning key 34) -- two rank contexts on one GPU, ragged right-padded batch of b
+    sequences, two decode steps: every checked row against the oracle run of that sequence alone (transformers modeling_qwen2.py:269-298), both
+    ranks' greedy picks equal"""
+    cfg = tiny(layers_t=2, **dims)
+    keep = lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k
+    sd = {k: v for k, v in synth.state_dict(cfg, 17).items() if keep(k)}
+    H = cfg.text["hidden_size"]
+    grp = Group(2)
+    engines, hooks = [], []
+    for r in range(2):
+        e = Engine(cfg, dtype=dt, max_seq=96, max_batch=b, max_tiles=1, tp_rank=r, tp_size=2, comm=C.c_void_p(1), vision=False)
+        h = grp.hook_for(r)
+        _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+        e.load_state_dict(sd)
+        engines.append(e); hooks.append(h)
+    S = 24
+    from gpu_util import rnd
+    x = rnd(torch.randn(b, S, H, generator=torch.Generator().manual_seed(b)) * 0.5, dt)
+    lens = [S - (i % 5) for i in range(b)]
+    toks = torch.arange(b) % 300 + 5
+
+    def run(r):
+        e = engines[r]
+        e.prefill(x, lens)
+        n1, l1 = e.decode_step(toks, want_logits=True)
+        n2, l2 = e.decode_step(n1, want_logits=True)
+        torch.cuda.synchronize()
+        return l1.float().cpu(), l2.float().cpu(), n1.cpu(), n2.cpu()
+
+    res = _run_ranks(run, 2)
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])      # vocab-parallel greedy agrees on both ranks
+    full1 = torch.cat([res[0][0], res[1][0]], dim=-1); full2 = torch.cat([res[0][1], res[1][1]], dim=-1)
+    sdt = {k: rnd(T32(v), dt) for k, v in sd.items()}
+    for i in sorted({0, 1, b // 2, b - 1}):
+        cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+        oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
+        o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+        o2 = oracle.decode_step(res[0][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+        assert rel(full1[i], o1) < TOL_DEEP[dt] and rel(full2[i], o2) < TOL_DEEP[dt], (i, rel(full1[i], o1), rel(full2[i], o2))
+        assert int(res[0][2][i]) == int(torch.argmax(full1[i]))
+    for e in engines:
+        e.close()
