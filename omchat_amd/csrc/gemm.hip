@@ -22,10 +22,13 @@
 
 namespace {
 
+int g_gemm_wide_store = 1;   // omchat_op_set_tuning key 37: 1 = 16-byte epilogue stores (two column blocks exchanged between lane pairs), 0 = 8-byte stores
+
 struct GemmP {
   const void* A; const void* W; void* C; const void* bias; const void* ls; const void* resid;
   int lda, ldw, ldc, ldr, M, N, K;
   const float* a_scale; const float* w_scale;      // fp8 x fp8 kernel: per-row scales of A and W (null otherwise)
+  int wide_store;                                  // 16-byte epilogue stores (gemm_epilogue)
 };
 
 // Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
@@ -163,6 +166,52 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
           }
         }
       }
+      // one output fragment (i, jj) of this lane: four consecutive columns, packed to 8 bytes
+      auto out4 = [&](int i, int jj) {
+        const int j = j0 + jj;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) rv = unpack4<T>(rb[i][jj]);
+        float o[4];
+        if constexpr (EPI == EPI_GELU) {
+          const f32x2 g0 = gelu_erf2((f32x2){rnd<T>(acc[i][j][0] + bv[jj][0]), rnd<T>(acc[i][j][1] + bv[jj][1])});
+          const f32x2 g1 = gelu_erf2((f32x2){rnd<T>(acc[i][j][2] + bv[jj][2]), rnd<T>(acc[i][j][3] + bv[jj][3])});
+          o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][r] + bv[jj][r];
+            if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
+            if constexpr (EPI == EPI_LS_RESID) v = rv[r] + rnd<T>(v * lsv[jj][r]);
+            if constexpr (EPI == EPI_RESID) v = rv[r] + v;
+            o[r] = v;
+          }
+        }
+        return pack4<T>(o[0], o[1], o[2], o[3]);
+      };
+      // Wide stores (round 5): the PMC passes read 1.6-1.7 x the output bytes in WRITE_SIZE for these epilogues (fc1 133 MB for 78.7 MB): a 128-byte
+      // line of C was completed by FOUR 8-byte-per-lane store instructions MR stores apart, and L2 wrote partly filled lines back in between.  Two
+      // neighbouring column blocks are exchanged between the lane pairs (fg, fg ^ 1) with v_permlane16_swap after packing -- the even lane keeps
+      // block j and takes its partner's four columns of it, the odd lane gets block j + 1 -- so every lane stores 16 bytes = 8 consecutive columns and
+      // a row's 64 bytes of the block pair leave in one instruction.  Needs N, ldc % 8 == 0 and a 16-byte aligned C (every hot-path shape).
+      const bool wide = (JG % 2 == 0) && (NR % 2 == 0) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && p.wide_store;
+      if (wide) {
+#pragma unroll
+        for (int jj = 0; jj < JG; jj += 2) {
+          const int j = j0 + jj;
+          if (j + 1 < NR && colu + j * 16 < p.N) {              // (N % 8 == 0 and blocks of 16: a started block pair may end inside the second block)
+            const bool second = colu + (j + 1) * 16 < p.N;
+            const int cw = (fr * p.ldc + 4 * (fg & ~1)) * 2 + (colu + (j + (fg & 1)) * 16) * 2;
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+              const u32x2 a = out4(i, jj), b = out4(i, jj + 1);
+              const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+              const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+              const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+              if (second || !(fg & 1)) __builtin_amdgcn_raw_buffer_store_b128(w, crs, cw + i * 16 * p.ldc * 2, 0, 0);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int jj = 0; jj < JG; ++jj) {
         const int j = j0 + jj;
@@ -170,27 +219,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
         if (j < NR && col < p.N) {
           const int cj = c_lane + (colu + j * 16) * 2;
 #pragma unroll
-          for (int i = 0; i < MR; ++i) {
-            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_LS_RESID || EPI == EPI_RESID) rv = unpack4<T>(rb[i][jj]);
-            float o[4];
-            if constexpr (EPI == EPI_GELU) {
-              const f32x2 g0 = gelu_erf2((f32x2){rnd<T>(acc[i][j][0] + bv[jj][0]), rnd<T>(acc[i][j][1] + bv[jj][1])});
-              const f32x2 g1 = gelu_erf2((f32x2){rnd<T>(acc[i][j][2] + bv[jj][2]), rnd<T>(acc[i][j][3] + bv[jj][3])});
-              o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] + bv[jj][r];
-                if constexpr (EPI != EPI_NONE) v = rnd<T>(v);      // T(acc + b) feeds further fp32 math; alone, the store below is that rounding
-                if constexpr (EPI == EPI_LS_RESID) v = rv[r] + rnd<T>(v * lsv[jj][r]);
-                if constexpr (EPI == EPI_RESID) v = rv[r] + v;
-                o[r] = v;
-              }
-            }
-            __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(o[0], o[1], o[2], o[3]), crs, cj + i * 16 * p.ldc * 2, 0, 0);
-          }
+          for (int i = 0; i < MR; ++i) __builtin_amdgcn_raw_buffer_store_b64(out4(i, jj), crs, cj + i * 16 * p.ldc * 2, 0, 0);
         }
+      }
       }
     }
   }
@@ -654,7 +685,7 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   const int KT = a.K / 64;
   const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
@@ -694,7 +725,7 @@ int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   if (tiles > n_cu && g_gemm_persist && n_cu >= 8) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
   else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
@@ -711,7 +742,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store};
   const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
   OM_LAUNCH_CHECK();
@@ -807,6 +838,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 void gemm_set_skew(int v) { g_gemm_skew = v; }
 void gemm_set_persist(int v) { g_gemm_persist = v; }
+void gemm_set_wide_store(int v) { g_gemm_wide_store = v; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Tile choice by measurement.  Which kernel wins depends on the shape in ways a fill-the-last-round model does not capture
