@@ -198,8 +198,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
 #pragma unroll
         for (int jj = 0; jj < JG; jj += 2) {
           const int j = j0 + jj;
-          if (j + 1 < NR && colu + j * 16 < p.N) {              // (N % 8 == 0 and blocks of 16: a started block pair may end inside the second block)
-            const bool second = colu + (j + 1) * 16 < p.N;
+          if (j + 1 < NR && colu + j * 16 < p.N) {              // (a started block pair may end inside either block: per-lane test below)
+            // this lane's eight columns start at a multiple of 8: inside the matrix or wholly outside it (N % 8 == 0)
+            const bool mine = colu + (j + (fg & 1)) * 16 + 4 * (fg & ~1) < p.N;
             const int cw = (fr * p.ldc + 4 * (fg & ~1)) * 2 + (colu + (j + (fg & 1)) * 16) * 2;
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
@@ -207,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
               const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
               const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
               const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
-              if (second || !(fg & 1)) __builtin_amdgcn_raw_buffer_store_b128(w, crs, cw + i * 16 * p.ldc * 2, 0, 0);
+              if (mine) __builtin_amdgcn_raw_buffer_store_b128(w, crs, cw + i * 16 * p.ldc * 2, 0, 0);
             }
           }
         }

@@ -371,3 +371,30 @@ def test_mha_prefill_attention_with_two_key_groups_vs_reference_and_one_group(gp
     ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), v.float())
     assert rel(outs[(2, 1)], ref) < TOL[dt] and rel(outs[(1, 1)], ref) < TOL[dt]
     assert rel(outs[(2, 1)], outs[(1, 1)]) < TOL[dt] / 4
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [2, 9, 10, 1])
+@pytest.mark.parametrize("M,N,K,ldc", [(515, 3000, 128, 3000), (300, 1000, 64, 1008), (1025, 3200, 128, 3200), (257, 1004, 64, 1004), (130, 520, 64, 528)])
+def test_gemm_epilogue_wide_stores_same_bits_as_narrow(gpu_lib, dt, tile, M, N, K, ldc):
+    """16-byte epilogue stores (tuning key 37 = 1: neighbouring column blocks exchanged between lane pairs) against the 8-byte form: the same values to the
+    same places, bit for bit, for every epilogue -- N a multiple of 16, N = 8 mod 16 (the last block pair ends inside a block), N % 8 != 0 (falls back),
+    padded row stride; nothing written outside [M, N] (the padding columns keep their sentinel)"""
+    A = rnd(randn((M, K), 1), dt); W = rnd(randn((N, K), 2, 0.05), dt)
+    bias = rnd(randn((N,), 3, 0.1), dt); ls = rnd(randn((N,), 4, 0.1) + 0.1, dt); resid = rnd(randn((M, ldc), 5), dt)
+    dA, dW, db, dl, dr = dev(A, dt), dev(W, dt), dev(bias, dt), dev(ls, dt), dev(resid, dt)
+    for epi in (_lib.EPI_NONE, _lib.EPI_GELU, _lib.EPI_LS_RESID, _lib.EPI_RESID):
+        use_bias = epi != _lib.EPI_RESID
+        outs = {}
+        try:
+            for key in (1, 0):
+                gpu_lib.omchat_op_set_tuning(37, key)
+                out = torch.full((M, ldc), 77.0, dtype=DT[dt], device="cuda")
+                _lib.check(gpu_lib.omchat_op_gemm(CODE[dt], ptr(dA), K, ptr(dW), K, ptr(out), ldc, M, N, K, ptr(db) if use_bias else None,
+                                                  ptr(dl), ptr(dr), ldc, epi, tile, None))
+                sync()
+                outs[key] = out.clone()
+        finally:
+            gpu_lib.omchat_op_set_tuning(37, 1)
+        assert torch.equal(outs[1], outs[0]), (epi, tile)
+        assert bool((outs[1][:, N:] == 77.0).all()) and torch.isfinite(outs[1][:, :N].float()).all()
