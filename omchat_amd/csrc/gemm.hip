@@ -195,15 +195,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
       // a row's 64 bytes of the block pair leave in one instruction.  Needs N, ldc % 8 == 0 and a 16-byte aligned C (every hot-path shape).
       const bool wide = (JG % 2 == 0) && (NR % 2 == 0) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && p.wide_store;
       if (wide) {
+        // row fragment outer, block pairs inner: the two 64-byte halves of a 128-byte line of C leave in consecutive instructions
 #pragma unroll
-        for (int jj = 0; jj < JG; jj += 2) {
-          const int j = j0 + jj;
-          if (j + 1 < NR && colu + j * 16 < p.N) {              // (a started block pair may end inside either block: per-lane test below)
-            // this lane's eight columns start at a multiple of 8: inside the matrix or wholly outside it (N % 8 == 0)
-            const bool mine = colu + (j + (fg & 1)) * 16 + 4 * (fg & ~1) < p.N;
-            const int cw = (fr * p.ldc + 4 * (fg & ~1)) * 2 + (colu + (j + (fg & 1)) * 16) * 2;
+        for (int i = 0; i < MR; ++i) {
 #pragma unroll
-            for (int i = 0; i < MR; ++i) {
+          for (int jj = 0; jj < JG; jj += 2) {
+            const int j = j0 + jj;
+            if (j + 1 < NR && colu + j * 16 < p.N) {              // (a started block pair may end inside either block: per-lane test below)
+              // this lane's eight columns start at a multiple of 8: inside the matrix or wholly outside it (N % 8 == 0)
+              const bool mine = colu + (j + (fg & 1)) * 16 + 4 * (fg & ~1) < p.N;
+              const int cw = (fr * p.ldc + 4 * (fg & ~1)) * 2 + (colu + (j + (fg & 1)) * 16) * 2;
               const u32x2 a = out4(i, jj), b = out4(i, jj + 1);
               const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
               const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
