@@ -253,7 +253,10 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 34: launch shapes for the SHARD widths of a tensor-parallel rank's decode GEMVs (default 7): bit 0 = the x-stationary form, one tile per
  * workgroup, for the short qkv shard of a batched step; bit 1 = split-K slices of >= 16 chunks and one chunk per wave per step for short-K
  * o_proj / down_proj shards; bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up shard (0 = the round-4 shapes; same sums up
- * to fp32 order where the slice count changes) */
+ * to fp32 order where the slice count changes);
+ * key 35 (experiments build): a rank context whose exchanges are no-ops takes the one-GPU launch structures on its shard widths (measurement);
+ * key 36 (experiments build): 2 = the MHA prefill attention splits the keys between two wave groups of an eight-wave workgroup (measured slower);
+ * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */
