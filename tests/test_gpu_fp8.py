@@ -313,6 +313,8 @@ def test_fp8_modes_error_per_layer_over_four_full_width_layers_16k_context(gpu_l
     from oracle.decoder import rope_cos_sin, qwen2_attention, qwen2_mlp
     from oracle.vit import rms_norm
     import json, os, time
+    if (os.cpu_count() or 1) < 48:
+        pytest.skip(f"the 16 k-key oracle pass needs a many-core host ({os.cpu_count()} CPUs here)")
     dt, L, S = "bf16", 4, 16400
     cfg = omchat13b()
     cfg.text["num_hidden_layers"] = L

@@ -102,6 +102,10 @@ def _device_weight_source(cfg, seed=0):
 @pytest.fixture(scope="module")
 def runs(gpu_lib):
     from oracle import stream
+    # the streamed fp32 oracle is ~190 s on the 128 host threads torch uses on the MI355X boxes; a host with a fraction of that would push the
+    # whole GPU suite past its time budget -- skipping loudly is the lesser evil there
+    if (os.cpu_count() or 1) < 48:
+        pytest.skip(f"full-depth oracle pass needs a many-core host ({os.cpu_count()} CPUs here): run tests/test_gpu_fulldepth.py on its own")
     cfg = omchat13b()
     t0 = time.time()
     g16 = _gpu_run("bf16", None)
