@@ -588,13 +588,14 @@ def main():
             if f8:
                 kern = "gemv_rows_kernel<EPI_SWIGLU, F8> (decode gate|up e4m3 weight stream, batch 1)"
             elif b == 1:
-                kern = "gemv_rows_norm_loop_kernel<EPI_SWIGLU> (decode post-attention RMSNorm + gate|up weight stream, batch 1)"
+                kern = "gemv_rows_norm_kernel<EPI_SWIGLU, 1 pair per wave> (decode post-attention RMSNorm + gate|up weight stream, batch 1)"
             else:
                 kern = f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
             tr, src = (None, None)
             if plain and not f8:
                 if b == 1:      # the launch that streams gate|up in the default configuration first, then the forms behind tuning keys 16 / 14
-                    subs = (["gemv_rows_norm_loop_kernelI", "Li4ELi7ELb0E"], ["gemv_rows_norm_kernelI", "Li4ELi3ELi7ELb0E"], ["gemv_rows_kernelI", "Li4ELi4ELi4E"])
+                    subs = (["gemv_rows_norm_kernelI", "Li4ELi1ELi7ELb0E"], ["gemv_rows_norm_loop_kernelI", "Li4ELi7ELb0E"], ["gemv_rows_norm_kernelI", "Li4ELi3ELi7ELb0E"],
+                            ["gemv_rows_kernelI", "Li4ELi4ELi4E"])
                     for i, sub in enumerate(subs):
                         tr, src = pmc_traffic(sub, quiet=i + 1 < len(subs))
                         if tr is not None:

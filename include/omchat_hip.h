@@ -224,7 +224,7 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 14: batch-1 decode, bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final RMSNorm inside the
  * qkv / lm_head GEMV with down_proj un-split (default 3; 0 = both residual + RMSNorm launches stay);
  * key 16: which of those norm-in-GEMV launches take the loop form (one resident round of workgroups, three register buffers per wave):
- * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 1; every form gives the same bits);
+ * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 0 since round 5 -- key 38; every form gives the same bits);
  * key 17: 1 (default) = batch-1 o_proj / qkv launches whose rows deal evenly to two workgroups per CU use N / (2 CUs) waves per workgroup;
  * key 19: split-KV merges with more partials per head than this take the 512-thread form (default 64: at 57 partials the 128-thread
  * one-batch form is faster, 4.9 vs 5.9 us);
@@ -256,7 +256,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * to fp32 order where the slice count changes);
  * key 35 (experiments build): a rank context whose exchanges are no-ops takes the one-GPU launch structures on its shard widths (measurement);
  * key 36 (experiments build): 2 = the MHA prefill attention splits the keys between two wave groups of an eight-wave workgroup (measured slower);
- * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits) */
+ * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits);
+ * key 38: (gate, up) pairs per wave of the batch-1 gate|up GEMV's non-loop norm form: 1 (default: thousands of small workgroups that the dispatcher
+ * re-balances over the XCDs; decode 2.650 -> 2.597 ms per token against the loop form), 2, 3 (same bits) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -1270,6 +1270,9 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   }
 }
 
+int g_gemv_longk_rpw = 0;       // omchat_op_set_tuning key 39: rows per workgroup of the long-K batch-1 GEMV (0 = N / (2 CUs), at most 8)
+int g_gemv_lm_rr = 0;
+int g_gemv_gu_waves = 4;        // omchat_op_set_tuning key 41 (A/B)           // omchat_op_set_tuning key 40: rows per wave of the lm_head norm GEMV (0 = 4)
 template <typename T>
 int launch_rows_longk(const GemvP& p, hipStream_t s) {
   const int n_cu = device_cus();
@@ -1295,7 +1298,13 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
 int g_gemv_rows_balance = 1;   // omchat_op_set_tuning key 17: 1 = one-row-per-wave launches whose rows deal evenly to 2 workgroups per CU take N / (2 CUs) waves per workgroup (o_proj 7, qkv 9)
 unsigned g_gemv_skew = 0;      // omchat_op_set_tuning key 28 (experiment): per-(blockIdx % 8) share deltas of the loop form, eight nibbles (d + 8)
 int g_gemv_dyn = 0;            // omchat_op_set_tuning key 24: 1 = the loop form takes its outputs from atomic work counters when the caller provides them (gemv_rows_norm_dyn_kernel)
-int g_gemv_norm_loop = 1;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
+// omchat_op_set_tuning key 38: (gate, up) pairs per wave of the NON-loop norm form of the batch-1 gate|up GEMV.  Round 5: ONE pair per wave (4736
+// workgroups of four waves for Qwen2-7B) beats the loop form's one resident round of 512 workgroups x 37 pairs: decode 2.650 -> 2.597 ms per token on
+// one box (3 pairs per wave: 2.671, 2: 2.624).  The XCDs do not deliver the same HBM bandwidth when all stream at once, so a
+// static equal split ends on the slowest XCD; thousands of 14 KB-per-wave workgroups are re-balanced by the dispatcher as they retire, the way the
+// lm_head launch (9504 workgroups) always was -- it streams at 7.0 TB/s where the loop form reached 6.35.
+int g_gemv_gu_rr = 1;
+int g_gemv_norm_loop = 0;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
 
 template <typename T, int EPI, int RR, bool F8, int NCH>
 void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
@@ -1327,6 +1336,8 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
       return;
     }
   }
+  // (four waves per workgroup: 8 / 16 waves -- fewer repeats of the norm -- measured 2.633 / 2.646 against 2.599 ms per token; down_proj's long-K form
+  // with fewer rows per workgroup 2.615-2.765: each workgroup stages the 37 KB x for itself; lm_head with 2 / 1 rows per wave 2.591 against 2.597: noise)
   hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, RR, NCH, F8>), dim3(cdiv(cdiv(n_out, RR), 4)), dim3(256), 0, s, p);
 }
 template <typename T, int EPI, int RR, bool F8>
@@ -1380,7 +1391,9 @@ void launch_rows(const GemvP& p, hipStream_t s) {
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
     if (p.norm_w) {          // the norm shared through LDS; 3 (gate, up) pairs per wave: 6 x 7 chunks of weights + the row fit 256 VGPRs
       if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 2, false>(p, s);      // qkv: 8 rows (56 KB) per workgroup against 14 KB of x + norm weights
-      else if (EPI == EPI_SWIGLU) launch_rows_norm<T, EPI, 3, false>(p, s);
+      else if (EPI == EPI_SWIGLU && g_gemv_gu_rr == 2) launch_rows_norm<T, EPI, 2, false>(p, s);
+      else if (EPI == EPI_SWIGLU && g_gemv_gu_rr == 3) launch_rows_norm<T, EPI, 3, false>(p, s);
+      else if (EPI == EPI_SWIGLU) launch_rows_norm<T, EPI, 1, false>(p, s);
       else launch_rows_norm<T, EPI, 4, false>(p, s);
       return;
     }
@@ -1553,6 +1566,7 @@ void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_shard_shapes(int v) { g_gemv_shard = v; }
 int gemv_get_shard_shapes() { return g_gemv_shard; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
+void gemv_set_gu_rr(int v) { g_gemv_gu_rr = v; }
 void gemv_set_dyn(int v) { g_gemv_dyn = v; }
 void gemv_set_skew(int v) { g_gemv_skew = (unsigned)v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }

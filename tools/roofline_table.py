@@ -35,6 +35,9 @@ def kind_of(name):
             elif fam == "gemm_kernel":
                 m = re.search(r"gemm_kernelI\w+?Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d)E", name)
                 epi = int(m.group(5)) if m else None
+            elif fam == "gemv_rows_norm_kernel":
+                m = re.search(r"gemv_rows_norm_kernelI[A-Za-z0-9_]+?Li(\d)E", name)
+                epi = int(m.group(1)) if m else None
             elif fam == "attn2_kernel":
                 m = re.search(r"attn2_kernelI\w+?Li(\d)ELb(\d)E", name)
                 epi = int(m.group(2)) if m else None           # 1 = causal (decoder prefill), 0 = the ViT
@@ -78,7 +81,10 @@ def label(seq):
         elif f == "gemv_rows_longk_kernel":
             out[i] = "decode down_proj GEMV"
         elif f == "gemv_rows_norm_kernel":
-            out[i] = "decode qkv GEMV (+RMSNorm)" if nxt and nxt.startswith("attn_decode") else ("lm_head GEMV (+final norm)" if nxt and nxt.startswith("argmax") else None)
+            if e == 4:                                          # EPI_SWIGLU: the non-loop gate|up form (round 5 default)
+                out[i] = "decode gate|up GEMV (+RMSNorm)"
+            else:
+                out[i] = "decode qkv GEMV (+RMSNorm)" if nxt and nxt.startswith("attn_decode") else ("lm_head GEMV (+final norm)" if nxt and nxt.startswith("argmax") else None)
         elif f == "gemv_rows_kernel" and prev == "attn_merge_kernel":
             out[i] = "decode o_proj GEMV"
         elif f == "rmsnorm_kernel":
