@@ -1270,9 +1270,6 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   }
 }
 
-int g_gemv_longk_rpw = 0;       // omchat_op_set_tuning key 39: rows per workgroup of the long-K batch-1 GEMV (0 = N / (2 CUs), at most 8)
-int g_gemv_lm_rr = 0;
-int g_gemv_gu_waves = 4;        // omchat_op_set_tuning key 41 (A/B)           // omchat_op_set_tuning key 40: rows per wave of the lm_head norm GEMV (0 = 4)
 template <typename T>
 int launch_rows_longk(const GemvP& p, hipStream_t s) {
   const int n_cu = device_cus();
