@@ -1301,6 +1301,7 @@ int g_gemv_dyn = 0;            // omchat_op_set_tuning key 24: 1 = the loop form
 // static equal split ends on the slowest XCD; thousands of 14 KB-per-wave workgroups are re-balanced by the dispatcher as they retire, the way the
 // lm_head launch (9504 workgroups) always was -- it streams at 7.0 TB/s where the loop form reached 6.35.
 int g_gemv_gu_rr = 1;
+int g_gemv_gu_rr8 = 1;          // the same for the e4m3 replica (key 38, value x 16): 1.700 -> 1.678 -> 1.658 ms per token at 4 / 2 / 1 pairs per wave
 int g_gemv_norm_loop = 0;      // omchat_op_set_tuning key 16: loop form (gemv_rows_norm_loop_kernel) of a batch-1 step's bit 0 = gate|up, 1 = qkv, 2 = e4m3 gate|up, 3 = lm_head
 
 template <typename T, int EPI, int RR, bool F8, int NCH>
@@ -1376,6 +1377,8 @@ void launch_rows(const GemvP& p, hipStream_t s) {
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_NONE) {
       if (p.norm_w) {
         if (EPI == EPI_NONE && p.N < 32768) launch_rows_norm<T, EPI, 2, true>(p, s);
+        else if (EPI == EPI_SWIGLU && g_gemv_gu_rr8 == 2) launch_rows_norm<T, EPI, 2, true>(p, s);
+        else if (EPI == EPI_SWIGLU && g_gemv_gu_rr8 == 1) launch_rows_norm<T, EPI, 1, true>(p, s);
         else launch_rows_norm<T, EPI, 4, true>(p, s);
         return;
       }
@@ -1563,7 +1566,7 @@ void gemv_set_no_xs(int v) { g_gemv_no_xs = v; }
 void gemv_set_shard_shapes(int v) { g_gemv_shard = v; }
 int gemv_get_shard_shapes() { return g_gemv_shard; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
-void gemv_set_gu_rr(int v) { g_gemv_gu_rr = v; }
+void gemv_set_gu_rr(int v) { if (v >= 16) g_gemv_gu_rr8 = v / 16; else g_gemv_gu_rr = v; }
 void gemv_set_dyn(int v) { g_gemv_dyn = v; }
 void gemv_set_skew(int v) { g_gemv_skew = (unsigned)v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }
