@@ -616,3 +616,24 @@ def test_tuning_keys_are_refused_without_the_opt_in():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hits = subprocess.run(["grep", "-rn", "omchat_op_set_tuning(", os.path.join(root, "omchat_amd"), "--include=*.py"], capture_output=True, text=True).stdout
     assert hits.strip() == "", hits
+
+
+def test_roofline_table_merges_the_two_launches_of_a_split_gemm():
+    """tile ids 12 / 13 run a GEMM as two launches over disjoint column ranges (the bf16 ViT fc1 in the committed table): the tail launch belongs to
+    the same call, and the GEMM behind it is still fc2"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("roofline_table", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "roofline_table.py"))
+    rt = importlib.util.module_from_spec(spec); spec.loader.exec_module(rt)
+    N = "_ZN12_GLOBAL__N_1"
+    norm = N + "14rmsnorm_kernelIDF16bEEvPKT_iS3_PS1_iifi"
+    g0 = N + "12gemm8_kernelIDF16bLi0ELb0EEEvNS_5GemmPEi"
+    qkn = N + "17vit_qknorm_kernelIDF16bEEvPT_iPKS1_S4_iiffPKf"
+    mha = N + "12attn2_kernelIDF16bLi4ELb0ELi128ELi1EEEvNS_5AttnPE"
+    proj = N + "11gemm_kernelIDF16bLi192ELi224ELi4ELi2ELi2EEEvNS_5GemmPE"
+    fc1 = "void (anonymous namespace)::gemm8_kernel<bool _Accum, int, E, false>((anonymous namespace)::GemmP, int)"
+    fc1_tail = N + "11gemm_kernelIDF16bLi192ELi224ELi4ELi2ELi1EEEvNS_5GemmPE"
+    fc2 = N + "11gemm_kernelIDF16bLi192ELi224ELi4ELi2ELi2EEEvNS_5GemmPE"
+    layer = [norm, g0, qkn, mha, proj, norm, fc1, fc1_tail, fc2]
+    got = rt.label(layer * 2)
+    want = ["RMSNorm (ViT)", "ViT qkv GEMM", "ViT q/k norm", "ViT attention (MHA)", "ViT proj GEMM", "RMSNorm (ViT)", "ViT fc1 GEMM (GELU)", "ViT fc1 GEMM (GELU)", "ViT fc2 GEMM"]
+    assert got == want * 2

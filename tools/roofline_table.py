@@ -65,7 +65,9 @@ def label(seq):
         elif f == "vit_qknorm_kernel":
             out[i] = "ViT q/k norm"
         elif f in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel"):
-            if nxt in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel"):
+            nxt2 = fam[i + 2] if i + 2 < len(seq) else None
+            if nxt in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel") or (nxt in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel") and nxt2 in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel")
+                                                                       and prev == "rmsnorm_kernel"):
                 out[i] = "ViT qkv GEMM"
             elif nxt == "rope_kv_kernel":
                 out[i] = "prefill qkv GEMM"
@@ -75,7 +77,15 @@ def label(seq):
                 # fc1 / gate|up follow a norm and feed the second MLP GEMM; the ViT's follows its attention block
                 out[i] = "ViT fc1 GEMM (GELU)" if ctx == "vit" else "prefill gate|up GEMM (SwiGLU)"
             elif prev in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel") and out[i - 1] in ("ViT fc1 GEMM (GELU)", "prefill gate|up GEMM (SwiGLU)"):
-                out[i] = "ViT fc2 GEMM" if ctx == "vit" else "prefill down_proj GEMM"
+                # a GEMM may run as TWO launches over disjoint column ranges (tile ids 12 / 13: whole rounds + a tail): the tail keeps the epilogue
+                # of its GEMM (GELU = 1 for fc1), the next GEMM of the MLP has the residual epilogue (2 / 3)
+                if e == 1 and out[i - 1] == "ViT fc1 GEMM (GELU)":
+                    out[i] = out[i - 1]
+                else:
+                    out[i] = "ViT fc2 GEMM" if ctx == "vit" else "prefill down_proj GEMM"
+            elif prev in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel") and out[i - 1] in ("ViT fc2 GEMM", "prefill down_proj GEMM", "ViT qkv GEMM", "ViT proj GEMM",
+                                                                                         "prefill qkv GEMM", "prefill o_proj GEMM") and kinds[i - 1][1] == e and e is not None:
+                out[i] = out[i - 1]                              # tail launch of the same GEMM
         elif f == "gemv_rows_norm_loop_kernel":
             out[i] = "decode gate|up GEMV (+RMSNorm)"
         elif f == "gemv_rows_longk_kernel":
@@ -146,17 +156,25 @@ def main():
     roles = label(names)
     W = work(a.tiles, a.text, a.gen)
     t = collections.defaultdict(list)
+    prev_role = None
     for r, u in zip(roles, us):
         if r:
-            t[r].append(u)
+            if r == prev_role and "GEMM" in r:
+                t[r][-1] += u                      # the tail launch of a two-launch GEMM: one call
+            else:
+                t[r].append(u)
+        prev_role = r
     traffic = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
     for path, ctr, slot, mul in ((a.fetch, "FETCH_SIZE", 0, 2.0), (a.write, "WRITE_SIZE", 1, 1.0)):
         if path:
             pn, pv = read_pmc(path, ctr)
+            pr = None
             for r, v in zip(label(pn), pv):
                 if r:
                     traffic[r][slot] += mul * v * 1024.0
-                    traffic[r][2 + slot] += 1
+                    if not (r == pr and "GEMM" in r):
+                        traffic[r][2 + slot] += 1
+                pr = r
     total = sum(us)
     print(f"# {a.trace}: {len(us)} dispatches, {total / 1e3:.2f} ms of kernel time; geometry: {a.tiles} tiles + {a.text} text ids, {a.gen} decode tokens")
     print(f"{'role':36s} {'calls':>6s} {'avg us':>9s} {'% time':>7s} {'work / launch':>16s} {'achieved':>14s} {'frac':>6s} {'PMC traffic':>12s} {'x alg.':>7s}")
