@@ -18,7 +18,7 @@ from omchat_amd.config import omchat8b_21, omchat13b, tiny
 from omchat_amd.engine import Engine
 from omchat_amd.image_processing import HipImageProcessor
 
-DEFAULT_KEY16 = 1      # gemv.hip: g_gemv_norm_loop
+DEFAULT_KEY16 = 0          # loop form of the norm-in-GEMV launches: off since round 5 (the gate|up launch takes the one-pair-per-wave form, key 38)
 DTS = ["bf16", "f16"]
 CONSIST_TOL = {"bf16": 6e-2, "f16": 1e-2}
 

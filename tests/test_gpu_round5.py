@@ -398,3 +398,29 @@ def test_gemm_epilogue_wide_stores_same_bits_as_narrow(gpu_lib, dt, tile, M, N, 
             gpu_lib.omchat_op_set_tuning(37, 1)
         assert torch.equal(outs[1], outs[0]), (epi, tile)
         assert bool((outs[1][:, N:] == 77.0).all()) and torch.isfinite(outs[1][:, :N].float()).all()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,K", [(37888, 3584), (4736, 3584), (8192 + 64, 2048), (96, 1024 + 8)])
+def test_gate_up_norm_gemv_pairs_per_wave_same_bits(gpu_lib, dt, N, K):
+    """tuning key 38: the batch-1 gate|up GEMV with its RMSNorm in registers as 1 (default), 2 or 3 (gate, up) pairs per wave, and the loop form (key 16):
+    one wave owns a pair's whole dot products in every form, so not a bit may differ; and against the fp32 restatement with Qwen2RMSNorm's rounding points
+    (transformers modeling_qwen2.py:247-252 + :46-48)"""
+    x = rnd(randn((K,), 1), dt); w = rnd(randn((N, K), 2, 0.05), dt); nw = rnd(randn((K,), 3, 0.1) + 1.0, dt)
+    xn = rnd(nw * rnd(x * torch.rsqrt((x * x).mean() + 1e-6), dt), dt)
+    blocks = (w @ xn).reshape(N // 32, 2, 16)
+    ref = (rnd(torch.nn.functional.silu(rnd(blocks[:, 0], dt)), dt) * rnd(blocks[:, 1], dt)).reshape(N // 2)
+    dx, dw, dn = dev(x, dt), dev(w, dt), dev(nw, dt)
+    outs = []
+    try:
+        for k38, k16 in ((1, 0), (2, 0), (3, 0), (1, 1)):
+            gpu_lib.omchat_op_set_tuning(38, k38); gpu_lib.omchat_op_set_tuning(16, k16)
+            out = torch.full((N // 2,), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemv_norm(CODE[dt], ptr(dx), ptr(dw), K, ptr(out), N, K, ptr(dn), 1e-6, None, _lib.EPI_SWIGLU, 0, None))
+            sync()
+            outs.append(out)
+    finally:
+        gpu_lib.omchat_op_set_tuning(38, 1); gpu_lib.omchat_op_set_tuning(16, 0)
+    assert rel(outs[0], ref) < TOL[dt]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
