@@ -1270,8 +1270,88 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   }
 }
 
+#if OMCHAT_EXPERIMENTS
+// The same rows WITHOUT the LDS stage (round 5, tuning key 39): a wave streams one row and uses every x element once, so the LDS copy only saves L2
+// reads of x (37 KB, resident in every XCD's L2).  Here a wave loads its x passes from L2 next to its weight passes, two passes in flight:
+// no barrier and no shared state, so the workgroups can be as small as one wave and the dispatcher re-deals them over the XCDs as they retire (what
+// made the one-pair-per-wave gate|up launch faster).  Same chunk order and the same dot products as the LDS form: bit-identical.
+// MEASURED SLOWER (same box, configs[1] decode ms per token): LDS form 2.605; this form as 1 / 2 / 4 waves per workgroup 2.700 / 2.707 / 2.712 -- the
+// x registers halve the waves per SIMD (204 VGPRs) and 3584 rows no longer fit one resident round.  Experiments build only.
+template <typename T, bool F8>
+__global__ __launch_bounds__(256) void gemv_rows_longk_direct_kernel(GemvP p) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nch = (p.K + 511) >> 9, npass = (nch + 7) >> 3;
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  if (n >= p.N) return;
+  const int row = n;
+  typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
+  auto load_w = [&](wreg_t (&w)[8], int pass) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int k = (pass * 8 + c) * 512 + lane * 8;
+      k = k < p.K ? k : 0;
+      if constexpr (F8) w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x2*>((const unsigned char*)p.W + (size_t)row * p.ldw + k));
+      else w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)row * p.ldw + k));
+    }
+  };
+  auto load_x = [&](rw_u32x4 (&x)[8], int pass) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int k = (pass * 8 + c) * 512 + lane * 8;
+      const rw_u32x4 z = {0u, 0u, 0u, 0u};
+      x[c] = k < p.K ? *reinterpret_cast<const rw_u32x4*>((const T*)p.X + k) : z;
+    }
+  };
+  float acc = 0.f;
+  auto dots = [&](wreg_t (&w)[8], rw_u32x4 (&x)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if constexpr (F8) acc = rw_dot8_fp8<T>(w[c], x[c], acc);
+      else acc = rw_dot8<T>(w[c], x[c], acc);
+    }
+  };
+  wreg_t wa[8], wb[8];
+  rw_u32x4 xa[8], xb[8];
+  load_w(wa, 0);
+  load_x(xa, 0);
+  if (npass > 1) { load_w(wb, 1); load_x(xb, 1); }
+  const float e_bias_raw = tof(((const T*)(p.bias ? p.bias : p.X))[p.bias ? row : 0]);
+  const float e_res_raw = tof(((const T*)(p.resid ? p.resid : p.X))[p.resid ? row : 0]);
+  const float e_bias = p.bias ? e_bias_raw : 0.f, e_res = p.resid ? e_res_raw : 0.f;
+  float e_scale = 1.f;
+  if constexpr (F8) e_scale = p.w_scale[row];
+  // two passes of weights and x in flight per wave (128 registers: three to four waves per SIMD); a buffer pair is refilled right after its dot products
+  for (int ps = 0; ps < npass; ps += 2) {
+    dots(wa, xa);
+    if (ps + 2 < npass) { load_w(wa, ps + 2); load_x(xa, ps + 2); }
+    if (ps + 1 < npass) {
+      dots(wb, xb);
+      if (ps + 3 < npass) { load_w(wb, ps + 3); load_x(xb, ps + 3); }
+    }
+  }
+  float a = acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if constexpr (F8) a *= e_scale;
+  if (lane == 0) {
+    const float y = rnd<T>(a + e_bias);
+    ((T*)p.Y)[n] = fromf<T>(e_res + y);
+  }
+}
+
+#endif
+int g_gemv_longk_direct = 0;   // omchat_op_set_tuning key 39 (experiments build): waves per workgroup (1, 2, 4) of the no-LDS long-K form; 0 = x through LDS (gemv_rows_longk_kernel)
+
 template <typename T>
 int launch_rows_longk(const GemvP& p, hipStream_t s) {
+#if OMCHAT_EXPERIMENTS
+  if (g_gemv_longk_direct > 0) {
+    const int wpw = g_gemv_longk_direct > 4 ? 4 : g_gemv_longk_direct;
+    if (p.w_scale) hipLaunchKernelGGL((gemv_rows_longk_direct_kernel<T, true>), dim3(cdiv(p.N, wpw)), dim3(64 * wpw), 0, s, p);
+    else hipLaunchKernelGGL((gemv_rows_longk_direct_kernel<T, false>), dim3(cdiv(p.N, wpw)), dim3(64 * wpw), 0, s, p);
+    return 0;
+  }
+#endif
   const int n_cu = device_cus();
   int rpw = cdiv(p.N, 2 * n_cu);                // two workgroups per CU
   rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);
@@ -1568,6 +1648,7 @@ int gemv_get_shard_shapes() { return g_gemv_shard; }
 void gemv_set_norm_loop(int v) { g_gemv_norm_loop = v; }
 void gemv_set_gu_rr(int v) { if (v >= 16) g_gemv_gu_rr8 = v / 16; else g_gemv_gu_rr = v; }
 void gemv_set_dyn(int v) { g_gemv_dyn = v; }
+void gemv_set_longk_direct(int v) { g_gemv_longk_direct = v; }
 void gemv_set_skew(int v) { g_gemv_skew = (unsigned)v; }
 void gemv_set_rows_balance(int v) { g_gemv_rows_balance = v; }
 

@@ -14,6 +14,8 @@ from omchat_amd import synth, _lib
 from omchat_amd.config import tiny
 from omchat_amd.engine import Engine
 
+DEFAULT_KEY39 = 0      # tuning key 39 of the shipped library (0 = long-K GEMV stages x in LDS)
+
 DTS = ["bf16", "f16"]
 
 
@@ -421,6 +423,34 @@ def test_gate_up_norm_gemv_pairs_per_wave_same_bits(gpu_lib, dt, N, K):
             outs.append(out)
     finally:
         gpu_lib.omchat_op_set_tuning(38, 1); gpu_lib.omchat_op_set_tuning(16, 0)
+    assert rel(outs[0], ref) < TOL[dt]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,K,in_place", [(3584, 18944, True), (256, 4608, True), (96, 8256, False), (7, 32768, True), (3000, 12352, True)])
+def test_long_k_gemv_without_the_lds_stage_same_bits(gpu_lib, dt, N, K, in_place):
+    """tuning key 39: the batch-1 down_proj GEMV (K in one piece, residual in the epilogue) with x loaded from L2 by every wave instead of staged in LDS,
+    as workgroups of 1 / 2 / 4 waves: the same chunk order and dot products as gemv_rows_longk_kernel, so not a bit may differ; ragged K and N; and
+    against fp32 torch (Qwen2MLP.down_proj + the residual add, transformers modeling_qwen2.py:41-48, :296-297).  Measured slower than the LDS form (DESIGN.md
+    section 6, round 5), so the kernel is only in the -DOMCHAT_EXPERIMENTS=1 build"""
+    if not gpu_lib.omchat_has_experiments():
+        pytest.skip("gemv_rows_longk_direct_kernel is in the experiments build only")
+    x = rnd(randn((K,), 1, 0.5), dt); w = rnd(randn((N, K), 2, 0.05), dt); r = rnd(randn((N,), 3), dt)
+    ref = r + rnd(w @ x, dt)
+    dx, dw = dev(x, dt), dev(w, dt)
+    outs = []
+    try:
+        for k39 in (0, 1, 2, 4):
+            gpu_lib.omchat_op_set_tuning(39, k39)
+            dr = dev(r, dt)
+            y = dr if in_place else torch.full((N,), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dx), K, ptr(dw), K, ptr(y), N, 1, N, K, None, ptr(dr), N, _lib.EPI_RESID, 0, None))
+            sync()
+            outs.append(y)
+    finally:
+        gpu_lib.omchat_op_set_tuning(39, DEFAULT_KEY39)
     assert rel(outs[0], ref) < TOL[dt]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
