@@ -57,6 +57,62 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const T* x, int l
   }
 }
 
+#if OMCHAT_EXPERIMENTS
+// The same RMSNorm with one WAVE per row (round 5; prefill / ViT row counts, H <= 4096): every load of the row and of the weight is issued before the
+// first use, the statistics need no LDS and no barrier, and all rows of a 3 k-row launch are resident at once.  A lane plays the four threads
+// {lane, lane + 64, lane + 128, lane + 192} of rmsnorm_kernel's workgroup and the partial sums are combined in that kernel's order, so the bits are the same.
+// MEASURED: no faster (rocprof, configs[1]: 10.4 us against 9.3 (ViT) / 10.7 (prefill) per launch; q / k norm 18.3 against 18.5; ViT 38.0-38.4 ms either way):
+// these launches move 39 / 79 MB of read + write traffic at the chip's copy rate, not at a latency chain's.  Experiments build only (tuning key 40).
+constexpr int NORM_WAVE_H = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_wave_kernel(const T* x, int ldx, const T* w, T* y, int ldy, int rows, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (size_t)row * ldx;
+  T* yr = y + (size_t)row * ldy;
+  const int nchunk = H >> 3;
+  v8 xv[2][4], wv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int c = i * 256 + v * 64 + lane; if (c < nchunk) xv[i][v] = ld8<T>(xr + c * 8); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int c = i * 256 + v * 64 + lane; if (c < nchunk) wv[i][v] = ld8<T>(w + c * 8); }
+  float tot = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + v * 64 + lane;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = tof(xv[i][v][j]); ss += f * f; }
+      }
+    }
+    tot += wave_sum(ss);
+  }
+  const float inv = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = i * 256 + v * 64 + lane;
+      if (c < nchunk) {
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[i][v][j]) * rnd<T>(tof(xv[i][v][j]) * inv));
+        st8<T>(yr + c * 8, o);
+      }
+    }
+}
+
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // fp8 x fp8 prefill (BASELINE configs[4]): the activation operand of the GEMM is e4m3 with one scale per token (row).
 //   NORM: y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (the reference's RMSNorm, same roundings), then s = absmax(y) / 448 (1 for a zero row),
@@ -291,6 +347,66 @@ __global__ __launch_bounds__(NORM_THREADS) void vit_qknorm_kernel(T* qkv, int ld
     }
   }
 }
+
+#if OMCHAT_EXPERIMENTS
+// one wave per (row, q | k) -- see rmsnorm_wave_kernel: same bits as vit_qknorm_kernel, all loads up front, no barrier
+template <typename T>
+__global__ __launch_bounds__(256) void vit_qknorm_wave_kernel(T* qkv, int ld, const T* wq, const T* wk, int rows, int C, int C_total,
+                                                              float eps, float q_scale, const float* sumsq_in) {
+  typedef typename V8<T>::type v8;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int part = blockIdx.y;
+  const int nchunk = C >> 3;
+  T* xr = qkv + (size_t)row * ld + part * C;
+  const T* w = part == 0 ? wq : wk;
+  v8 xv[2][4], wv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int c = i * 256 + v * 64 + lane; if (c < nchunk) xv[i][v] = ld8<T>(xr + c * 8); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const int c = i * 256 + v * 64 + lane; if (c < nchunk) wv[i][v] = ld8<T>(w + c * 8); }
+  float tot = 0.f;
+  if (sumsq_in) tot = sumsq_in[row * 2 + part];
+  else {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = i * 256 + v * 64 + lane;
+        if (c < nchunk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = tof(xv[i][v][j]); ss += f * f; }
+        }
+      }
+      tot += wave_sum(ss);
+    }
+  }
+  const float inv = rsqrtf(tot / (float)C_total + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = i * 256 + v * 64 + lane;
+      if (c < nchunk) {
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = rnd<T>(tof(wv[i][v][j]) * rnd<T>(tof(xv[i][v][j]) * inv));
+          if (part == 0) t = t * q_scale;
+          o[j] = fromf<T>(t);
+        }
+        st8<T>(xr + c * 8, o);
+      }
+    }
+}
+
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv, int ld, int C, float* out) {
@@ -533,6 +649,12 @@ inline int grid_for(long n, int threads) {
   else if ((dtype) == OMCHAT_BF16) { typedef bf16 T; CALL; }         \
   else { omchat_set_error("bad dtype"); return 1; }
 
+// omchat_op_set_tuning key 40 (experiments build): 1 = RMSNorm / ViT q-k norm launches of >= NORM_WAVE_ROWS rows with H <= 4096 take the one-wave-per-row
+// kernels (same bits as the workgroup-per-row ones; measured no faster), 0 (default) = always a workgroup per row
+static int g_norm_wave = 0;
+[[maybe_unused]] constexpr int NORM_WAVE_ROWS = 256;
+void norm_set_wave(int v) { g_norm_wave = v; }
+
 int launch_layernorm(int dtype, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int rows, int H, float eps, hipStream_t s) {
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H must be a multiple of 8 and <= 16384");
   OM_CHECK(w && b, "LayerNorm needs weight and bias");
@@ -545,6 +667,13 @@ int launch_rmsnorm(int dtype, const void* x, int ldx, const void* w, void* y, in
   OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0, "H % 8, H <= 16384, ld % 8");
   OM_CHECK(pack_nb == 0 || (rows <= 16 * pack_nb && H % 64 == 0 && x != y), "packed output: rows <= 16 * NB, H % 64 == 0, not in place");
   if (rows == 0) return 0;
+#if OMCHAT_EXPERIMENTS
+  if (g_norm_wave && rows >= NORM_WAVE_ROWS && H <= NORM_WAVE_H && pack_nb == 0) {
+    DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_wave_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, rows, H, eps));
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   DISPATCH(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, (const T*)w, (T*)y, ldy, H, eps, pack_nb));
   OM_LAUNCH_CHECK();
   return 0;
@@ -570,6 +699,14 @@ int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* 
                       float q_scale, const float* sumsq_in, hipStream_t s) {
   OM_CHECK(C % 8 == 0 && C <= NORM_THREADS * NORM_MAXC * 8 && ld % 8 == 0, "C % 8, C <= 16384, ld % 8");
   if (rows == 0) return 0;
+#if OMCHAT_EXPERIMENTS
+  if (g_norm_wave && rows >= NORM_WAVE_ROWS && C <= NORM_WAVE_H) {
+    DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_wave_kernel<T>, dim3((rows + 3) / 4, 2), dim3(256), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk, rows,
+                                       C, C_total, eps, q_scale, sumsq_in));
+    OM_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows, 2), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
                                      C, C_total, eps, q_scale, sumsq_in));
   OM_LAUNCH_CHECK();

@@ -151,6 +151,7 @@ void gemv_set_no_xs(int v);
 void gemv_set_shard_shapes(int v);      // tuning key 34
 void gemv_set_gu_rr(int v);             // tuning key 38
 void gemv_set_longk_direct(int v);      // tuning key 39
+void norm_set_wave(int v);              // tuning key 40
 int gemv_get_shard_shapes();
 
 // decode: one query token per sequence, q heads grouped per kv head; split-KV partials + merge.

@@ -454,3 +454,61 @@ def test_long_k_gemv_without_the_lds_stage_same_bits(gpu_lib, dt, N, K, in_place
     assert rel(outs[0], ref) < TOL[dt]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,H", [(3075, 3200), (300, 3584), (257, 4096), (1025, 1024), (259, 72)])
+def test_rmsnorm_one_wave_per_row_same_bits(gpu_lib, dt, rows, H):
+    """tuning key 40: RMSNorm launches of >= 256 rows (prefill, ViT) as one wave per row -- a lane plays four threads of the workgroup-per-row kernel and
+    the partial sums combine in that kernel's order, so not a bit may differ; against the oracle's rounding sequence (InternRMSNorm,
+    modeling_intern_vit.py:39-44 == Qwen2RMSNorm, transformers modeling_qwen2.py:247-252); a ragged last workgroup (rows % 4) and H % 512 != 0.
+    Measured no faster (these launches run at the chip's copy rate), so the wave kernels are in the -DOMCHAT_EXPERIMENTS=1 build only"""
+    import oracle
+    if not gpu_lib.omchat_has_experiments():
+        pytest.skip("rmsnorm_wave_kernel is in the experiments build only")
+    x = rnd(randn((rows, H), 1, 2.0), dt); w = rnd(randn((H,), 2, 0.1) + 1.0, dt)
+    dx, dw = dev(x, dt), dev(w, dt)
+    outs = []
+    try:
+        for k40 in (1, 0):
+            gpu_lib.omchat_op_set_tuning(40, k40)
+            out = torch.full((rows + 1, H), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_op_rmsnorm(CODE[dt], ptr(dx), ptr(dw), ptr(out), rows, H, 1e-6, None))
+            sync()
+            outs.append(out)
+    finally:
+        gpu_lib.omchat_op_set_tuning(40, 0)
+    assert torch.isnan(outs[0][rows].float()).all()          # nothing beyond the last row
+    assert torch.equal(outs[0][:rows], outs[1][:rows])
+    ref = oracle.rms_norm(x.to(DT[dt]), w.to(DT[dt]), 1e-6).float()
+    assert rel(outs[0][:rows], ref) < 2e-3
+    assert (outs[0][:rows].float().cpu() == ref).float().mean() > 0.98
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,C", [(3075, 3200), (258, 1024), (1025, 384)])
+def test_vit_qknorm_one_wave_per_row_same_bits(gpu_lib, dt, rows, C):
+    """tuning key 40 for the ViT's q / k norm over all heads of a token (modeling_intern_vit.py:143-148), in place on the fused qkv rows: one wave per
+    (row, q | k) against one workgroup, bit for bit; v untouched; against the oracle (experiments build only, as above)"""
+    import oracle
+    if not gpu_lib.omchat_has_experiments():
+        pytest.skip("vit_qknorm_wave_kernel is in the experiments build only")
+    qkv = rnd(randn((rows, 3 * C), 1), dt); wq = rnd(randn((C,), 2, 0.1) + 1, dt); wk = rnd(randn((C,), 3, 0.1) + 1, dt)
+    dwq = dev(wq, dt); dwk = dev(wk, dt)
+    scale = 128 ** -0.5
+    outs = []
+    try:
+        for k40 in (1, 0):
+            gpu_lib.omchat_op_set_tuning(40, k40)
+            d = dev(qkv, dt)
+            _lib.check(gpu_lib.omchat_op_vit_qknorm(CODE[dt], ptr(d), 3 * C, ptr(dwq), ptr(dwk), rows, C, C, 1e-6, scale, None))
+            sync()
+            outs.append(d)
+    finally:
+        gpu_lib.omchat_op_set_tuning(40, 0)
+    assert torch.equal(outs[0], outs[1])
+    T = DT[dt]
+    q = (oracle.rms_norm(qkv[:, :C].to(T), wq.to(T), 1e-6) * scale).float()
+    k = oracle.rms_norm(qkv[:, C:2 * C].to(T), wk.to(T), 1e-6).float()
+    assert rel(outs[0][:, :C], q) < 3e-3 and rel(outs[0][:, C:2 * C], k) < 3e-3
+    assert torch.equal(outs[0][:, 2 * C:].float().cpu(), qkv[:, 2 * C:])
