@@ -115,3 +115,27 @@ def run_streamed(pixels, input_ids, forced_tokens, get, embed_rows, vcfg, tcfg, 
         x = torch.cat([embeds, embed_rows(torch.tensor(forced_tokens, dtype=torch.int64))[None]], dim=1)
     logits = decoder_streamed(x, get, tcfg, last_n=k + 1, progress=progress)
     return dict(tower=tower, feats=feats, embeds=embeds, logits=logits[0], S=S)
+
+
+def ragged_rows_streamed(input_ids, attention_mask, feats, forced_tokens, get, embed_rows, tcfg, progress=None):
+    """A RIGHT-padded batch through prefill + padded-batch decode steps (omchat_arch.py:55-209 with an attention mask, then the
+    decode branch :61-70), computed row by row WITHOUT padding: the additive mask gives a padded key the weight exp(-inf) = 0
+    exactly, right padding leaves a valid token at position = its index, and the decode branch gives step k of a row of
+    valid length n the position sum(mask) - 1 = n + k and every key of the row -- so the logits of row r equal those of ONE
+    causal pass over [valid spliced embeds of r ; forced tokens of r] (tests/test_stream_oracle.py pins this equality against
+    the literal masked restatement on the tiny config).  `feats`: projected features per <image> sentinel, in batch order;
+    forced_tokens [b][k].  Returns (lengths, [logits [1 + k, vocab] per row])."""
+    class _Rows:
+        dtype = torch.float32
+        shape = (tcfg["vocab_size"], tcfg["hidden_size"])
+
+        def __getitem__(self, ids):
+            return embed_rows(ids)
+    embeds, mask_sp, lengths = splice_inputs(input_ids, attention_mask, [f for f in feats], _Rows(), "right", None)
+    out = []
+    for r, n in enumerate(lengths):
+        assert bool(mask_sp[r, :n].all()) and not bool(mask_sp[r, n:].any())
+        f = torch.tensor(list(forced_tokens[r]), dtype=torch.int64)
+        x = torch.cat([embeds[r:r + 1, :n], embed_rows(f)[None]], dim=1) if len(f) else embeds[r:r + 1, :n]
+        out.append(decoder_streamed(x, get, tcfg, last_n=len(f) + 1, progress=progress)[0])
+    return lengths, out

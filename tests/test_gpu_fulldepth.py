@@ -204,3 +204,87 @@ def test_full_depth_internvit300m_tower_and_projector_vs_streamed_oracle(gpu_lib
     _report(f"{dt}_tower300m", e_t); _report(f"{dt}_feats300m", e_f)
     assert torch.isfinite(tower).all() and torch.isfinite(feats).all()
     assert e_t < TOL[dt][0] and e_f < TOL[dt][1], (e_t, e_f)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FULL-DEPTH padded batch (round 5): two rows of different spliced length through the reference's batch path -- splice with the attention mask
+# (omchat_arch.py:55-209), right-padded prefill, then the decode branch (:61-70) through generate()'s own entries (masked_decode_begin + masked_next)
+# -- 45 tower layers + 28 decoder layers, the full vocabulary, against the layer-streamed fp32 oracle applied to every row WITHOUT padding
+# (oracle/stream.py ragged_rows_streamed; tests/test_stream_oracle.py pins that form to the literal masked restatement).
+# ---------------------------------------------------------------------------------------------------------------------
+RAGGED_TEXT = (40, 87)          # text ids per row; one <image> sentinel each: spliced lengths 1064 and 1111
+
+
+def _ragged_sample():
+    text = synth.token_ids(sum(RAGGED_TEXT), 151643, 7).tolist()
+    a, b = text[:RAGGED_TEXT[0]], text[RAGGED_TEXT[0]:]
+    rows = [[-200] + a, b[:7] + [-200] + b[7:]]
+    T = max(len(r) for r in rows)
+    ids = torch.zeros(2, T, dtype=torch.long); mask = torch.zeros(2, T, dtype=torch.long)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = torch.tensor(r); mask[i, :len(r)] = 1
+    return ids, mask
+
+
+def _gpu_ragged_run(dt, forced):
+    """forced = None: free-running greedy (the ids every other run is then forced to); else [b][k] ids to feed"""
+    from omchat_amd.model.omchat_qwen2 import OmChatQwen2ForCausalLM
+    cfg = omchat13b()
+    e = Engine(cfg, dtype=dt, max_seq=1160, max_batch=2, max_tiles=2)
+    e.fill_synthetic(0)
+    px, _ = _sample(cfg)
+    px2 = px[:2]
+    m = OmChatQwen2ForCausalLM(cfg.clone(), e)
+    m.get_vision_tower = lambda: object()
+    feats = e.encode_images(px2)
+    m.encode_images = lambda images: feats
+    ids, mask = _ragged_sample()
+    dummy = torch.zeros(2, 3, 448, 448)
+    out = m(input_ids=ids, attention_mask=mask, images=dummy, use_cache=True)
+    kv = out.past_key_values
+    logits = [out.logits[:, 0].float().cpu()]
+    tok = torch.argmax(logits[0], dim=-1) if forced is None else torch.tensor([f[0] for f in forced])
+    tok_mask = torch.cat([mask, torch.ones(2, 1, dtype=torch.long)], dim=1)
+    _, pos1, mask1, _, _, _ = m.prepare_inputs_labels_for_multimodal(tok[:, None], None, tok_mask, kv, None, dummy)
+    e.masked_decode_begin(pos1, mask1)
+    fed = [[], []]
+    for k in range(N_FORCED):
+        for i in range(2):
+            fed[i].append(int(tok[i]))
+        nxt, lg = e.decode_step_masked_next(tok, want_logits=True); sync()
+        logits.append(lg.float().cpu())
+        tok = nxt.cpu().long() if forced is None or k + 1 >= N_FORCED else torch.tensor([f[k + 1] for f in forced])
+    out = dict(logits=logits, fed=fed, feats=feats.float().cpu(), kv_len=kv.get_seq_length())
+    e.close()
+    del e, m
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.fixture(scope="module")
+def ragged_runs(runs):
+    from oracle import stream
+    cfg = omchat13b()
+    g16 = _gpu_ragged_run("bf16", None)
+    h16 = _gpu_ragged_run("f16", g16["fed"])
+    get, embed_rows = _device_weight_source(cfg)
+    ids, mask = _ragged_sample()
+    t0 = time.time()
+    # the oracle's OWN projected features of tiles 0 and 1 (the tower treats tiles independently: same pixels as the batch-1 sample's first two tiles)
+    lengths, ol = stream.ragged_rows_streamed(ids, mask, runs["oracle"]["feats"][:2], g16["fed"], get, embed_rows, cfg.text)
+    print(f"\nfull-depth ragged batch: streamed fp32 oracle over rows of {lengths} positions: {time.time() - t0:.1f} s")
+    return dict(oracle=ol, lengths=lengths, bf16=g16, f16=h16)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_full_depth_ragged_batch_prefill_and_masked_decode_vs_per_row_oracle(ragged_runs, dt):
+    o, g = ragged_runs["oracle"], ragged_runs[dt]
+    assert ragged_runs["lengths"] == [1024 + RAGGED_TEXT[0], 1024 + RAGGED_TEXT[1]] and g["kv_len"] == max(ragged_runs["lengths"])
+    assert g["fed"] == ragged_runs["bf16"]["fed"]
+    errs = [[rel(g["logits"][k][i], o[i][k]) for k in range(1 + N_FORCED)] for i in range(2)]
+    print(f"\n{dt}: ragged batch, rel err of the logits per row (prefill, then {N_FORCED} masked decode steps): " + "; ".join(str(["%.3e" % e for e in r]) for r in errs))
+    _report(f"{dt}_ragged_logits", errs)
+    for i in range(2):
+        for k in range(1 + N_FORCED):
+            assert torch.isfinite(g["logits"][k][i]).all()
+            assert errs[i][k] < TOL[dt][2], (i, k, errs[i][k])
