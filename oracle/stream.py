@@ -19,8 +19,8 @@ weights k + 1 times.
 import torch
 
 from .vit import vit_embeddings, vit_layer, projector_forward
-from .decoder import qwen2_layer, rope_cos_sin, rms_norm
-from .splice import splice_inputs
+from .decoder import qwen2_layer, rope_cos_sin, rms_norm, KVCache
+from .splice import splice_inputs, decode_step_inputs
 
 TOWER = "model.vision_tower.vision_tower."
 
@@ -117,25 +117,48 @@ def run_streamed(pixels, input_ids, forced_tokens, get, embed_rows, vcfg, tcfg, 
     return dict(tower=tower, feats=feats, embeds=embeds, logits=logits[0], S=S)
 
 
-def ragged_rows_streamed(input_ids, attention_mask, feats, forced_tokens, get, embed_rows, tcfg, progress=None):
-    """A RIGHT-padded batch through prefill + padded-batch decode steps (omchat_arch.py:55-209 with an attention mask, then the
-    decode branch :61-70), computed row by row WITHOUT padding: the additive mask gives a padded key the weight exp(-inf) = 0
-    exactly, right padding leaves a valid token at position = its index, and the decode branch gives step k of a row of
-    valid length n the position sum(mask) - 1 = n + k and every key of the row -- so the logits of row r equal those of ONE
-    causal pass over [valid spliced embeds of r ; forced tokens of r] (tests/test_stream_oracle.py pins this equality against
-    the literal masked restatement on the tiny config).  `feats`: projected features per <image> sentinel, in batch order;
-    forced_tokens [b][k].  Returns (lengths, [logits [1 + k, vocab] per row])."""
+def padded_batch_streamed(input_ids, attention_mask, feats, forced_tokens, get, embed_rows, tcfg, padding_side="right", progress=None):
+    """A padded batch as the reference computes it, one decoder layer at a time: splice with the TEXT-level attention mask
+    (omchat_arch.py:55-209), padded prefill under the spliced mask (positions arange, padded keys masked), then k teacher-forced
+    decode steps through the decode branch (omchat_arch.py:61-70): the mask generate() carries is the TEXT-level one extended by a
+    one per step, the branch extends it with ones to cache length + 1 and takes position_ids = sum(mask) - 1 -- so a decode step
+    masks cache slots [t_r, T) of a right-padded row (t_r text ids of T), NOT its padded slots; this literal behaviour is what the
+    HIP path mirrors.  Teacher forcing makes the steps' layer-i inputs known once layer i - 1 is done, so every layer's weights are
+    fetched once and only one layer's cache is alive.  forced_tokens: int64 [b, k].
+    Returns (lengths, logits fp32 [b, 1 + k, vocab]): [:, 0] at each row's last valid (right) / last (left) prefill position."""
     class _Rows:
         dtype = torch.float32
         shape = (tcfg["vocab_size"], tcfg["hidden_size"])
 
         def __getitem__(self, ids):
             return embed_rows(ids)
-    embeds, mask_sp, lengths = splice_inputs(input_ids, attention_mask, [f for f in feats], _Rows(), "right", None)
-    out = []
-    for r, n in enumerate(lengths):
-        assert bool(mask_sp[r, :n].all()) and not bool(mask_sp[r, n:].any())
-        f = torch.tensor(list(forced_tokens[r]), dtype=torch.int64)
-        x = torch.cat([embeds[r:r + 1, :n], embed_rows(f)[None]], dim=1) if len(f) else embeds[r:r + 1, :n]
-        out.append(decoder_streamed(x, get, tcfg, last_n=len(f) + 1, progress=progress)[0])
-    return lengths, out
+    embeds, mask_sp, lengths = splice_inputs(input_ids, attention_mask, [f for f in feats], _Rows(), padding_side, None)
+    b, L0, _ = embeds.shape
+    forced = torch.as_tensor(forced_tokens, dtype=torch.int64).reshape(b, -1)
+    k = forced.shape[1]
+    nh = tcfg["num_attention_heads"]
+    d = tcfg.get("head_dim") or tcfg["hidden_size"] // nh
+    theta = tcfg.get("rope_theta", 1e6)
+    cos0, sin0 = rope_cos_sin(torch.arange(L0)[None, :].expand(b, L0), d, theta, embeds.dtype)
+    steps = []
+    tok_mask = torch.cat([attention_mask, torch.ones((b, 1), dtype=attention_mask.dtype)], dim=1)
+    for j in range(k):
+        mo, po = decode_step_inputs(tok_mask, L0 + j)
+        steps.append((mo, rope_cos_sin(po, d, theta, embeds.dtype)))
+        tok_mask = torch.cat([tok_mask, torch.ones((b, 1), dtype=attention_mask.dtype)], dim=1)
+    h0 = embeds
+    hd = [embed_rows(forced[:, j])[:, None] for j in range(k)]
+    for i in range(tcfg["num_hidden_layers"]):
+        w = {key: get(key) for key in _layer_keys_dec(i)}
+        cache = KVCache(i + 1)
+        h0 = qwen2_layer(h0, w, i, tcfg, cos0, sin0, cache, mask_sp)
+        for j in range(k):
+            mo, (cj, sj) = steps[j]
+            hd[j] = qwen2_layer(hd[j], w, i, tcfg, cj, sj, cache, mo)
+        del w, cache
+        if progress:
+            progress("dec", i)
+    last = [n - 1 for n in lengths] if padding_side == "right" else [L0 - 1] * b
+    rows = torch.cat([torch.stack([h0[r, last[r]] for r in range(b)])[:, None]] + hd, dim=1)          # [b, 1 + k, H]
+    rows = rms_norm(rows, get("model.norm.weight"), tcfg.get("rms_norm_eps", 1e-6))
+    return lengths, torch.nn.functional.linear(rows, get("lm_head.weight"))

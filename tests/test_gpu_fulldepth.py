@@ -209,8 +209,9 @@ def test_full_depth_internvit300m_tower_and_projector_vs_streamed_oracle(gpu_lib
 # ---------------------------------------------------------------------------------------------------------------------
 # FULL-DEPTH padded batch (round 5): two rows of different spliced length through the reference's batch path -- splice with the attention mask
 # (omchat_arch.py:55-209), right-padded prefill, then the decode branch (:61-70) through generate()'s own entries (masked_decode_begin + masked_next)
-# -- 45 tower layers + 28 decoder layers, the full vocabulary, against the layer-streamed fp32 oracle applied to every row WITHOUT padding
-# (oracle/stream.py ragged_rows_streamed; tests/test_stream_oracle.py pins that form to the literal masked restatement).
+# -- 45 tower layers + 28 decoder layers, the full vocabulary, against the layer-streamed fp32 oracle of the LITERAL padded batch
+# (oracle/stream.py padded_batch_streamed; tests/test_stream_oracle.py pins it to the whole-dict masked restatement).  Literal matters: the decode
+# branch is fed the TEXT-level mask, so the shorter row's steps mask cache slots [t_r, T) and see its padded slots -- not the row computed alone.
 # ---------------------------------------------------------------------------------------------------------------------
 RAGGED_TEXT = (40, 87)          # text ids per row; one <image> sentinel each: spliced lengths 1064 and 1111
 
@@ -271,17 +272,17 @@ def ragged_runs(runs):
     ids, mask = _ragged_sample()
     t0 = time.time()
     # the oracle's OWN projected features of tiles 0 and 1 (the tower treats tiles independently: same pixels as the batch-1 sample's first two tiles)
-    lengths, ol = stream.ragged_rows_streamed(ids, mask, runs["oracle"]["feats"][:2], g16["fed"], get, embed_rows, cfg.text)
-    print(f"\nfull-depth ragged batch: streamed fp32 oracle over rows of {lengths} positions: {time.time() - t0:.1f} s")
+    lengths, ol = stream.padded_batch_streamed(ids, mask, runs["oracle"]["feats"][:2], g16["fed"], get, embed_rows, cfg.text, "right")
+    print(f"\nfull-depth ragged batch: streamed fp32 oracle of the padded batch, rows of {lengths} positions: {time.time() - t0:.1f} s")
     return dict(oracle=ol, lengths=lengths, bf16=g16, f16=h16)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_full_depth_ragged_batch_prefill_and_masked_decode_vs_per_row_oracle(ragged_runs, dt):
+def test_full_depth_ragged_batch_prefill_and_masked_decode_vs_padded_oracle(ragged_runs, dt):
     o, g = ragged_runs["oracle"], ragged_runs[dt]
     assert ragged_runs["lengths"] == [1024 + RAGGED_TEXT[0], 1024 + RAGGED_TEXT[1]] and g["kv_len"] == max(ragged_runs["lengths"]) + N_FORCED      # the common cache slot: Lmax + k for every row
     assert g["fed"] == ragged_runs["bf16"]["fed"]
-    errs = [[rel(g["logits"][k][i], o[i][k]) for k in range(1 + N_FORCED)] for i in range(2)]
+    errs = [[rel(g["logits"][k][i], o[i, k]) for k in range(1 + N_FORCED)] for i in range(2)]
     print(f"\n{dt}: ragged batch, rel err of the logits per row (prefill, then {N_FORCED} masked decode steps): " + "; ".join(str(["%.3e" % e for e in r]) for r in errs))
     _report(f"{dt}_ragged_logits", errs)
     for i in range(2):

@@ -50,47 +50,49 @@ def test_streamed_run_equals_whole_dict_oracle_and_cached_decode_steps():
     assert len(per_layer) == len(set(per_layer))
 
 
-def test_ragged_rows_unpadded_equal_the_masked_padded_restatement():
-    """oracle/stream.py ragged_rows_streamed (the full-depth padded-batch GPU test's oracle: every row alone, no padding) against the LITERAL
-    restatement of the reference's padded batch: splice with the attention mask (omchat_arch.py:55-209), padded prefill with the additive mask,
-    then the decode branch (:61-70: mask extended with ones, position_ids = sum(mask) - 1) on the shared cache -- the same logits per row up to
-    fp32 summation order"""
+def test_padded_batch_streamed_equals_the_whole_dict_masked_restatement():
+    """oracle/stream.py padded_batch_streamed (the full-depth padded-batch GPU test's oracle: one layer at a time, teacher-forced decode steps on a
+    one-layer cache) against the whole-dict restatement of the reference's padded batch -- splice with the attention mask (omchat_arch.py:55-209),
+    padded prefill, then the decode branch (:61-70) fed the TEXT-level mask generate() carries -- same logits; and the property that makes the literal
+    form matter: a right-padded row's decode step masks cache slots [t_r, T), not its pads, so it does NOT equal the row computed alone"""
     cfg = tiny()
-    seed = 5
-    sd = {k: T(v) for k, v in synth.state_dict(cfg, seed).items()}
+    sd = {k: T(v) for k, v in synth.state_dict(cfg, 5).items()}
     get = lambda key: sd[key]
     embed_rows = lambda ids: sd["model.embed_tokens.weight"][ids]
-    px = T(synth.pixels(3, 56, 2))
-    feats = oracle.encode_images(px, sd, cfg.vision)
+    feats = oracle.encode_images(T(synth.pixels(3, 56, 2)), sd, cfg.vision)
     rows = [[5, -200, 6, -200, 9, 10, 11], [-200] + list(range(30, 49)), [40, 41, 42]]
-    n_img = 3
     Tn = max(len(r) for r in rows)
-    ids = torch.zeros(3, Tn, dtype=torch.long); mask = torch.zeros(3, Tn, dtype=torch.long)
-    for i, r in enumerate(rows):
-        ids[i, :len(r)] = torch.tensor(r); mask[i, :len(r)] = 1
     # a row without a sentinel consumes a (zero-length slice of a) feature entry: four entries for three sentinels + one empty row
-    feats4 = torch.cat([feats[:n_img], feats[:1]], dim=0)
-    # literal padded path
-    emb, mask_sp, lengths = oracle.splice_inputs(ids, mask, [f for f in feats4], sd["model.embed_tokens.weight"], "right", None)
-    cache = oracle.KVCache(cfg.text["num_hidden_layers"])
-    h = oracle.qwen2_model(emb, sd, cfg.text, cache, None, mask_sp)
-    want = [[oracle.lm_head(h[i:i + 1, n - 1:n], sd)[0, 0]] for i, n in enumerate(lengths)]
-    tok = torch.stack([torch.argmax(w[0]) for w in want])
-    forced = [[] for _ in rows]
-    tok_mask = torch.cat([mask_sp.to(torch.long), torch.ones(3, 1, dtype=torch.long)], dim=1)
-    for k in range(3):
-        for i in range(3):
-            forced[i].append(int(tok[i]))
-        mo, po = oracle.decode_step_inputs(tok_mask, cache.get_seq_length())
-        ho = oracle.qwen2_model(sd["model.embed_tokens.weight"][tok][:, None], sd, cfg.text, cache, po, mo)
-        lg = oracle.lm_head(ho, sd)[:, -1]
-        for i in range(3):
-            want[i].append(lg[i])
-        tok = torch.argmax(lg, dim=-1)
-        tok_mask = torch.cat([tok_mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
-    lengths2, got = stream.ragged_rows_streamed(ids, mask, feats4, forced, get, embed_rows, cfg.text)
-    assert lengths2 == lengths and len(set(lengths)) == 3
-    for i in range(3):
-        assert got[i].shape[0] == 4
+    feats4 = torch.cat([feats, feats[:1]], dim=0)
+    for side in ("right", "left"):
+        ids = torch.zeros(3, Tn, dtype=torch.long); mask = torch.zeros(3, Tn, dtype=torch.long)
+        for i, r in enumerate(rows):
+            sl = slice(0, len(r)) if side == "right" else slice(Tn - len(r), Tn)
+            ids[i, sl] = torch.tensor(r); mask[i, sl] = 1
+        emb, mask_sp, lengths = oracle.splice_inputs(ids, mask, [f for f in feats4], sd["model.embed_tokens.weight"], side, None)
+        cache = oracle.KVCache(cfg.text["num_hidden_layers"])
+        h = oracle.qwen2_model(emb, sd, cfg.text, cache, None, mask_sp)
+        last = [n - 1 for n in lengths] if side == "right" else [emb.shape[1] - 1] * 3
+        want = [torch.stack([oracle.lm_head(h[i:i + 1, last[i]:last[i] + 1], sd)[0, 0] for i in range(3)])]
+        tok = torch.argmax(want[0], dim=-1)
+        forced = []
+        tok_mask = torch.cat([mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
+        for k in range(3):
+            forced.append(tok)
+            mo, po = oracle.decode_step_inputs(tok_mask, cache.get_seq_length())
+            ho = oracle.qwen2_model(sd["model.embed_tokens.weight"][tok][:, None], sd, cfg.text, cache, po, mo)
+            want.append(oracle.lm_head(ho, sd)[:, -1])
+            tok = torch.argmax(want[-1], dim=-1)
+            tok_mask = torch.cat([tok_mask, torch.ones(3, 1, dtype=torch.long)], dim=1)
+        forced = torch.stack(forced, dim=1)
+        lengths2, got = stream.padded_batch_streamed(ids, mask, feats4, forced, get, embed_rows, cfg.text, side)
+        assert lengths2 == lengths and len(set(lengths)) == 3 and got.shape[:2] == (3, 4)
         for k in range(4):
-            assert rel_err(got[i][k], want[i][k]) < 2e-5, (i, k)
+            assert rel_err(got[:, k], want[k]) < 2e-5, (side, k)           # other GEMM shapes in the final norm / lm_head: fp32 summation order only
+        if side == "right":
+            # the shortest row alone (no padding): its prefill logits are the padded batch's, its decode steps are not
+            r = 2
+            x = torch.cat([emb[r:r + 1, :lengths[r]], embed_rows(forced[r])[None]], dim=1)
+            alone = stream.decoder_streamed(x, get, cfg.text, last_n=4)[0]
+            assert rel_err(alone[0], want[0][r]) < 2e-5
+            assert rel_err(alone[1], want[1][r]) > 1e-3
