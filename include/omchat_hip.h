@@ -263,7 +263,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * key 39 (experiments build): n = 1 / 2 / 4: the batch-1 long-K GEMV (down_proj) loads x from L2 in every wave instead of staging it in LDS, as
  * workgroups of n waves (same bits; measured slower: 2.70 against 2.605 ms per token);
  * key 40 (experiments build): 1 = RMSNorm and ViT q / k norm launches of >= 256 rows (H <= 4096) take one wave per row -- all loads up front, no LDS,
- * no barrier; same bits, measured no faster -- 0 (default) = one workgroup per row */
+ * no barrier; same bits, measured no faster -- 0 (default) = one workgroup per row;
+ * key 41 (experiments build, TIMING PROBE: results are INVALID under it): 1 = every launch goes out with hipExtAnyOrderLaunch (consumers may overtake
+ * producers): prices the launch boundaries of a step */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -6,6 +6,9 @@
 #include <vector>
 
 #define S(x) ((hipStream_t)(x))
+#if OMCHAT_EXPERIMENTS
+int g_launch_any_order = 0;      // tuning key 41: timing probe, see kernels.h
+#endif
 
 extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                               const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream) {
@@ -55,6 +58,9 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 38) { gemv_set_gu_rr(value); return 0; }
   if (key == 39) { gemv_set_longk_direct(value); return 0; }
   if (key == 40) { norm_set_wave(value); return 0; }
+#if OMCHAT_EXPERIMENTS
+  if (key == 41) { g_launch_any_order = value; return 0; }
+#endif
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;
 }

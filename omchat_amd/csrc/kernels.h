@@ -9,6 +9,23 @@
 #define OMCHAT_EXPERIMENTS 0
 #endif
 #include "common.h"
+#if OMCHAT_EXPERIMENTS
+// TIMING PROBE ONLY (tuning key 41, experiments build): every kernel launch of the library goes out with hipExtAnyOrderLaunch.  On this GPU the flag does not
+// let a kernel overtake its predecessor (tools/tune_anyorder.hip: it still starts after the predecessor's last wave) but the boundary shrinks from 2.5 to
+// 0.3 us -- the release / acquire cache maintenance between the two is what goes.  Without it a consumer on another XCD may read stale lines, so results
+// under this key are NOT valid; it prices what boundaries without cache maintenance would return.
+#include <hip/hip_ext.h>
+extern int g_launch_any_order;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                                      \
+  do {                                                                                                                                         \
+    if (g_launch_any_order)                                                                                                                    \
+      hipExtLaunchKernelGGL((kernelName), dim3(numBlocks), dim3(numThreads), (memPerBlock), (streamId), nullptr, nullptr, hipExtAnyOrderLaunch, \
+                            __VA_ARGS__);                                                                                                      \
+    else                                                                                                                                       \
+      hipLaunchKernelGGLInternal((kernelName), numBlocks, numThreads, memPerBlock, streamId, __VA_ARGS__);                                     \
+  } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[M,N] = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulate on MFMA.  K % 64 == 0, lda/ldw % 8 == 0.
