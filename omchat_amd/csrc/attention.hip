@@ -1098,7 +1098,8 @@ __global__ __launch_bounds__(64) void attn_decode_dma_kernel(AttnP p) {
 // phase 2: thread d sums its column over the splits with independent (unrolled) loads.
 template <typename T>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
-                                                         T* O, int64_t o_sb, int64_t o_sh, int pack_nb, int split_keys) {
+                                                         T* O, int64_t o_sb, int64_t o_sh, int pack_nb, int split_keys,
+                                                         unsigned* done_flags = nullptr, unsigned done_epoch = 0, int done_mode = 0) {
   __shared__ float fw[1024];
   __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -1132,7 +1133,27 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
     float a = 0.f;
 #pragma unroll
     for (int s = 0; s < 64; ++s) a += fw[s] * v[s];
+#if OMCHAT_EXPERIMENTS
+    if (done_flags && (done_mode & 4)) {
+      // mode bit 2: the row element as a write-through store (sc0 sc1), drained, instead of a plain store + agent-scope release (buffer_wbl2 sc1)
+      const T o = fromf<T>(a / red[0]);
+      const size_t idx = pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d);
+      const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(O + idx - d, 0, 256, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, o), os, d * 2, 0, 17);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (d == 0) __hip_atomic_store(done_flags + h, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+#endif
     O[pack_nb ? packed_x_index(b, h * 128 + d, pack_nb) : (size_t)(b * o_sb + h * o_sh + d)] = fromf<T>(a / red[0]);
+#if OMCHAT_EXPERIMENTS
+    if (done_flags) {      // tuning key 42: an out-of-order consumer polls these (gemv_rows_wait_kernel)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (d == 0) __hip_atomic_store(done_flags + h, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
     return;
   }
   float acc = 0.f, ltot = 0.f, m_run = NEG_BIG;
@@ -1493,6 +1514,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   const int dma_lds = std::min(65536, std::max(g_attn_dma_stages * 16384, (160 / dma_slots) * 1024));
   dim3 grid(nsplit, a.kv_heads, a.batch);
   dim3 mgrid(a.q_heads, a.batch);
+  if (a.done_flags && (a.batch != 1 || nsplit > 64 || nsplit > g_merge_mid_min)) { omchat_set_error("launch_attn_decode: completion flags exist for the one-round-trip merge only (batch 1, <= 64 splits)"); return 1; }
   if (dtype == OMCHAT_F16) {
     if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true, true>), grid, dim3(64), 0, s, p);
     else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
@@ -1510,7 +1532,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
       if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
       else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode);
   } else if (dtype == OMCHAT_BF16) {
     if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true, true>), grid, dim3(64), 0, s, p);
     else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
@@ -1528,7 +1550,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
       if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
       else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
+    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

@@ -60,6 +60,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 40) { norm_set_wave(value); return 0; }
 #if OMCHAT_EXPERIMENTS
   if (key == 41) { g_launch_any_order = value; return 0; }
+  if (key == 42) { model_set_ao_oproj(value); return 0; }
 #endif
   omchat_set_error("omchat_op_set_tuning: unknown key");
   return 1;

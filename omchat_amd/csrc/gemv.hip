@@ -1717,6 +1717,79 @@ int launch_pack_w(int dtype, const void* W, int ldw, int N, int K, void* out, hi
   return 0;
 }
 
+#if OMCHAT_EXPERIMENTS
+// PROTOTYPE (round 5, tuning key 42): the batch-1 o_proj GEMV launched OUT OF ORDER behind the split-KV merge (hipExtAnyOrderLaunch: its workgroups are
+// placed as soon as the merge's are) -- every wave issues its weight row first, wave 0 then polls the merge's per-head completion flags (epoch values,
+// written after an agent-scope release by each merge workgroup), the workgroup acquires and only then loads the attention row.  One row per wave, K = NCH x 512
+// in one piece, residual in the epilogue: the same chunk order and dot products as gemv_rows_kernel<EPI_RESID> -- the same bits.
+template <typename T, int NCH>
+__global__ __launch_bounds__(448) void gemv_rows_wait_kernel(GemvP p, const unsigned* flags, unsigned epoch, int nflags, unsigned* err, int mode) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  const bool valid = n < p.N;
+  const int row = valid ? n : p.N - 1;
+  rw_u32x4 w[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)row * p.ldw + c * 512 + lane * 8));
+  const float e_res = tof(((const T*)p.resid)[row]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (wave == 0) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned f = lane < nflags ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      if (__all(f == epoch)) break;
+      if (mode & 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(1);      // mode bit 3: ~1 us between polls instead of ~30 ns
+      if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ull) { if (lane == 0) atomicOr(err, 4u); break; }      // 2 s of the 100 MHz clock
+    }
+  }
+  __syncthreads();
+  rw_u32x4 xr[NCH];
+  if (mode & 2) {
+    // mode bit 1: the attention row by cache-bypassing loads (sc0 sc1) instead of an agent-scope acquire (buffer_inv sc1 in 3584 waves) in front of plain loads
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, NCH * 1024, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) xr[c] = __builtin_bit_cast(rw_u32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, c * 1024 + lane * 16, 0, 17));
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) xr[c] = *reinterpret_cast<const rw_u32x4*>((const T*)p.X + c * 512 + lane * 8);
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) a = rw_dot8<T>(w[c], xr[c], a);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0 && valid) ((T*)p.Y)[n] = fromf<T>(e_res + rnd<T>(a));
+}
+
+template <typename T>
+static int launch_gemv_wait_t(const GemvArgs& a, const unsigned* flags, unsigned epoch, int nflags, unsigned* err, int mode, hipStream_t s) {
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, 0, 1, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
+  int wpw = cdiv(a.N, 2 * device_cus());
+  wpw = wpw < 1 ? 1 : (wpw > 7 ? 7 : wpw);
+  hipExtLaunchKernelGGL((gemv_rows_wait_kernel<T, 7>), dim3(cdiv(a.N, wpw)), dim3(64 * wpw), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, p, flags, epoch, nflags, err, mode);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+#endif
+
+// experiments build: see gemv_rows_wait_kernel.  Requirements: b = 1, K = 3584, 16-bit weights, EPI_RESID without bias, nflags <= 64.
+int launch_gemv_wait(int dtype, const GemvArgs& a, const unsigned* flags, unsigned epoch, int nflags, unsigned* err, int mode, hipStream_t s) {
+#if OMCHAT_EXPERIMENTS
+  OM_CHECK(a.b == 1 && a.K == 3584 && !a.w_scale && a.epi == EPI_RESID && !a.bias && a.resid && !a.x_packed && nflags >= 1 && nflags <= 64 && flags && err,
+           "launch_gemv_wait: batch 1, K = 3584, 16-bit weights, residual epilogue without bias");
+  if (dtype == OMCHAT_F16) return launch_gemv_wait_t<f16>(a, flags, epoch, nflags, err, mode, s);
+  if (dtype == OMCHAT_BF16) return launch_gemv_wait_t<bf16>(a, flags, epoch, nflags, err, mode, s);
+  omchat_set_error("bad dtype");
+  return 1;
+#else
+  (void)dtype; (void)a; (void)flags; (void)epoch; (void)nflags; (void)err; (void)mode; (void)s;
+  omchat_set_error("launch_gemv_wait: -DOMCHAT_EXPERIMENTS=1 builds only");
+  return 1;
+#endif
+}
+
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t s) {
   OM_CHECK(a.b >= 1 && a.b <= 32, "batch must be 1..32 per call");
   OM_CHECK(!a.x_packed || !a.w_scale, "packed x: 16-bit weights");      // (EPI_RESID: x-stationary form only, checked in launch_t)

@@ -96,6 +96,8 @@ struct GemvArgs {
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
 int launch_pack_w(int dtype, const void* W, int ldw, int N, int K, void* out, hipStream_t s);
 int launch_gemv(int dtype, const GemvArgs& a, hipStream_t stream);
+// experiments build (tuning key 42): the batch-1 o_proj GEMV launched out of order behind the split-KV merge, waiting on its per-head completion flags
+int launch_gemv_wait(int dtype, const GemvArgs& a, const unsigned* flags, unsigned epoch, int nflags, unsigned* err, int mode, hipStream_t s);
 // per-row (output channel) symmetric quantisation of W [N][ldw] (T) to OCP e4m3: scale[n] = absmax_n / 448 (1 if the row is 0),
 // W8[n][k] = e4m3_rne(W[n][k] / scale[n])
 int launch_quant_fp8_rows(int dtype, const void* W, int ldw, int N, int K, void* W8, int ld8, float* scale, hipStream_t stream);
@@ -169,6 +171,7 @@ void gemv_set_shard_shapes(int v);      // tuning key 34
 void gemv_set_gu_rr(int v);             // tuning key 38
 void gemv_set_longk_direct(int v);      // tuning key 39
 void norm_set_wave(int v);              // tuning key 40
+void model_set_ao_oproj(int v);         // tuning key 42
 int gemv_get_shard_shapes();
 
 // decode: one query token per sequence, q heads grouped per kv head; split-KV partials + merge.
@@ -195,6 +198,8 @@ struct AttnDecodeArgs {
   // padded batch as the reference decodes it (omchat_decode_step_masked): key j of sequence b is visible iff key_mask[b * mask_sb + j] != 0
   // (device bytes, rows zero-padded to mask_sb % 64 == 0); `pos` then holds the RoPE positions (not kv_len - 1); kv_len must be null
   const unsigned char* key_mask; int64_t mask_sb;
+  // experiments build (tuning key 42): the merge launch publishes done_flags[head] = done_epoch after an agent-scope release (batch 1, <= 64 splits only)
+  unsigned* done_flags = nullptr; unsigned done_epoch = 0; int done_mode = 0;
 };
 // quantise rows [pos0, pos1) of every (sequence < b, kv head) of a 16-bit cache [b_cap, kv_heads, cap, 128] into the fp8 cache + scales
 // (pos1 = null-terminated per sequence: rows >= len[b] are skipped when len != null)

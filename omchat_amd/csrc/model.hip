@@ -89,6 +89,8 @@ int g_decode_layer = 0;          // omchat_op_set_tuning key 23: 1 = batch-1 dec
 void model_set_decode_layer(int v) { g_decode_layer = v; }
 int g_fuse_attn_oproj = 0;      // omchat_op_set_tuning key 22: 1 = batch-1 decode on one GPU runs split-KV attention + merge + o_proj as ONE launch (fused_decode.hip); 0 = three launches (A/B, same bits)
 void model_set_fuse_attn_oproj(int v) { g_fuse_attn_oproj = v; }
+int g_ao_oproj = 0;            // omchat_op_set_tuning key 42 (experiments build, prototype): batch-1 o_proj launched out of order behind the split-KV merge (gemv_rows_wait_kernel)
+void model_set_ao_oproj(int v) { g_ao_oproj = v; }
 int g_fuse_peer_norm = 1;      // omchat_op_set_tuning key 9: 0 = tensor-parallel decode keeps the all-reduce and the residual + RMSNorm as two launches (A/B)
 void model_set_fuse_peer_norm(int v) { g_fuse_peer_norm = v; }
 
@@ -1268,18 +1270,28 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     a.o_pack_nb = fused ? pk : 0;
     // batch 1, one GPU (round 4): attention + merge + o_proj (+ residual) as ONE launch with in-launch hand-offs (fused_decode.hip; the same
     // bits as the three launches).  Eager steps only: the launch is tagged with a per-launch counter, which a captured graph would freeze.
+    bool ao_oproj = false;
     const bool fuse_ao = g_fuse_attn_oproj && n2 && exact_len && !f8 && a.rope && ctx->fd_ws && attn_oproj_fused_ok(a, H, qd);
     if (fuse_ao) {
       FusedDecodeArgs fa{L.wo, qd, x, H, qd, ctx->fd_ws, ++ctx->fd_epoch, ctx->fd_err, 2000};
       TRY(launch_attn_oproj_fused(ctx->dt, a, fa, s));
       ++ctx->n_fused_launches;
     } else {
+#if OMCHAT_EXPERIMENTS
+      // tuning key 42 (prototype): o_proj out of order behind the merge, which publishes per-head completion flags (fd_ws doubles as the flag words:
+      // key 22 and key 42 are not meant to be on together)
+      ao_oproj = g_ao_oproj && n2 && !f8 && !masked && ctx->fd_ws && Lmax <= 4096 && H == 3584 && qd == 3584 && c.t_heads <= 64 && !ctx->graph_on;
+      if (ao_oproj) { a.done_flags = (unsigned*)ctx->fd_ws; a.done_epoch = ++ctx->fd_epoch; a.done_mode = g_ao_oproj; }
+#endif
       TRY(launch_attn_decode(ctx->dt, a, s));
     }
     // batch 1, one GPU (round 3): o_proj without split-K writes x + attn itself (EPI_RESID, in place) and the post-attention RMSNorm runs
     // in the registers of the gate|up GEMV's waves (gemv.hip: norm_w): seven dependent launches per layer instead of eight
     if (fuse_ao) {
       // x + attn is already in place
+    } else if (ao_oproj) {
+      const GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
+      TRY(launch_gemv_wait(ctx->dt, g, (const unsigned*)ctx->fd_ws, ctx->fd_epoch, c.t_heads, ctx->fd_err, g_ao_oproj, s));
     } else if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
     } else if (nb2) {
