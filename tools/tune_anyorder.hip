@@ -46,6 +46,25 @@ __global__ __launch_bounds__(256) void k_read(const unsigned* buf, unsigned valu
   if (!ok) atomicAdd(stale, 1u);
 }
 
+__global__ void k_pub(unsigned* flag, unsigned epoch) {
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_poll(const unsigned* flag, unsigned epoch) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int i = 0; i < 2000000; ++i) {
+      const unsigned f = lane < 28 ? __hip_atomic_load(flag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      if (__all((int)(f - epoch) >= 0)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+__global__ void k_body(unsigned* sink) {
+  if (threadIdx.x == 0 && blockIdx.x == 0xffffff) sink[0] = 1u;
+}
+
 int main() {
   hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   unsigned long long* d; hipMalloc(&d, 16);
@@ -97,6 +116,30 @@ int main() {
     unsigned n; hipMemcpy(&n, stale, 4, hipMemcpyDeviceToHost);
     printf("visibility, %s stores / %s loads, reader launched %s: %u stale 16-byte reads of %d (%d rounds)\n", wt ? "write-through (sc0 sc1, drained)" : "plain",
            wt ? "bypassing (sc0 sc1)" : "plain", any ? "any-order" : "in-order ", n, rounds * nwg * 256, rounds);
+  }
+  // ---- 3. chain cost: [A (28 workgroups, publishes a flag) ; B (512 x 448 threads, polls the flag when launched any-order) ; C (4736 x 256 threads)] x 200,
+  //         all in-order against B any-order: what the packets around an out-of-order one cost
+  {
+    unsigned* flag; hipMalloc(&flag, 256); hipMemset(flag, 0, 256);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    unsigned epoch = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, s);
+        for (int i = 0; i < 200; ++i) {
+          ++epoch;
+          hipLaunchKernelGGL(k_pub, dim3(28), dim3(128), 0, s, flag, epoch);
+          if (mode == 0) hipLaunchKernelGGL(k_poll, dim3(512), dim3(448), 0, s, (const unsigned*)flag, epoch);
+          else hipExtLaunchKernelGGL(k_poll, dim3(512), dim3(448), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, (const unsigned*)flag, epoch);
+          if (mode == 2) hipExtLaunchKernelGGL(k_body, dim3(4736), dim3(256), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, flag + 32);
+          else hipLaunchKernelGGL(k_body, dim3(4736), dim3(256), 0, s, flag + 32);
+        }
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep) printf("chain A ; B ; C x 200: %s: %.2f us per chain\n", mode == 0 ? "all in-order              " : mode == 1 ? "B any-order (polls A's flag)" :
+               "B and C any-order (C unordered: price only)", ms * 1000.0 / 200);
+      }
+    }
   }
   printf("hipGetLastError: %s\n", hipGetErrorString(hipGetLastError()));
   return 0;
