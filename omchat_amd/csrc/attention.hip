@@ -1099,7 +1099,8 @@ __global__ __launch_bounds__(64) void attn_decode_dma_kernel(AttnP p) {
 template <typename T>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int nsplit, int q_heads, const int* kv_len, int L, float c,
                                                          T* O, int64_t o_sb, int64_t o_sh, int pack_nb, int split_keys,
-                                                         unsigned* done_flags = nullptr, unsigned done_epoch = 0, int done_mode = 0) {
+                                                         unsigned* done_flags = nullptr, unsigned done_epoch = 0, int done_mode = 0,
+                                                         unsigned long long* done_dbg = nullptr) {
   __shared__ float fw[1024];
   __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (d == 0) __hip_atomic_store(done_flags + h, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done_dbg && d == 0) atomicMax(done_dbg, wall_clock64());
       return;
     }
 #endif
@@ -1153,6 +1155,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
       __syncthreads();
       if (d == 0) __hip_atomic_store(done_flags + h, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (done_dbg && d == 0) atomicMax(done_dbg, wall_clock64());
 #endif
     return;
   }
@@ -1532,7 +1535,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
       if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
       else hipLaunchKernelGGL((attn_merge_mid_kernel<f16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode);
+    else hipLaunchKernelGGL(attn_merge_kernel<f16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (f16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode, a.done_dbg);
   } else if (dtype == OMCHAT_BF16) {
     if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true, true>), grid, dim3(64), 0, s, p);
     else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
@@ -1550,7 +1553,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
       if (g_merge_dg >= 1) hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 4>), dim3(a.q_heads, a.batch, 4), dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
       else hipLaunchKernelGGL((attn_merge_mid_kernel<bf16, 8, 1>), mgrid, dim3(1024), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys);
     }
-    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode);
+    else hipLaunchKernelGGL(attn_merge_kernel<bf16>, mgrid, dim3(128), 0, s, a.ws, nsplit, a.q_heads, a.kv_len, a.L, p.c, (bf16*)a.O, a.o_sb, a.o_sh, a.o_pack_nb, split_keys, a.done_flags, a.done_epoch, a.done_mode, a.done_dbg);
   } else { omchat_set_error("launch_attn_decode: bad dtype"); return 1; }
   OM_LAUNCH_CHECK();
   return 0;

@@ -23,7 +23,16 @@ struct GemvP {
   const void* norm_w; float norm_eps;      // whole-row batch-1 form: X is the RAW hidden row, normalised in registers (gemv_rows_norm_kernel)
   unsigned* dyn;                           // gemv_rows_norm_dyn_kernel: 8 pool counters + 1 completion counter (one 256-byte line each), zero before the first launch
   void* y_pack;                            // gemv_xs_kernel<EPI_RESID>: packed copy of the result rows
+  unsigned long long* dbg;                 // experiments build: clock stamps (measurement of the out-of-order prototype), else null
 };
+// stamps: [0] merge end, [1] o_proj first start (stored inverted: max of ~t), [2] o_proj flags seen, [3] o_proj end, [4] gate|up first start (inverted), [5] gate|up end
+#if OMCHAT_EXPERIMENTS
+#define OM_DBG_MIN(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), ~wall_clock64()); } while (0)
+#define OM_DBG_MAX(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), wall_clock64()); } while (0)
+#else
+#define OM_DBG_MIN(slot, cond) do { } while (0)
+#define OM_DBG_MAX(slot, cond) do { } while (0)
+#endif
 
 template <typename T, int NTILE, int N, int WAVES, bool NTL, int NB>
 __device__ __forceinline__ void gemv_group(f32x4 (&acc)[NTILE][NB], const T* const (&wrow)[NTILE], const T* const (&xrow)[NB], int k0,
@@ -658,6 +667,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
   constexpr int OUT = RR;                                 // outputs per group
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* W = (const T*)p.W;
+  if constexpr (EPI == EPI_RESID && WAVES == 7) OM_DBG_MIN(1, blockIdx.x < 8);
   // K slice of this workgroup row (blockIdx.y): chunk range [c_lo, c_hi)
   const int nch_all = (p.K + 511) / 512;
   const int c_lo = (int)(((long)nch_all * blockIdx.y) / p.ksplit), c_hi = (int)(((long)nch_all * (blockIdx.y + 1)) / p.ksplit);
@@ -722,6 +732,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_kernel(GemvP p) {
       }
     }
   }
+  if constexpr (EPI == EPI_RESID && WAVES == 7) OM_DBG_MAX(3, (blockIdx.x & 7) == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -743,6 +754,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   const int g = blockIdx.x * WAVES + wave;
+  if constexpr (EPI == EPI_SWIGLU) OM_DBG_MIN(4, blockIdx.x < 8);
   // ---- 0. x and the norm weights are requested IN FRONT of the weight rows (round 4).  Vector memory returns in order: behind the weight
   // loads the 2 x 7 KB of x / norm weights (L2 hits) could not be used before the wave's whole first batch of weights had come in from HBM, and
   // the norm -- two barriers and two LDS round trips -- then ran with nothing left in flight behind it.  In front, the norm is done while the
@@ -889,6 +901,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
       }
     }
   }
+  if constexpr (EPI == EPI_SWIGLU) OM_DBG_MAX(5, blockIdx.x + 64 >= gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1491,7 +1504,7 @@ template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
   const int ks = a.ksplit > 1 ? a.ksplit : 1;
   GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, a.out_f32, ks, a.w_scale, a.y_packed, a.norm_w, a.norm_eps,
-          (unsigned*)a.dyn_ctr, a.y_pack};
+          (unsigned*)a.dyn_ctr, a.y_pack, a.dbg};
   if (a.norm_w && a.x_packed && !(a.w_packed && ks == 1 && (a.K >> 6) == 56 && a.epi == EPI_SWIGLU && a.N % 32 == 0 && !g_gemv_no_xs)) {
     omchat_set_error("launch_gemv: the in-register RMSNorm on packed x exists for the x-stationary gate|up form only (packed W, K = 3584, no split-K)");
     return 1;
@@ -1728,6 +1741,7 @@ __global__ __launch_bounds__(448) void gemv_rows_wait_kernel(GemvP p, const unsi
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;
   const bool valid = n < p.N;
   const int row = valid ? n : p.N - 1;
+  OM_DBG_MIN(1, blockIdx.x < 8);
   rw_u32x4 w[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) w[c] = __builtin_nontemporal_load(reinterpret_cast<const rw_u32x4*>((const T*)p.W + (size_t)row * p.ldw + c * 512 + lane * 8));
@@ -1743,6 +1757,7 @@ __global__ __launch_bounds__(448) void gemv_rows_wait_kernel(GemvP p, const unsi
       if ((++spins & 255u) == 0u && wall_clock64() - t0 > 200000000ull) { if (lane == 0) atomicOr(err, 4u); break; }      // 2 s of the 100 MHz clock
     }
   }
+  OM_DBG_MAX(2, blockIdx.x < 8);
   __syncthreads();
   rw_u32x4 xr[NCH];
   if (mode & 2) {
@@ -1761,11 +1776,12 @@ __global__ __launch_bounds__(448) void gemv_rows_wait_kernel(GemvP p, const unsi
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
   if (lane == 0 && valid) ((T*)p.Y)[n] = fromf<T>(e_res + rnd<T>(a));
+  OM_DBG_MAX(3, (blockIdx.x & 7) == 0);
 }
 
 template <typename T>
 static int launch_gemv_wait_t(const GemvArgs& a, const unsigned* flags, unsigned epoch, int nflags, unsigned* err, int mode, hipStream_t s) {
-  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, 0, 1, nullptr, 0, nullptr, 0.f, nullptr, nullptr};
+  GemvP p{a.X, a.W, a.Y, a.bias, a.resid, a.ldx, a.ldw, a.ldy, a.ldr, a.b, a.N, a.K, 0, 1, nullptr, 0, nullptr, 0.f, nullptr, nullptr, a.dbg};
   int wpw = cdiv(a.N, 2 * device_cus());
   wpw = wpw < 1 ? 1 : (wpw > 7 ? 7 : wpw);
   hipExtLaunchKernelGGL((gemv_rows_wait_kernel<T, 7>), dim3(cdiv(a.N, wpw)), dim3(64 * wpw), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, p, flags, epoch, nflags, err, mode);

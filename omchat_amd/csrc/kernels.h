@@ -91,6 +91,8 @@ struct GemvArgs {
   // batched x-stationary form, EPI_RESID (round 5): the result rows are ALSO written in the packed x layout here (same NB), un-normalised --
   // the consuming gate|up GEMV normalises them in registers (norm_w with x_packed)
   void* y_pack = nullptr;
+  // experiments build, measurement only: 8 x 64-bit clock stamps of this launch's layer (see model.hip dbg_stamps)
+  unsigned long long* dbg = nullptr;
 };
 // row-major [rows <= 32][K] -> packed x (tests, tools); row-major W [N][ldw] -> packed replica (N % 16 == 0)
 int launch_pack_x(int dtype, const void* X, int ldx, int b, int K, void* out, hipStream_t s);
@@ -200,6 +202,7 @@ struct AttnDecodeArgs {
   const unsigned char* key_mask; int64_t mask_sb;
   // experiments build (tuning key 42): the merge launch publishes done_flags[head] = done_epoch after an agent-scope release (batch 1, <= 64 splits only)
   unsigned* done_flags = nullptr; unsigned done_epoch = 0; int done_mode = 0;
+  unsigned long long* done_dbg = nullptr;      // experiments build, measurement only: clock stamp of the merge's end
 };
 // quantise rows [pos0, pos1) of every (sequence < b, kv head) of a 16-bit cache [b_cap, kv_heads, cap, 128] into the fp8 cache + scales
 // (pos1 = null-terminated per sequence: rows >= len[b] are skipped when len != null)

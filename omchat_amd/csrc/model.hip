@@ -169,6 +169,7 @@ struct omchat_ctx {
   // one-launch decoder layer (decode_layer.hip): granule buffers; shares the error word and the launch counter above
   void* dl_ws = nullptr;
   long n_layer_launches = 0;
+  unsigned long long* dbg_stamps = nullptr;      // experiments build: [layers][8] clock stamps of the last decode step (tuning key 42 bit 4)
   unsigned* dyn_ctr = nullptr;      // [layers][65 * 64] work counters of the dynamic gate|up GEMV (gemv_rows_norm_dyn_kernel), zero between launches
   int *d_pos = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_start = nullptr;
   bool left_padded = false;
@@ -406,6 +407,8 @@ int build(omchat_ctx* ctx) {
       OM_HIP(hipMemset(ctx->dl_ws, 0, lb));
       TRY(ctx->alloc((void**)&ctx->dyn_ctr, (size_t)c.t_layers * 65 * 64 * 4));
       OM_HIP(hipMemset(ctx->dyn_ctr, 0, (size_t)c.t_layers * 65 * 64 * 4));
+      TRY(ctx->alloc((void**)&ctx->dbg_stamps, (size_t)c.t_layers * 64));
+      OM_HIP(hipMemset(ctx->dbg_stamps, 0, (size_t)c.t_layers * 64));
     }
     TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
@@ -1209,6 +1212,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   const bool nb2 = OMCHAT_EXPERIMENTS && (g_norm_in_gemv & 4) && fused && wpk && ctx->tp_size == 1 && !f8 && (qd >> 6) == 56 && (H >> 6) == 56 && qd % 64 == 0 &&
                    H / 16 <= device_cus() && (2 * It) / 32 >= 4 * device_cus();
   if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
+#if OMCHAT_EXPERIMENTS
+  if ((g_ao_oproj & 16) && ctx->dbg_stamps) OM_HIP(hipMemsetAsync(ctx->dbg_stamps, 0, (size_t)c.t_layers * 64, s));      // measurement: the stamps of THIS step only
+#endif
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     static const omchat_ctx::DecLayer8 none8{};
@@ -1280,8 +1286,9 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
 #if OMCHAT_EXPERIMENTS
       // tuning key 42 (prototype): o_proj out of order behind the merge, which publishes per-head completion flags (fd_ws doubles as the flag words:
       // key 22 and key 42 are not meant to be on together)
-      ao_oproj = g_ao_oproj && n2 && !f8 && !masked && ctx->fd_ws && Lmax <= 4096 && H == 3584 && qd == 3584 && c.t_heads <= 64 && !ctx->graph_on;
+      ao_oproj = (g_ao_oproj & 1) && n2 && !f8 && !masked && ctx->fd_ws && Lmax <= 4096 && H == 3584 && qd == 3584 && c.t_heads <= 64 && !ctx->graph_on;
       if (ao_oproj) { a.done_flags = (unsigned*)ctx->fd_ws; a.done_epoch = ++ctx->fd_epoch; a.done_mode = g_ao_oproj; }
+      if ((g_ao_oproj & 16) && n2 && ctx->dbg_stamps) a.done_dbg = ctx->dbg_stamps + (size_t)i * 8;
 #endif
       TRY(launch_attn_decode(ctx->dt, a, s));
     }
@@ -1290,8 +1297,13 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (fuse_ao) {
       // x + attn is already in place
     } else if (ao_oproj) {
-      const GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
+      GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
+      if ((g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 8;
       TRY(launch_gemv_wait(ctx->dt, g, (const unsigned*)ctx->fd_ws, ctx->fd_epoch, c.t_heads, ctx->fd_err, g_ao_oproj, s));
+    } else if (n2 && OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps && !f8) {
+      GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
+      g.dbg = ctx->dbg_stamps + (size_t)i * 8;
+      TRY(launch_gemv(ctx->dt, g, s));
     } else if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
     } else if (nb2) {
@@ -1317,6 +1329,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       GemvArgs g = gemv_args(x, H, L.wgu, H, ctx->tw_act, It, 1, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, Q.wgu, Q.sgu, nullptr, false);
       g.norm_w = L.ln2; g.norm_eps = c.t_eps;
       if (ctx->dyn_ctr && !ctx->graph_on) g.dyn_ctr = ctx->dyn_ctr + (size_t)i * 65 * 64;
+      if (OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 8;
       TRY(launch_gemv(ctx->dt, g, s));
     } else if (nb2) {
       GemvArgs g = gemv_args(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, b, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, nullptr, nullptr, P.wgu, true);
@@ -1587,6 +1600,27 @@ extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* ti
     *timeout_bits = 0;
     if (ctx->fd_err) OM_HIP(hipMemcpy(timeout_bits, ctx->fd_err, 4, hipMemcpyDeviceToHost));
   }
+#if OMCHAT_EXPERIMENTS
+  if ((g_ao_oproj & 16) && ctx->dbg_stamps) {
+    // measurement of the out-of-order o_proj prototype: clock stamps (100 MHz) of the LAST decode step, averaged over the layers
+    const int nl = ctx->c.t_layers;
+    std::vector<unsigned long long> st((size_t)nl * 8);
+    OM_HIP(hipMemcpy(st.data(), ctx->dbg_stamps, (size_t)nl * 64, hipMemcpyDeviceToHost));
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    for (int i = 0; i < nl; ++i) {
+      const unsigned long long* t = &st[(size_t)i * 8];
+      if (!t[0] || !t[3] || !t[4] || !t[5]) continue;
+      const double merge_end = (double)t[0], o_start = (double)~t[1], o_seen = t[2] ? (double)t[2] : 0.0, o_end = (double)t[3], g_start = (double)~t[4], g_end = (double)t[5];
+      a[0] += (o_start - merge_end) / 100.0; a[1] += o_seen ? (o_seen - merge_end) / 100.0 : 0.0; a[2] += (o_end - merge_end) / 100.0;
+      a[3] += (g_start - o_end) / 100.0; a[4] += (g_end - g_start) / 100.0; a[5] += (g_end - merge_end) / 100.0;
+      ++n;
+    }
+    if (n) fprintf(stderr, "[omchat dbg] key 42 = %d, last decode step, mean over %d layers (us): o_proj first start - merge end %.2f | flags seen - merge end %.2f | "
+                   "o_proj end - merge end %.2f | gate-up first start - o_proj end %.2f | gate-up end - start %.2f | gate-up end - merge end %.2f\n",
+                   g_ao_oproj, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n);
+  }
+#endif
   return 0;
 }
 

@@ -1,0 +1,28 @@
+"""Experiment (needs the -DOMCHAT_EXPERIMENTS=1 library via OMCHAT_LIB): in-kernel clock stamps of merge -> o_proj -> gate|up in a batch-1 decode step, ordered launches
+against the out-of-order o_proj prototype (tuning key 42; bit 4 = collect stamps).  The library prints the intervals of the last step when fused_status() is called."""
+import os, sys
+os.environ["OMCHAT_ALLOW_TUNING"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from omchat_amd import _lib
+from omchat_amd.config import omchat13b
+from omchat_amd.engine import Engine
+
+lib = _lib.lib()
+assert lib.omchat_has_experiments(), "needs OMCHAT_LIB=<experiments twin>"
+cfg = omchat13b()
+S, STEPS = 3584, 24
+for val in (16, 16 + 7, 16, 16 + 7, 16 + 1):
+    lib.omchat_op_set_tuning(42, val)
+    e = Engine(cfg, dtype="bf16", max_seq=S + STEPS + 8, max_batch=1, max_tiles=1, vision=False)
+    e.fill_synthetic(0)
+    x = (torch.randn(1, S, cfg.text["hidden_size"], generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16).cuda()
+    logits, _ = e.prefill(x, [S]); torch.cuda.synchronize()
+    tok = int(torch.argmax(logits[0]))
+    for _ in range(STEPS):
+        nxt, _ = e.decode_step(torch.tensor([tok])); tok = int(nxt[0])
+    torch.cuda.synchronize()
+    sys.stderr.flush()
+    e.fused_status()
+    e.close()
+    lib.omchat_op_set_tuning(42, 0)
