@@ -649,6 +649,9 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
   const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+#if OMCHAT_EXPERIMENTS
+  if (p.dbg && split < 8 && kvh == 0 && lane == 0) atomicMax(p.dbg + 10, ~wall_clock64());      // measurement: first start (stored inverted)
+#endif
   float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
   if (split * KV_TILE >= kv_len) {            // empty split (uniform): neutral partial
     if (fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
@@ -662,6 +665,9 @@ __global__ __launch_bounds__(64, 2) void attn_decode_kernel(AttnP p) {
     for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
     if (fg == 0) { wsb[128] = mx; wsb[129] = l; }
   }
+#if OMCHAT_EXPERIMENTS
+  if (p.dbg && kvh == 0 && lane == 0) atomicMax(p.dbg + 11, wall_clock64());
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1104,6 +1110,9 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float* ws, int ns
   __shared__ float fw[1024];
   __shared__ float red[4];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+#if OMCHAT_EXPERIMENTS
+  if (done_dbg && d == 0 && h < 8) atomicMax(done_dbg + 12, ~wall_clock64());      // measurement: first start (stored inverted)
+#endif
   const int len = kv_len ? kv_len[b] : L;
   int ns = (len + split_keys - 1) / split_keys;
   ns = ns < nsplit ? ns : nsplit;
@@ -1506,6 +1515,9 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
           a.kv_len, nullptr, a.q_heads, a.kv_heads, 1, a.L, 0, 0, nsplit, a.scale * 1.4426950408889634f, a.ws,
           a.rope, a.pos, a.k_new, a.v_new, a.new_sb, (void*)a.K, (void*)a.V, a.rope_max, a.k_scale, a.v_scale, a.scale_sb, a.scale_sh, tpw,
           a.key_mask, a.mask_sb};
+#if OMCHAT_EXPERIMENTS
+  p.dbg = a.done_dbg;
+#endif
   OM_CHECK(!a.key_mask || (((kv8 && !a.rope) || (!kv8 && a.rope && a.pos)) && !a.kv_len && a.mask_sb % 64 == 0 && a.mask_sb >= a.L),
            "masked decode: fused RoPE with explicit positions (16-bit cache) or rows appended beforehand (e4m3 cache), uniform length, mask rows padded to a multiple of 64");
   OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");

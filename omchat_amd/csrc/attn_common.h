@@ -28,6 +28,9 @@ struct AttnP {
   // key_mask[b * mask_sb + j] != 0 (rows zero-padded to mask_sb, a multiple of 64), and the new token is rotated to pos[b] -- not to the
   // slot it is appended at (kv_len - 1)
   const unsigned char* key_mask; int64_t mask_sb;
+#if OMCHAT_EXPERIMENTS
+  unsigned long long* dbg;      // measurement only: clock stamps of the layer (model.hip dbg_stamps), else null
+#endif
 };
 
 // 8 e4m3 bytes -> 8 T (exact widening)

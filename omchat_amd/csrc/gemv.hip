@@ -25,7 +25,8 @@ struct GemvP {
   void* y_pack;                            // gemv_xs_kernel<EPI_RESID>: packed copy of the result rows
   unsigned long long* dbg;                 // experiments build: clock stamps (measurement of the out-of-order prototype), else null
 };
-// stamps: [0] merge end, [1] o_proj first start (stored inverted: max of ~t), [2] o_proj flags seen, [3] o_proj end, [4] gate|up first start (inverted), [5] gate|up end
+// stamps: [0] merge end, [1] o_proj first start (stored inverted: max of ~t), [2] o_proj flags seen, [3] o_proj end, [4] gate|up first start (inverted), [5] gate|up end,
+// [6] down_proj first start (inverted), [7] down_proj end, [8] qkv first start (inverted), [9] qkv end, [10] attention first start (inverted), [11] attention end, [12] merge first start (inverted)
 #if OMCHAT_EXPERIMENTS
 #define OM_DBG_MIN(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), ~wall_clock64()); } while (0)
 #define OM_DBG_MAX(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), wall_clock64()); } while (0)
@@ -755,6 +756,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   const int g = blockIdx.x * WAVES + wave;
   if constexpr (EPI == EPI_SWIGLU) OM_DBG_MIN(4, blockIdx.x < 8);
+  if constexpr (EPI == EPI_NONE) OM_DBG_MIN(8, blockIdx.x < 8);
   // ---- 0. x and the norm weights are requested IN FRONT of the weight rows (round 4).  Vector memory returns in order: behind the weight
   // loads the 2 x 7 KB of x / norm weights (L2 hits) could not be used before the wave's whole first batch of weights had come in from HBM, and
   // the norm -- two barriers and two LDS round trips -- then ran with nothing left in flight behind it.  In front, the norm is done while the
@@ -902,6 +904,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
     }
   }
   if constexpr (EPI == EPI_SWIGLU) OM_DBG_MAX(5, blockIdx.x + 64 >= gridDim.x);
+  if constexpr (EPI == EPI_NONE) OM_DBG_MAX(9, (blockIdx.x & 7) == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1223,6 +1226,7 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
   const int n = blockIdx.x * rows_per_wg + wave;
   const bool valid = n < p.N;
   const int row = valid ? n : p.N - 1;
+  OM_DBG_MIN(6, blockIdx.x < 8);
   typedef typename std::conditional<F8, rw_u32x2, rw_u32x4>::type wreg_t;
   auto load_w = [&](wreg_t (&w)[8], int pass) {
 #pragma unroll
@@ -1281,6 +1285,7 @@ __global__ __launch_bounds__(512) void gemv_rows_longk_kernel(GemvP p, int rows_
     const float y = rnd<T>(a + e_bias);
     ((T*)p.Y)[n] = fromf<T>(e_res + y);
   }
+  OM_DBG_MAX(7, (blockIdx.x & 7) == 0);
 }
 
 #if OMCHAT_EXPERIMENTS

@@ -1,5 +1,6 @@
-"""Experiment (needs the -DOMCHAT_EXPERIMENTS=1 library via OMCHAT_LIB): in-kernel clock stamps of merge -> o_proj -> gate|up in a batch-1 decode step, ordered launches
-against the out-of-order o_proj prototype (tuning key 42; bit 4 = collect stamps).  The library prints the intervals of the last step when fused_status() is called."""
+"""Experiment (needs the -DOMCHAT_EXPERIMENTS=1 library via OMCHAT_LIB): in-kernel clock stamps of the six launches of a batch-1 decode layer (first wave's start,
+last wave's end), ordered launches (key 42 = 16) and with the out-of-order o_proj prototype (16 + 7).  The library prints kernel times and boundaries of the last step
+when fused_status() is called."""
 import os, sys
 os.environ["OMCHAT_ALLOW_TUNING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,7 @@ lib = _lib.lib()
 assert lib.omchat_has_experiments(), "needs OMCHAT_LIB=<experiments twin>"
 cfg = omchat13b()
 S, STEPS = 3584, 24
-for val in (16, 16 + 7, 16, 16 + 7, 16 + 1):
+for val in (16, 16, 16 + 7, 16):
     lib.omchat_op_set_tuning(42, val)
     e = Engine(cfg, dtype="bf16", max_seq=S + STEPS + 8, max_batch=1, max_tiles=1, vision=False)
     e.fill_synthetic(0)
