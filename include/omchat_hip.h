@@ -266,9 +266,11 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * no barrier; same bits, measured no faster -- 0 (default) = one workgroup per row;
  * key 41 (experiments build, TIMING PROBE: results are INVALID under it): 1 = every launch goes out with hipExtAnyOrderLaunch (consumers may overtake
  * producers): prices the launch boundaries of a step;
+ * key 28 (experiments build): < 256: workgroups moved from every odd XCD's share of the batch-1 gate|up launch to every even XCD's (contiguous pair ranges per XCD; same bits;
+ * -0.6 % of the step at 24); >= 256: eight nibbles of per-XCD share deltas of the loop form (round 4);
  * key 42 (experiments build, prototype): bit 0 = the batch-1 o_proj GEMV is launched out of order behind the split-KV merge and waits on its per-head completion
  * flags (gemv_rows_wait_kernel; bit-identical results); bit 1 = cache-bypassing loads of the row instead of an agent-scope acquire, bit 2 = write-through store
- * in the merge instead of a release, bit 3 = slower poll; measured not faster (7: 2.618 against 2.608 ms per token) */
+ * in the merge instead of a release, bit 3 = slower poll, bit 4 = collect in-kernel clock stamps of the six launches of a layer (printed by omchat_fused_status); measured not faster (7: 2.618 against 2.608 ms per token) */
 /* batch-1 skinny GEMM with the RMSNorm that precedes it computed in the registers of every wave: y = epi(W RMSNorm(x; norm_w, eps)),
  * x the raw hidden row [K], K <= 4096, epi NONE / SWIGLU (transformers modeling_qwen2.py:247-252 + :46-48; the decode step uses it for
  * post_attention_layernorm + gate|up) */

@@ -24,9 +24,12 @@ struct GemvP {
   unsigned* dyn;                           // gemv_rows_norm_dyn_kernel: 8 pool counters + 1 completion counter (one 256-byte line each), zero before the first launch
   void* y_pack;                            // gemv_xs_kernel<EPI_RESID>: packed copy of the result rows
   unsigned long long* dbg;                 // experiments build: clock stamps (measurement of the out-of-order prototype), else null
+#if OMCHAT_EXPERIMENTS
+  int xskew;                               // tuning key 28 < 256 (experiment): workgroups moved from every odd XCD's share to every even XCD's (gate|up non-loop form)
+#endif
 };
 // stamps: [0] merge end, [1] o_proj first start (stored inverted: max of ~t), [2] o_proj flags seen, [3] o_proj end, [4] gate|up first start (inverted), [5] gate|up end,
-// [6] down_proj first start (inverted), [7] down_proj end, [8] qkv first start (inverted), [9] qkv end, [10] attention first start (inverted), [11] attention end, [12] merge first start (inverted)
+// [6] down_proj first start (inverted), [7] down_proj end, [8] qkv first start (inverted), [9] qkv end, [10] attention first start (inverted), [11] attention end, [12] merge first start (inverted), [16 + x] gate|up end on XCD x
 #if OMCHAT_EXPERIMENTS
 #define OM_DBG_MIN(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), ~wall_clock64()); } while (0)
 #define OM_DBG_MAX(slot, cond) do { if (p.dbg && (cond) && threadIdx.x == 0) atomicMax(p.dbg + (slot), wall_clock64()); } while (0)
@@ -754,7 +757,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
   __shared__ float red[WAVES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
-  const int g = blockIdx.x * WAVES + wave;
+  int g = blockIdx.x * WAVES + wave;
+#if OMCHAT_EXPERIMENTS
+  if constexpr (EPI == EPI_SWIGLU && RR == 1 && WAVES == 4) {
+    // experiment (tuning key 28): the odd XCDs end this launch 2-3 us after the even ones (clock stamps), and workgroup ids go
+    // round the XCDs -- so XCD x gets a contiguous range of pairs, p.xskew workgroups longer on even x and as much shorter on odd x
+    if (p.xskew) {
+      const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int base = ((n_out + 3) / 4) / 8;
+      const int n_x = base + ((x & 1) ? -p.xskew : p.xskew);
+      if (j >= n_x) return;
+      g = (x * base + ((x & 1) ? p.xskew : 0) + j) * 4 + wave;
+    }
+  }
+#endif
   if constexpr (EPI == EPI_SWIGLU) OM_DBG_MIN(4, blockIdx.x < 8);
   if constexpr (EPI == EPI_NONE) OM_DBG_MIN(8, blockIdx.x < 8);
   // ---- 0. x and the norm weights are requested IN FRONT of the weight rows (round 4).  Vector memory returns in order: behind the weight
@@ -903,7 +919,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_rows_norm_kernel(GemvP p) {
       }
     }
   }
-  if constexpr (EPI == EPI_SWIGLU) OM_DBG_MAX(5, blockIdx.x + 64 >= gridDim.x);
+  if constexpr (EPI == EPI_SWIGLU) { OM_DBG_MAX(5, blockIdx.x + 64 >= gridDim.x); OM_DBG_MAX(16 + (blockIdx.x & 7), blockIdx.x + 512 >= gridDim.x); }      // + the end per XCD
   if constexpr (EPI == EPI_NONE) OM_DBG_MAX(9, (blockIdx.x & 7) == 0);
 }
 
@@ -924,6 +940,7 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int p
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_out = EPI == EPI_SWIGLU ? p.N / 2 : p.N;
   int o0 = blockIdx.x * per_wg, o1 = o0 + per_wg < n_out ? o0 + per_wg : n_out;
+  if constexpr (EPI == EPI_SWIGLU) OM_DBG_MIN(4, blockIdx.x < 8);
   if (skew) {      // experiment (tuning key 28): shares by blockIdx % 8, per_wg + d_l with d_l = nibble l of skew - 8 (the deltas sum to 0)
     const int l = blockIdx.x & 7;
     int pre = 0;
@@ -1033,6 +1050,10 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int p
       finish(wc, u + 8);
       if (u + 20 < o1) load_w(wc, u + 20);
     }
+  }
+  if constexpr (EPI == EPI_SWIGLU) {      // measurement (experiments build): start / end of the launch and the end per XCD (workgroup ids go round the 8 XCDs)
+    OM_DBG_MAX(5, (blockIdx.x & 7) == 0);
+    OM_DBG_MAX(16 + (blockIdx.x & 7), true);
   }
 }
 
@@ -1418,7 +1439,7 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
 #endif
     if (want && n_out >= 8 * n_cu) {
       const int per = cdiv(n_out, 2 * n_cu);
-      const unsigned skew = (g_gemv_skew && n_out == per * 2 * n_cu && (2 * n_cu) % 8 == 0) ? g_gemv_skew : 0u;
+      const unsigned skew = (g_gemv_skew >= 256u && n_out == per * 2 * n_cu && (2 * n_cu) % 8 == 0) ? g_gemv_skew : 0u;
       hipLaunchKernelGGL((gemv_rows_norm_loop_kernel<T, EPI, NCH, F8>), dim3(cdiv(n_out, per)), dim3(256), 0, s, p, per, skew);
       return;
     }
@@ -1434,6 +1455,16 @@ void launch_rows_norm_n(const GemvP& p, hipStream_t s) {
   }
   // (four waves per workgroup: 8 / 16 waves -- fewer repeats of the norm -- measured 2.633 / 2.646 against 2.599 ms per token; down_proj's long-K form
   // with fewer rows per workgroup 2.615-2.765: each workgroup stages the 37 KB x for itself; lm_head with 2 / 1 rows per wave 2.591 against 2.597: noise)
+#if OMCHAT_EXPERIMENTS
+  if constexpr (EPI == EPI_SWIGLU && RR == 1) {
+    const int nwg = cdiv(n_out, 4), xs = (int)(g_gemv_skew < 256u ? g_gemv_skew : 0u);
+    if (xs > 0 && nwg % 8 == 0 && n_out % 4 == 0 && xs < nwg / 8) {
+      GemvP q = p; q.xskew = xs;
+      hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, RR, NCH, F8>), dim3(8 * (nwg / 8 + xs)), dim3(256), 0, s, q);
+      return;
+    }
+  }
+#endif
   hipLaunchKernelGGL((gemv_rows_norm_kernel<T, EPI, RR, NCH, F8>), dim3(cdiv(cdiv(n_out, RR), 4)), dim3(256), 0, s, p);
 }
 template <typename T, int EPI, int RR, bool F8>

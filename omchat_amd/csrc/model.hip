@@ -407,8 +407,8 @@ int build(omchat_ctx* ctx) {
       OM_HIP(hipMemset(ctx->dl_ws, 0, lb));
       TRY(ctx->alloc((void**)&ctx->dyn_ctr, (size_t)c.t_layers * 65 * 64 * 4));
       OM_HIP(hipMemset(ctx->dyn_ctr, 0, (size_t)c.t_layers * 65 * 64 * 4));
-      TRY(ctx->alloc((void**)&ctx->dbg_stamps, (size_t)c.t_layers * 128));
-      OM_HIP(hipMemset(ctx->dbg_stamps, 0, (size_t)c.t_layers * 128));
+      TRY(ctx->alloc((void**)&ctx->dbg_stamps, (size_t)c.t_layers * 256));
+      OM_HIP(hipMemset(ctx->dbg_stamps, 0, (size_t)c.t_layers * 256));
     }
     TRY(ctx->alloc(&ctx->arg_scratch, argmax_scratch_bytes(c.max_batch)));
     TRY(ctx->alloc((void**)&ctx->tp_table, (size_t)ctx->tp_size * c.max_batch * 2 * 4));
@@ -1213,7 +1213,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
                    H / 16 <= device_cus() && (2 * It) / 32 >= 4 * device_cus();
   if (fused && !n1) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->dl[0].ln1, ctx->tw_xn, H, b, H, c.t_eps, s, pk));
 #if OMCHAT_EXPERIMENTS
-  if ((g_ao_oproj & 16) && ctx->dbg_stamps) OM_HIP(hipMemsetAsync(ctx->dbg_stamps, 0, (size_t)c.t_layers * 128, s));      // measurement: the stamps of THIS step only
+  if ((g_ao_oproj & 16) && ctx->dbg_stamps) OM_HIP(hipMemsetAsync(ctx->dbg_stamps, 0, (size_t)c.t_layers * 256, s));      // measurement: the stamps of THIS step only
 #endif
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
@@ -1241,7 +1241,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (n1) {
       GemvArgs g = gemv_args(x, H, L.wqkv, H, ctx->tw_qkv, qkvd, 1, qkvd, L.bqkv, nullptr, EPI_NONE, 0, Q.wqkv, Q.sqkv, nullptr, false);
       g.norm_w = L.ln1; g.norm_eps = c.t_eps;
-      if (OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 16;
+      if (OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 32;
       TRY(launch_gemv(ctx->dt, g, s));
     } else {
       TRY(gemv(ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, qkvd, L.bqkv, nullptr, EPI_NONE, Q.wqkv, Q.sqkv, P.wqkv));
@@ -1289,7 +1289,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       // key 22 and key 42 are not meant to be on together)
       ao_oproj = (g_ao_oproj & 1) && n2 && !f8 && !masked && ctx->fd_ws && Lmax <= 4096 && H == 3584 && qd == 3584 && c.t_heads <= 64 && !ctx->graph_on;
       if (ao_oproj) { a.done_flags = (unsigned*)ctx->fd_ws; a.done_epoch = ++ctx->fd_epoch; a.done_mode = g_ao_oproj; }
-      if ((g_ao_oproj & 16) && n2 && ctx->dbg_stamps) a.done_dbg = ctx->dbg_stamps + (size_t)i * 16;
+      if ((g_ao_oproj & 16) && n2 && ctx->dbg_stamps) a.done_dbg = ctx->dbg_stamps + (size_t)i * 32;
 #endif
       TRY(launch_attn_decode(ctx->dt, a, s));
     }
@@ -1299,11 +1299,11 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       // x + attn is already in place
     } else if (ao_oproj) {
       GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
-      if ((g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 16;
+      if ((g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 32;
       TRY(launch_gemv_wait(ctx->dt, g, (const unsigned*)ctx->fd_ws, ctx->fd_epoch, c.t_heads, ctx->fd_err, g_ao_oproj, s));
     } else if (n2 && OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps && !f8) {
       GemvArgs g = gemv_args(ctx->tw_ao, qd, L.wo, qd, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
-      g.dbg = ctx->dbg_stamps + (size_t)i * 16;
+      g.dbg = ctx->dbg_stamps + (size_t)i * 32;
       TRY(launch_gemv(ctx->dt, g, s));
     } else if (n2) {
       TRY(gemv(ctx->tw_ao, qd, L.wo, qd, x, H, H, nullptr, x, EPI_RESID, Q.wo, Q.so));
@@ -1330,7 +1330,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       GemvArgs g = gemv_args(x, H, L.wgu, H, ctx->tw_act, It, 1, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, Q.wgu, Q.sgu, nullptr, false);
       g.norm_w = L.ln2; g.norm_eps = c.t_eps;
       if (ctx->dyn_ctr && !ctx->graph_on) g.dyn_ctr = ctx->dyn_ctr + (size_t)i * 65 * 64;
-      if (OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 16;
+      if (OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps) g.dbg = ctx->dbg_stamps + (size_t)i * 32;
       TRY(launch_gemv(ctx->dt, g, s));
     } else if (nb2) {
       GemvArgs g = gemv_args(ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, b, 2 * It, nullptr, nullptr, EPI_SWIGLU, 0, nullptr, nullptr, P.wgu, true);
@@ -1342,7 +1342,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
     if (mark) ctx->prof_mark(OMCHAT_PROF_DECODE_GATEUP, s);
     if (n1 && OMCHAT_EXPERIMENTS && (g_ao_oproj & 16) && ctx->dbg_stamps && !f8) {
       GemvArgs g = gemv_args(ctx->tw_act, It, L.wd, It, x, H, 1, H, nullptr, x, EPI_RESID, 0, nullptr, nullptr, nullptr, false);
-      g.dbg = ctx->dbg_stamps + (size_t)i * 16;
+      g.dbg = ctx->dbg_stamps + (size_t)i * 32;
       TRY(launch_gemv(ctx->dt, g, s));
     } else if (n1) {
       TRY(gemv(ctx->tw_act, It, L.wd, It, x, H, H, nullptr, x, EPI_RESID, Q.wd, Q.sd));
@@ -1610,15 +1610,15 @@ extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* ti
     // measurement: clock stamps (100 MHz) of the LAST decode step, averaged over the layers: every kernel of the six-launch layer from its first wave's
     // start to its last wave's end, and the boundary in front of it (first start - the previous kernel's end)
     const int nl = ctx->c.t_layers;
-    std::vector<unsigned long long> st((size_t)nl * 16);
-    OM_HIP(hipMemcpy(st.data(), ctx->dbg_stamps, (size_t)nl * 128, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> st((size_t)nl * 32);
+    OM_HIP(hipMemcpy(st.data(), ctx->dbg_stamps, (size_t)nl * 256, hipMemcpyDeviceToHost));
     // order in the layer: qkv (8, 9), attention (10, 11), merge (12, 0), o_proj (1, 3), gate|up (4, 5), down_proj (6, 7)
     static const int S0[6] = {8, 10, 12, 1, 4, 6}, S1[6] = {9, 11, 0, 3, 5, 7};
     static const char* NM[6] = {"qkv", "attention", "merge", "o_proj", "gate|up", "down_proj"};
-    double dur[6] = {0, 0, 0, 0, 0, 0}, gap[6] = {0, 0, 0, 0, 0, 0}, seen = 0;
-    int n = 0, ngap0 = 0;
+    double dur[6] = {0, 0, 0, 0, 0, 0}, gap[6] = {0, 0, 0, 0, 0, 0}, seen = 0, xcd_end[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xcd_raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n = 0, ngap0 = 0, nx = 0, xcd_slowest[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < nl; ++i) {
-      const unsigned long long* t = &st[(size_t)i * 16];
+      const unsigned long long* t = &st[(size_t)i * 32];
       bool ok = true;
       for (int k = 0; k < 6; ++k) ok = ok && t[S0[k]] && t[S1[k]];
       if (!ok) continue;
@@ -1626,8 +1626,18 @@ extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* ti
         dur[k] += ((double)t[S1[k]] - (double)~t[S0[k]]) / 100.0;
         if (k > 0) gap[k] += ((double)~t[S0[k]] - (double)t[S1[k - 1]]) / 100.0;
       }
-      if (i > 0 && st[(size_t)(i - 1) * 16 + 7]) { gap[0] += ((double)~t[8] - (double)st[(size_t)(i - 1) * 16 + 7]) / 100.0; ++ngap0; }
+      if (i > 0 && st[(size_t)(i - 1) * 32 + 7]) { gap[0] += ((double)~t[8] - (double)st[(size_t)(i - 1) * 32 + 7]) / 100.0; ++ngap0; }
       if (t[2]) seen += ((double)t[2] - (double)t[0]) / 100.0;
+      {      // gate|up: the end per XCD relative to the launch's first start, sorted within the layer (which XCD is slow changes from launch to launch)
+        double e[8]; bool all = true;
+        for (int x = 0; x < 8; ++x) { all = all && t[16 + x]; e[x] = ((double)t[16 + x] - (double)~t[4]) / 100.0; }
+        if (all) {
+          int slow = 0;
+          for (int x = 0; x < 8; ++x) { xcd_raw[x] += e[x]; if (e[x] > e[slow]) slow = x; }
+          ++xcd_slowest[slow];
+          std::sort(e, e + 8); for (int x = 0; x < 8; ++x) xcd_end[x] += e[x]; ++nx;
+        }
+      }
       ++n;
     }
     if (n) {
@@ -1640,6 +1650,14 @@ extern "C" int omchat_fused_status(omchat_ctx* ctx, long* launches, unsigned* ti
       }
       fprintf(stderr, " kernels %.2f + boundaries %.2f = %.2f per layer", sd, sg, sd + sg);
       if (seen > 0) fprintf(stderr, "; flags seen %.2f after the merge's end", seen / n);
+      if (nx) {
+        fprintf(stderr, "; gate|up end per XCD after its first start, fastest to slowest:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f", xcd_end[x] / nx);
+        fprintf(stderr, "; by XCD id 0..7:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f", xcd_raw[x] / nx);
+        fprintf(stderr, "; layers in which XCD x ended last:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %d", xcd_slowest[x]);
+      }
       fprintf(stderr, "\n");
     }
   }

@@ -13,8 +13,10 @@ lib = _lib.lib()
 assert lib.omchat_has_experiments(), "needs OMCHAT_LIB=<experiments twin>"
 cfg = omchat13b()
 S, STEPS = 3584, 24
-for val in (16, 16, 16 + 7, 16):
-    lib.omchat_op_set_tuning(42, val)
+# (key 42 value, key 16 value): key 16 = 1 puts the gate|up launch back on the round-3 loop form (one resident round of 512 workgroups)
+for val, loop in ((16, 0), (16, 0), (16, 1)):
+    lib.omchat_op_set_tuning(42, val); lib.omchat_op_set_tuning(16, loop)
+    print(f'key 42 = {val}, key 16 = {loop}', file=sys.stderr, flush=True)
     e = Engine(cfg, dtype="bf16", max_seq=S + STEPS + 8, max_batch=1, max_tiles=1, vision=False)
     e.fill_synthetic(0)
     x = (torch.randn(1, S, cfg.text["hidden_size"], generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16).cuda()
@@ -26,4 +28,4 @@ for val in (16, 16, 16 + 7, 16):
     sys.stderr.flush()
     e.fused_status()
     e.close()
-    lib.omchat_op_set_tuning(42, 0)
+    lib.omchat_op_set_tuning(42, 0); lib.omchat_op_set_tuning(16, 0)
