@@ -141,6 +141,38 @@ def spawn_ranks(a):
     return max(abs(rc) for rc in rcs) if any(rcs) else (0 if line else 1)
 
 
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo restricted to this process's affinity mask; os.cpu_count() when that cannot be read"""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, val = [x.strip() for x in line.split(":", 1)]
+                cur[k] = val
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            seen.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+        return max(1, len(seen))
+    except (OSError, ValueError, AttributeError):
+        return os.cpu_count() or 1
+
+
+def oracle_full_depth_record():
+    """wall time per phase of the LIVE full-depth oracle pass on an MI355X box's host (tests/test_gpu_fulldepth.py with OMCHAT_LIVE_ORACLE=1,
+    committed under profiles/): the un-extrapolated CPU figure beside the bounded sample this run times"""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_oracle_cpu_phases.json")), key=_profile_key)
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    d["file"] = "profiles/" + os.path.basename(files[-1])
+    return d
+
+
 def cpu_baseline(cfg, S, gen, n_tiles):
     """The oracle (kind 'port') on this host's cores, bounded sample: 1 ViT layer on 1 tile (1025 tokens), 1 decoder
     layer prefill at S, 4 decode steps of 1 decoder layer at L = S, lm_head once; extrapolated to the whole step."""
@@ -148,18 +180,10 @@ def cpu_baseline(cfg, S, gen, n_tiles):
     import oracle
     from oracle.decoder import qwen2_layer, rope_cos_sin
     torch.manual_seed(0)
-    # thread count: the best of a few candidates on a decode-shaped matvec (all 256 SMT threads of the GPU host is pathological)
+    # threads = ALL PHYSICAL cores of this host, stated (rounds 1-5 took whatever count a matvec probe
+    # preferred -- 32 on one box, 128 on another: a 2.3 x spread of the baseline on the same code).  SMT siblings are left idle.
     ncpu = os.cpu_count() or 1
-    wprobe, xprobe = torch.randn(18944, 3584), torch.randn(1, 3584)
-    best = (1e9, 1)
-    for nthr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
-        torch.set_num_threads(nthr)
-        torch.nn.functional.linear(xprobe, wprobe)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            torch.nn.functional.linear(xprobe, wprobe)
-        best = min(best, (time.perf_counter() - t0, nthr))
-    cores = best[1]
+    cores = physical_cores()
     torch.set_num_threads(cores)
     v, t = cfg.vision, cfg.text
     C, I = v["hidden_size"], v["intermediate_size"]
@@ -198,7 +222,7 @@ def cpu_baseline(cfg, S, gen, n_tiles):
         t0 = time.perf_counter(); torch.nn.functional.linear(xe[:, :1], lm); t_lm = time.perf_counter() - t0
     step_s = (n_tiles * v["num_hidden_layers"] * t_vit + t["num_hidden_layers"] * t_pre
               + gen * (t["num_hidden_layers"] * t_dec + t_lm))
-    return {"value": gen / step_s, "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": gen / step_s, "unit": "tokens/s", "cores": cores, "logical_cpus": ncpu, "kind": "port", "full_depth_run": oracle_full_depth_record(),
             "sample": f"oracle fp32: 1 ViT layer x 1 tile ({t_vit:.2f}s), 1 decoder layer prefill S={S} ({t_pre:.2f}s), "
                       f"{nstep} decode steps x 1 layer at L={S} ({t_dec*1e3:.1f} ms each), lm_head ({t_lm*1e3:.0f} ms); "
                       f"extrapolated to {n_tiles} tiles x {v['num_hidden_layers']} + {t['num_hidden_layers']} layers + {gen} tokens "
@@ -593,15 +617,16 @@ def main():
                 kern = f"gemv_xs_kernel<EPI_SWIGLU, NB={2 if b > 16 else 1}> (decode gate|up weight stream, x-stationary, batch {b})"
             tr, src = (None, None)
             if plain and not f8:
-                if b == 1:      # the launch that streams gate|up in the default configuration first, then the forms behind tuning keys 16 / 14
-                    subs = (["gemv_rows_norm_kernelI", "Li4ELi1ELi7ELb0E"], ["gemv_rows_norm_loop_kernelI", "Li4ELi7ELb0E"], ["gemv_rows_norm_kernelI", "Li4ELi3ELi7ELb0E"],
-                            ["gemv_rows_kernelI", "Li4ELi4ELi4E"])
+                # symbol patterns: ONE table shared with tools/roofline_table.py and checked against the built library by a CPU test
+                from tools import kernel_roles
+                if b == 1:      # the launch that streams gate|up in the default configuration first, then the forms behind tuning keys 38 / 16 / 14
+                    subs = kernel_roles.decode_gate_up_b1()
                     for i, sub in enumerate(subs):
                         tr, src = pmc_traffic(sub, quiet=i + 1 < len(subs))
                         if tr is not None:
                             break
                 else:
-                    tr, src = pmc_traffic(["gemv_xs_kernelI", f"Li4ELi{2 if b > 16 else 1}E"], "pmc_traffic_configs2")
+                    tr, src = pmc_traffic(kernel_roles.decode_gate_up_batched(b)[0], "pmc_traffic_configs2")
             roof = {"bound": "hbm", "kernel": kern, "achieved": gu_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gu_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_us": avg_s * 1e6,
                     "launches": n, "bytes_per_launch": gu_bytes}
@@ -609,7 +634,8 @@ def main():
         if n:
             fl = 2.0 * b * S_ * (2 * ld["t_mlp"]) * t["hidden_size"]
             avg_s = ms / n / 1e3
-            tr, src = pmc_traffic(["gemm8_kernel", "Li4E"]) if (plain and b == 1 and not f8) else (None, None)
+            from tools import kernel_roles
+            tr, src = pmc_traffic(kernel_roles.prefill_gate_up()[0]) if (plain and b == 1 and not f8) else (None, None)
             peak = MFMA_PEAK_FP8_TFLOPS if f8 else MFMA_PEAK_TFLOPS      # e4m3 operands are priced against the fp8 peak
             roof_pre = {"bound": "mfma", "kernel": "gemm8_kernel<256x256,EPI_SWIGLU" + (",F8" if f8 else "") + "> (prefill gate|up)", "achieved": fl / avg_s / 1e12,
                         "peak": peak, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / peak, "traffic": tr,
@@ -797,7 +823,7 @@ def main():
     if world == 1 and not shard:
         n_f, bits = eng.fused_status()
         res["fused_decode"] = {"launches": n_f, "timeout_bits": bits,
-                               "note": "attention + merge + o_proj of a batch-1 decode step as one launch with in-launch hand-offs (csrc/fused_decode.hip)"}
+                               "note": "attention + merge + o_proj of a batch-1 decode step as one launch with in-launch hand-offs (csrc/experiments/fused_decode.hip)"}
         if bits:
             raise SystemExit(f"bench.py: a hand-off of the fused decode launch timed out (bits {bits:#x}): results invalid")
     rgb = pins = None

@@ -222,7 +222,9 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * through LDS instead of fragment-shaped straight to registers (same bits; measured neutral); key 13: 1 = multi-round 256x256 GEMMs
  * take the persistent one-workgroup-per-CU form that overlaps the next tile's prologue with the epilogue (same bits; measured neutral);
  * key 14: batch-1 decode, bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final RMSNorm inside the
- * qkv / lm_head GEMV with down_proj un-split (default 3; 0 = both residual + RMSNorm launches stay);
+ * qkv / lm_head GEMV with down_proj un-split (default 3; 0 = both residual + RMSNorm launches stay); bit 2 (experiments build only; off by
+ * default in BOTH builds, so the twin's batched decode is the product's) = batched steps (2 <= b <= 32) take the seven-launch layer -- o_proj
+ * un-split with the residual in its epilogue, the post-attention norm in the x-stationary gate|up GEMV -- measured slower: 4.57-4.87 vs 4.28 ms;
  * key 16: which of those norm-in-GEMV launches take the loop form (one resident round of workgroups, three register buffers per wave):
  * bit 0 = gate|up, bit 1 = qkv, bit 2 = e4m3 gate|up, bit 3 = lm_head (default 0 since round 5 -- key 38; every form gives the same bits);
  * key 17: 1 (default) = batch-1 o_proj / qkv launches whose rows deal evenly to two workgroups per CU use N / (2 CUs) waves per workgroup;
@@ -250,10 +252,11 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * epilogue (bias, layer scale, residual) is applied once to the sum, so TP = N differs from TP = 1 in fp32 summation order only (twice
  * the bytes on the links); 0 (default) = every rank applies the epilogue to its own partial and 16-bit results are summed.  TP = 8 f16
  * logit error against TP = 1: 4.97e-3 with, 5.32e-3 without (profiles/r04_w, r04_x));
- * key 34: launch shapes for the SHARD widths of a tensor-parallel rank's decode GEMVs (default 7): bit 0 = the x-stationary form, one tile per
+ * key 34: launch shapes for the SHARD widths of a tensor-parallel rank's decode GEMVs (default 15): bit 0 = the x-stationary form, one tile per
  * workgroup, for the short qkv shard of a batched step; bit 1 = split-K slices of >= 16 chunks and one chunk per wave per step for short-K
- * o_proj / down_proj shards; bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up shard (0 = the round-4 shapes; same sums up
- * to fp32 order where the slice count changes);
+ * o_proj / down_proj shards; bit 2 = one (gate, up) pair per wave for the short batch-1 gate|up shard; bit 3 = the x-stationary form, one
+ * (gate, up) tile per workgroup, for a batched gate|up shard of at most one tile per CU (0 = the round-4 shapes; same sums up to fp32 order
+ * where the slice count changes);
  * key 35 (experiments build): a rank context whose exchanges are no-ops takes the one-GPU launch structures on its shard widths (measurement);
  * key 36 (experiments build): 2 = the MHA prefill attention splits the keys between two wave groups of an eight-wave workgroup (measured slower);
  * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits);
@@ -266,7 +269,7 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * no barrier; same bits, measured no faster -- 0 (default) = one workgroup per row;
  * key 41 (experiments build, TIMING PROBE: results are INVALID under it): 1 = every launch goes out with hipExtAnyOrderLaunch (consumers may overtake
  * producers): prices the launch boundaries of a step;
- * key 28 (experiments build): < 256: workgroups moved from every odd XCD's share of the batch-1 gate|up launch to every even XCD's (contiguous pair ranges per XCD; same bits;
+ * key 28 (the static-skew form < 256 exists in the experiments build only: the product build IGNORES values below 256): < 256: workgroups moved from every odd XCD's share of the batch-1 gate|up launch to every even XCD's (contiguous pair ranges per XCD; same bits;
  * -0.6 % of the step at 24); >= 256: eight nibbles of per-XCD share deltas of the loop form (round 4);
  * key 42 (experiments build, prototype): bit 0 = the batch-1 o_proj GEMV is launched out of order behind the split-KV merge and waits on its per-head completion
  * flags (gemv_rows_wait_kernel; bit-identical results); bit 1 = cache-bypassing loads of the row instead of an agent-scope acquire, bit 2 = write-through store

@@ -6,13 +6,18 @@ SRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomchat_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip", "fused_decode.hip", "decode_layer.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+SOURCES = ["gemm.hip", "gemv.hip", "attention.hip", "elementwise.hip", "preproc.hip", "model.hip", "capi.hip", "comm.hip"]
+# measured-negative experiment kernels (one-launch decode layer, fused attention + o_proj): NOT part of the product library -- compiled only
+# into the `--twin ... -DOMCHAT_EXPERIMENTS=1` build that the experiment tests and tools load through OMCHAT_LIB
+EXPERIMENT_SOURCES = ["experiments/fused_decode.hip", "experiments/decode_layer.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I" + SRC]
 
 
 def _stamp(path):
     h = hashlib.sha1()
-    for f in sorted(os.listdir(SRC)) + ["../../include/omchat_hip.h"]:
+    files = [f for f in sorted(os.listdir(SRC)) if os.path.isfile(os.path.join(SRC, f))]
+    files += ["experiments/" + f for f in sorted(os.listdir(os.path.join(SRC, "experiments")))] + ["../../include/omchat_hip.h"]
+    for f in files:
         with open(os.path.join(SRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -30,8 +35,10 @@ def build(force=False, verbose=True, extra_flags=(), out_dir=None):
         return lib
     objs = []
 
+    sources = SOURCES + (EXPERIMENT_SOURCES if "-DOMCHAT_EXPERIMENTS=1" in extra_flags else [])
+
     def cc(src):
-        obj = os.path.join(libdir, src.replace(".hip", ".o"))
+        obj = os.path.join(libdir, os.path.basename(src).replace(".hip", ".o"))
         cmd = [HIPCC, *FLAGS, *extra_flags, "-c", os.path.join(SRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -39,7 +46,7 @@ def build(force=False, verbose=True, extra_flags=(), out_dir=None):
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
-        objs = list(ex.map(cc, SOURCES))
+        objs = list(ex.map(cc, sources))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib",
            "-Wl,-z,defs"]      # an undefined symbol fails the build here, not the first dlopen on the GPU box
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1323,16 +1323,13 @@ int g_attn_kg = 0;            // key 36: key groups of the MHA prefill kernel (a
 void attn_set_kg(int v) { g_attn_kg = v; }
 // attn2_kernel takes its K / V rings as dynamic LDS (128 KB with two key groups at head dim 128): the attribute is set once per instantiation
 template <typename K>
-static int launch_attn2(K kern, dim3 grid, int threads, int lds, hipStream_t s, const AttnP& p, bool* attr_done) {
-  if (!*attr_done) {
-    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    *attr_done = true;
-  }
+static int launch_attn2(K kern, dim3 grid, int threads, int lds, hipStream_t s, const AttnP& p, PerDeviceOnce* attr_done) {
+  if (attr_done->first()) OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
   return 0;
 }
 #define OM_LAUNCH_ATTN2(KERN, GRID, THREADS, LDS)                                     \
-  do { static bool done_ = false; const int rc_ = launch_attn2((KERN), (GRID), (THREADS), (LDS), s, p, &done_); if (rc_) return rc_; } while (0)
+  do { static PerDeviceOnce done_; const int rc_ = launch_attn2((KERN), (GRID), (THREADS), (LDS), s, p, &done_); if (rc_) return rc_; } while (0)
 int g_attn_mha_xcd = 1;       // key 33: 1 = MHA prefill attention launches keep the query blocks of a head on one XCD (one-dimensional grid)
 void attn_set_mha_xcd(int v) { g_attn_mha_xcd = v; }
 int g_attn_hsplit = -1;       // key 30: heaviest causal block ranks of a GQA prefill attention launch issued as two head halves (-1 = a quarter of the ranks when the launch is <= one workgroup per CU, 0 = off, n > 0 = n ranks whatever the size)

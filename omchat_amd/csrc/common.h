@@ -164,3 +164,16 @@ static inline int device_cus() {
   return n_cu;
 }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// hipFuncSetAttribute is a per-DEVICE setting: a per-call-site "done" flag is kept per device id, so a process that drives a second GPU (the
+// normal deployment is one process per GPU) still raises the dynamic-LDS limit there before its first launch.
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  bool first() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return false;
+    done |= bit;
+    return true;
+  }
+};

@@ -23,12 +23,14 @@
 namespace {
 
 int g_gemm_wide_store = 1;   // omchat_op_set_tuning key 37: 1 = 16-byte epilogue stores (two column blocks exchanged between lane pairs), 0 = 8-byte stores
+int g_gemm_skip_dead = 1;    // omchat_op_set_tuning key 43: 1 = 64-row blocks / waves that lie wholly beyond M issue no operand reads and no MFMAs (same bits), 0 = full issue
 
 struct GemmP {
   const void* A; const void* W; void* C; const void* bias; const void* ls; const void* resid;
   int lda, ldw, ldc, ldr, M, N, K;
   const float* a_scale; const float* w_scale;      // fp8 x fp8 kernel: per-row scales of A and W (null otherwise)
   int wide_store;                                  // 16-byte epilogue stores (gemm_epilogue)
+  int skip_dead;                                   // ragged M: skip the MFMAs of row blocks beyond M (gemm8_segment, gemm_kernel)
 };
 
 // Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
@@ -300,11 +302,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / 64;
+  // ragged M (round 6, same rule as gemm8_segment): a wave whose rows all lie beyond M reads no operands and issues no MFMA
+  const bool wave_live = !p.skip_dead || m0 + wm * WTM < p.M;
   stage(0, 0);
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nk) stage((t + 1) & 1, t + 1);
+    if (!wave_live) continue;
     const char* base = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -441,6 +446,12 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = kt1 - kt0;
+  // Ragged M (round 6): rows beyond M are staged clamped and never stored; their MFMAs were still issued -- the 13th row tile of the 3-tile
+  // ViT (M = 3075 = 12 x 256 + 3) ran 64 MFMAs per wave and K-tile for three valid rows.  A 64-row block (wave group wm, half mh) that lies
+  // wholly beyond M now skips its operand reads and MFMAs (wave-uniform branches; barriers, staging and the slot schedule are untouched, so
+  // the valid rows are computed by exactly the same instructions: same bits).  tuning key 43 = 0 restores the full issue for A/B.
+  const int rows_left = p.skip_dead ? p.M - (m0 + wm * 128) : 128;
+  const bool live0 = rows_left > 0, live1 = rows_left > 64;
   // prologue: K-tile 0 completely, plus A_0 / B_0 of K-tile 1 (steady state issues them in p3 / p4 of tile t-1)
   auto issue_prologue = [&]() {
     issue(0, 0, a_src[0], 0); issue(0, 2, b_src[0], 0); issue(0, 3, b_src[1], 0); issue(0, 1, a_src[1], 0);
@@ -478,6 +489,8 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   __builtin_amdgcn_s_barrier();                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                                   \
+  if (!((MH) ? live1 : live0)) {                                                                                   \
+  } else                                                                                                           \
   if constexpr (F8 && OMCHAT_F8_SCALED) {                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
         acc[(MH) * 4 + i][(NH) * 2 + j] = mma_frag_f8x128<T>(BF[j][0], BF[j][1], af[i][0], af[i][1], acc[(MH) * 4 + i][(NH) * 2 + j]); \
@@ -492,15 +505,15 @@ __device__ __forceinline__ void gemm8_segment(const GemmP& p, int m0, int n0, in
   __builtin_amdgcn_sched_barrier(0);
 
     // phase 1: quadrant (0,0)
-    OM_LOAD_B(bf0, 0) OM_LOAD_A(0)
+    if (live0) { OM_LOAD_B(bf0, 0) OM_LOAD_A(0) }
     if (more1) issue(nb, 3, b_src[1], t + 1);
     OM_SYNC_COMPUTE(0, 0, bf0)
     // phase 2: quadrant (0,1)
-    OM_LOAD_B(bf1, 1)
+    if (live0) { OM_LOAD_B(bf1, 1) }
     if (more1) issue(nb, 1, a_src[1], t + 1);
     OM_SYNC_COMPUTE(0, 1, bf1)
     // phase 3: quadrant (1,1)
-    OM_LOAD_A(1)
+    if (live1) { OM_LOAD_A(1) }
     if (more2) issue(t & 1, 0, a_src[0], t + 2);
     OM_SYNC_COMPUTE(1, 1, bf1)
     // phase 4: quadrant (1,0), B_0 fragments still in registers
@@ -676,18 +689,14 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   auto kern = gemm8_kernel<T, EPI>;
   auto kern_p = gemm8p_kernel<T, EPI>;
   auto kern_sk = gemm8_sk_kernel<T, EPI>;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  const int n_cu = device_cus();
+  if (attr_set.first()) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    int dev = 0;
-    OM_HIP(hipGetDevice(&dev));
-    OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   const int KT = a.K / 64;
   const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
@@ -717,17 +726,13 @@ int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * 4 * 128 * 128;
   auto kern = gemm8_kernel<T, EPI, true>;
   auto kern_p = gemm8p_kernel<T, EPI, true>;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  const int n_cu = device_cus();
+  if (attr_set.first()) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    int dev = 0;
-    OM_HIP(hipGetDevice(&dev));
-    OM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store, g_gemm_skip_dead};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   if (tiles > n_cu && g_gemm_persist && n_cu >= 8) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
   else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
@@ -739,12 +744,9 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store};
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead};
   const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
   OM_LAUNCH_CHECK();
@@ -841,6 +843,7 @@ int launch_t(const GemmArgs& a, hipStream_t stream) {
 void gemm_set_skew(int v) { g_gemm_skew = v; }
 void gemm_set_persist(int v) { g_gemm_persist = v; }
 void gemm_set_wide_store(int v) { g_gemm_wide_store = v; }
+void gemm_set_skip_dead(int v) { g_gemm_skip_dead = v; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Tile choice by measurement.  Which kernel wins depends on the shape in ways a fill-the-last-round model does not capture

@@ -1399,13 +1399,13 @@ int launch_rows_longk(const GemvP& p, hipStream_t s) {
   const size_t lds = (size_t)npass * 8 * 512 * 2;
   if (p.w_scale) {
     auto k = gemv_rows_longk_kernel<T, true>;
-    static bool set = false;
-    if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
+    static PerDeviceOnce set;
+    if (set.first()) OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * rpw), lds, s, p, rpw);
   } else {
     auto k = gemv_rows_longk_kernel<T, false>;
-    static bool set = false;
-    if (!set) { OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); set = true; }
+    static PerDeviceOnce set;
+    if (set.first()) OM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * rpw), lds, s, p, rpw);
   }
   return 0;

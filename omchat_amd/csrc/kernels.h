@@ -63,6 +63,7 @@ size_t gemm_sk_ws_bytes();
 void gemm_set_skew(int v);
 void gemm_set_persist(int v);
 void gemm_set_wide_store(int v);      // tuning key 37
+void gemm_set_skip_dead(int v);       // tuning key 43
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM (decode)
 // Y[b,N] = epilogue(X[b,K] @ W[N,K]^T) for b <= 16: weight-streaming, HBM-bound.  K % 64 == 0.

@@ -581,8 +581,9 @@ static int gemm(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw,
   return launch_gemm(ctx->dt, g, s);
 }
 
-int g_norm_in_gemv = 7;       // omchat_op_set_tuning key 14: bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final norm
-                              // inside qkv / lm_head with down_proj un-split (0 = batch-1 decode keeps both residual + RMSNorm launches: A/B)
+int g_norm_in_gemv = 3;       // omchat_op_set_tuning key 14: bit 0 = the post-attention RMSNorm runs inside the gate|up GEMV, bit 1 = the input / final norm
+                              // inside qkv / lm_head with down_proj un-split (0 = batch-1 decode keeps both residual + RMSNorm launches: A/B);
+                              // bit 2 (experiments build only, measured slower: 4.57-4.87 vs 4.28 ms per step) = the seven-launch batched layer
 void model_set_norm_in_gemv(int v) { g_norm_in_gemv = v; }
 int g_pack_replica = 1;       // omchat_op_set_tuning key 6: 0 = batched decode reads the row-major weights (packed x only)
 void model_set_pack_replica(int v) { g_pack_replica = v; }
@@ -1523,10 +1524,18 @@ extern "C" int omchat_masked_decode_begin(omchat_ctx* ctx, int b, const int32_t*
   const omchat_config& c = ctx->c;
   TRY(masked_common_checks(ctx, b));
   OM_CHECK(mask_cols >= 1 && mask_cols <= mask_ld && mask_cols <= c.max_seq, "mask_cols: 1 .. min(mask_ld, max_seq)");
-  for (int i = 0; i < b; ++i) OM_CHECK(positions[i] >= 0 && positions[i] < c.max_seq, "position outside the RoPE table");
+  // Only the slots that exist at the first step carry caller data: [0, Lc) the cache, Lc the new token's own slot.  Everything behind is a
+  // generated token's slot and must read as visible whatever a zero-padded caller buffer holds there (zeros at or beyond Lc hid
+  // the new token and every later one without an error); a caller mask that hides slot Lc itself is refused like the host-mask entry does.
+  const int Lc = ctx->pre_S + ctx->masked_steps;
+  const int cols = mask_cols < Lc + 1 ? mask_cols : Lc + 1;
+  for (int i = 0; i < b; ++i) {
+    OM_CHECK(positions[i] >= 0 && positions[i] < c.max_seq, "position outside the RoPE table");
+    OM_CHECK(mask_cols <= Lc || key_mask[(size_t)i * mask_ld + Lc] != 0, "the new token must see itself (key_mask column pre_S + steps)");
+  }
   hipStream_t s = (hipStream_t)stream;
   OM_HIP(hipMemsetAsync(ctx->d_mask, 1, (size_t)b * ctx->mask_sb, s));
-  OM_HIP(hipMemcpy2DAsync(ctx->d_mask, (size_t)ctx->mask_sb, key_mask, (size_t)mask_ld, (size_t)mask_cols, (size_t)b, hipMemcpyHostToDevice, s));
+  OM_HIP(hipMemcpy2DAsync(ctx->d_mask, (size_t)ctx->mask_sb, key_mask, (size_t)mask_ld, (size_t)cols, (size_t)b, hipMemcpyHostToDevice, s));
   OM_HIP(hipMemcpyAsync(ctx->d_pos, positions, (size_t)b * 4, hipMemcpyHostToDevice, s));
   OM_HIP(hipStreamSynchronize(s));     // once per generation: the caller's buffers are free again
   ctx->mask_on_device = true;

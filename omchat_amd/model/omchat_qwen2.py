@@ -153,9 +153,12 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
             if ragged and side == "left" and not can_mask:
                 raise NotImplementedError("left-padded ragged batch: the masked decode step runs at tp_size == 1 only; pad on the right")
             self._padded_batch = ragged and can_mask
+            self._prefill_slots = S                                   # the common cache slot a padded batch's decode steps append at
             logits_last, hidden = self.engine.prefill(inputs_embeds, lengths, want_hidden=bool(output_hidden_states), padding_side=side)
+            local = logits_last                                       # this rank's vocabulary shard (the whole vocabulary at TP = 1)
             logits_last = self.engine.full_logits(logits_last)        # vocab-parallel lm_head: gather the rank-local shards
             out = CausalLMOutputWithPast(logits_last.unsqueeze(1), KVHandle(self.engine, b))
+            out.local_logits = local
             if output_hidden_states:
                 out["hidden_states"] = (hidden,); out.hidden_states = (hidden,)
             return out
@@ -216,17 +219,16 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         if streamer is not None:
             streamer.put(input_ids.cpu())
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True)
-        if self.engine.tp_size == 1:
-            tok = self.engine.argmax(out.logits[:, 0])
-        else:
-            # gathered [b, V] logits: first index wins an exact tie, the rule Engine.argmax / omchat_greedy implement (torch.argmax
-            # does not promise it)
-            lg = out.logits[:, 0]
-            idx = torch.arange(lg.shape[-1], device=lg.device)
-            tok = torch.where(lg == lg.max(dim=-1, keepdim=True).values, idx, lg.shape[-1]).min(dim=-1).values.to(torch.int32)
+        # ONE rule for the first token at every TP degree: omchat_greedy on this rank's vocabulary shard -- local first-index-wins argmax,
+        # then the (max, index) exchange the decode step uses (model.hip: greedy_pick); no torch re-statement on the gathered logits
+        tok = self.engine.argmax(out.local_logits)
+        padded = getattr(self, "_padded_batch", False)
         # The KV cache is context-owned with a fixed capacity (the reference's DynamicCache grows without bound): generate as
         # many tokens as fit and stop cleanly, returning what was produced, instead of failing mid-stream with 'KV cache full'.
-        room = self.engine.c.max_seq - max(self.engine.kv_lengths(b)) + 1
+        # A padded batch appends at the COMMON slot (omchat_arch.py:61-70: the cache length, pads included), so its room is counted from
+        # there, not from the longest row's own length
+        used = self._prefill_slots if padded else max(self.engine.kv_lengths(b))
+        room = self.engine.c.max_seq - used + 1
         if max_new_tokens > room:
             import warnings
             warnings.warn(f"max_new_tokens={max_new_tokens} clamped to {room}: KV cache capacity max_seq={self.engine.c.max_seq}")
@@ -238,8 +240,7 @@ class OmChatQwen2ForCausalLM(OmChatMetaForCausalLM):
         # cache length and takes position_ids = sum(mask) - 1.  Over the cache slots that key mask is the same at every step -- [prompt mask |
         # ones] -- and the positions grow by one, so the branch is evaluated ONCE here (this class's mirror of it) and handed to the engine
         # (masked_decode_begin); the steps then need no host data and run ahead of the host exactly like the unpadded ones.
-        padded = getattr(self, "_padded_batch", False)
-        if padded:
+        if padded and max_new_tokens > 1:                             # (one token = the prefill's: no decode step is enqueued, nothing to begin)
             tok_mask = (attention_mask if attention_mask is not None else torch.ones_like(input_ids)).to("cpu", torch.long)
             m1 = torch.cat([tok_mask, torch.ones(b, 1, dtype=torch.long)], dim=1)
             _, pos1, mask1, _, _, _ = self.prepare_inputs_labels_for_multimodal(torch.zeros(b, 1, dtype=torch.long), None, m1, out.past_key_values,

@@ -39,20 +39,25 @@ def _round_bf16_fp16_exact(v):
     return np.where(ok, f, np.float32(0.0)).astype(np.float32)
 
 
-def uniform(name, shape, seed=0, std=0.02, offset=0.0):
-    """float32 array of `shape`; values exact in bf16 and fp16.  `offset` is added before rounding (e.g. 1.0 for
-    norm weights)."""
-    n = int(np.prod(shape))
+def uniform_range(name, start, count, seed=0, std=0.02, offset=0.0):
+    """Elements [start, start + count) of the flattened tensor `name` (float32, 1-D): the generator is counter-based, so any slice --
+    a few embedding rows of a 545 M element table, a chunk handed to a worker thread -- costs only its own elements."""
     key = np.uint64((fnv1a64(name) ^ (seed & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF)
     with np.errstate(over="ignore"):
-        ctr = key + np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        ctr = key + (np.uint64(start) + np.arange(count, dtype=np.uint64)) * np.uint64(0x9E3779B97F4A7C15)
     h = _splitmix64(ctr)
     iv = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)
     mul = np.float32(np.float32(std * np.sqrt(3.0)) / np.float32(1 << 23))
     v = iv.astype(np.float32) * mul
     if offset:
         v = v + np.float32(offset)
-    return _round_bf16_fp16_exact(v.astype(np.float32)).reshape(shape)
+    return _round_bf16_fp16_exact(v.astype(np.float32))
+
+
+def uniform(name, shape, seed=0, std=0.02, offset=0.0):
+    """float32 array of `shape`; values exact in bf16 and fp16.  `offset` is added before rounding (e.g. 1.0 for
+    norm weights)."""
+    return uniform_range(name, 0, int(np.prod(shape)), seed, std, offset).reshape(shape)
 
 
 # ---------------------------------------------------------------------------------------------------------

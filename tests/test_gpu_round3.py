@@ -440,7 +440,7 @@ def test_decode_with_norm_in_gemv_vs_separate_launch_and_oracle(gpu_lib, dt, fp8
             runs[key] = (outs, [int(torch.argmax(o[0])) for o in outs])
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(14, 7)
+        gpu_lib.omchat_op_set_tuning(14, 3)
     for a_, b_ in zip(runs[1][0], runs[0][0]):
         assert rel(a_, b_) < (1.2e-2 if dt == "bf16" else 2.5e-3), rel(a_, b_)
     if not fp8:
@@ -495,7 +495,7 @@ def test_decode_six_launch_layer_modes_agree(gpu_lib, dt):
             runs[key] = outs
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(14, 7)
+        gpu_lib.omchat_op_set_tuning(14, 3)
     for key in (1, 0):
         for a_, b_ in zip(runs[3], runs[key]):
             assert torch.isfinite(a_).all() and rel(a_, b_) < (1.2e-2 if dt == "bf16" else 2.5e-3), (key, rel(a_, b_))

@@ -1,5 +1,5 @@
 """Round-4 GPU tests (all through the C ABI):
-  * the fused attention + merge + o_proj launch of the batch-1 decode step (csrc/fused_decode.hip) gives the BITS of the three launches it
+  * the fused attention + merge + o_proj launch of the batch-1 decode step (csrc/experiments/fused_decode.hip) gives the BITS of the three launches it
     replaces, at the tiny geometries (ragged K chunk, one row per workgroup) and at the full Qwen2-7B width (28 / 4 heads, 3584 wide, two
     rows per wave), across a key-tile boundary and at 3 k keys; no hand-off timed out
   * padded batches decode as the REFERENCE computes them (omchat_arch.py:61-70): logits of the three steps after the right-

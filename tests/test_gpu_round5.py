@@ -30,7 +30,7 @@ def test_shard_width_gemv_shapes_vs_fp32_and_round4_shapes(gpu_lib, dt, b, N, K,
     code = CODE[dt]
     got = {}
     try:
-        for key in (7, 0):
+        for key in (15, 0):
             gpu_lib.omchat_op_set_tuning(34, key)
             out = torch.full((b, N), float("nan"), dtype=DT[dt], device="cuda")
             _lib.check(gpu_lib.omchat_op_gemv_packed(code, ptr(dX), K, ptr(dW), K, ptr(out), N, b, N, K, ptr(db), _lib.EPI_NONE, 0, 1, 1, 0, None))
@@ -41,10 +41,10 @@ def test_shard_width_gemv_shapes_vs_fp32_and_round4_shapes(gpu_lib, dt, b, N, K,
             assert torch.isfinite(part).all() and rel(part.sum(0), y) < 1e-4
             got[key] = (out.clone(), part.sum(0))
     finally:
-        gpu_lib.omchat_op_set_tuning(34, 7)
+        gpu_lib.omchat_op_set_tuning(34, 15)
     # the two shapes sum K in different orders: equal to fp32 rounding, and to one 16-bit ulp after the output rounding
-    assert rel(got[7][1], got[0][1]) < 1e-5
-    assert rel(got[7][0], got[0][0]) < TOL[dt]
+    assert rel(got[15][1], got[0][1]) < 1e-5
+    assert rel(got[15][0], got[0][0]) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -55,7 +55,7 @@ def test_batch1_short_gate_up_one_pair_per_wave(gpu_lib, dt):
     ref = _gemm_ref(X, W, None, None, None, _lib.EPI_SWIGLU, dt)
     outs = {}
     try:
-        for key in (7, 3):
+        for key in (15, 11):
             gpu_lib.omchat_op_set_tuning(34, key)
             o = torch.full((1, N // 2), float("nan"), dtype=DT[dt], device="cuda")
             _lib.check(gpu_lib.omchat_op_gemv(CODE[dt], ptr(dev(X, dt)), K, ptr(dev(W, dt)), K, ptr(o), N // 2, 1, N, K, None, None, 0, _lib.EPI_SWIGLU, 0, None))
@@ -63,8 +63,8 @@ def test_batch1_short_gate_up_one_pair_per_wave(gpu_lib, dt):
             assert rel(o, ref) < TOL[dt]
             outs[key] = o.clone()
     finally:
-        gpu_lib.omchat_op_set_tuning(34, 7)
-    assert torch.equal(outs[7], outs[3])          # one row per wave either way: the same sum order, the same bits
+        gpu_lib.omchat_op_set_tuning(34, 15)
+    assert torch.equal(outs[15], outs[11])          # one row per wave either way: the same sum order, the same bits
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -85,7 +85,7 @@ def test_decode_step_at_the_tp8_rank_widths_vs_oracle(gpu_lib, dt, b):
     res = {}
     try:
         gpu_lib.omchat_op_set_tuning(14, 0)
-        for key in (7, 0):
+        for key in (15, 0):
             gpu_lib.omchat_op_set_tuning(34, key)
             e = Engine(cfg, dtype=dt, max_seq=S + 8, max_batch=b, max_tiles=1, vision=False)
             e.load_state_dict(sd)
@@ -95,17 +95,17 @@ def test_decode_step_at_the_tp8_rank_widths_vs_oracle(gpu_lib, dt, b):
             res[key] = (lg.cpu(), lg2.cpu(), nxt.cpu())
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(34, 7)
-        gpu_lib.omchat_op_set_tuning(14, 7)
+        gpu_lib.omchat_op_set_tuning(34, 15)
+        gpu_lib.omchat_op_set_tuning(14, 3)
     for i in sorted({0, 1 % b, b // 2, b - 1}):
         cache = oracle.KVCache(cfg.text["num_hidden_layers"])
         oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
         o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
-        o2 = oracle.decode_step(res[7][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
-        for key in (7, 0):
+        o2 = oracle.decode_step(res[15][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
+        for key in (15, 0):
             assert rel(res[key][0][i], o1) < TOL_DEEP[dt], (key, i, rel(res[key][0][i], o1))
-        assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
-    assert rel(res[7][0], res[0][0]) < TOL_DEEP[dt]
+        assert rel(res[15][1][i], o2) < TOL_DEEP[dt], (i, rel(res[15][1][i], o2))
+    assert rel(res[15][0], res[0][0]) < TOL_DEEP[dt]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -296,13 +296,13 @@ def test_batched_decode_with_the_norm_in_the_gate_up_gemv_vs_eight_launches_and_
             res[key] = (lg.cpu(), lg2.cpu(), nxt.cpu())
             e.close()
     finally:
-        gpu_lib.omchat_op_set_tuning(14, 7)
+        gpu_lib.omchat_op_set_tuning(14, 3)
     for i in sorted({0, b // 2, b - 1}):
         cache = oracle.KVCache(2)
         oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
         o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
         o2 = oracle.decode_step(res[7][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
-        for key in (7, 3):
+        for key in (15, 11):
             assert rel(res[key][0][i], o1) < TOL_DEEP[dt], (key, i, rel(res[key][0][i], o1))
         assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
     # the two structures sum o_proj's K in different orders (one slice against two) and form the variance in different orders

@@ -637,3 +637,25 @@ def test_roofline_table_merges_the_two_launches_of_a_split_gemm():
     got = rt.label(layer * 2)
     want = ["RMSNorm (ViT)", "ViT qkv GEMM", "ViT q/k norm", "ViT attention (MHA)", "ViT proj GEMM", "RMSNorm (ViT)", "ViT fc1 GEMM (GELU)", "ViT fc1 GEMM (GELU)", "ViT fc2 GEMM"]
     assert got == want * 2
+
+
+def test_pmc_symbol_patterns_match_the_built_library():
+    """bench.py reads `roofline.traffic` out of a committed PMC summary by kernel SYMBOL; the patterns live in tools/kernel_roles.py (shared with
+    tools/roofline_table.py) and every first-choice pattern must match a kernel of the library as built -- a renamed kernel or a changed template
+    parameter list fails HERE, on the CPU, instead of nulling the traffic figure on the GPU box."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import kernel_roles
+    from omchat_amd import _lib
+    syms = subprocess.run(["nm", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    stubs = [l.split()[-1] for l in syms.splitlines() if "__device_stub__" in l]
+    assert len(stubs) > 100
+    for role, subs in kernel_roles.first_choice_patterns():
+        # the host-side launch stub carries the kernel's mangled name with a __device_stub__ prefix inside the namespace part
+        hits = [s for s in stubs if all(x in s.replace("__device_stub__", "") for x in subs)]
+        assert hits, (role, subs)
+    # and every kernel family the roofline table labels exists (or is an experiments-build / planned name explicitly listed as optional)
+    optional = {"vit_qk_sumsq_kernel", "gemv_kernel", "attn_kernel", "gemm8p_kernel"}
+    for fam in kernel_roles.FAMILIES:
+        assert fam in optional or any(fam + "I" in s or fam + "E" in s or fam in s for s in stubs), fam

@@ -8,6 +8,7 @@
 #   py script [args]    python3 script args
 #   suite               the driver's round-end sequence: pytest -m gpu (durations recorded), smoke(), bench.py default line
 #   ab key v1 v2 [args] bench.py once per value of tuning key `key` (same box), decode / ViT / prefill figures side by side
+#   table34             configs[3] and configs[4]: kernel stats of a warmed step + FETCH_SIZE / WRITE_SIZE passes -> kernel_stats_configs{3,4}_*.csv, pmc_traffic_configs{3,4}.json
 #   table               configs[1]: kernel trace + FETCH_SIZE / WRITE_SIZE passes -> roofline_table.txt (tools/roofline_table.py), kernel stats CSV
 cd /tmp && export TMPDIR=/tmp
 export OMCHAT_ALLOW_TUNING=1      # tools/*.py set tuning keys (process-global measurement hooks)
@@ -67,6 +68,19 @@ PY
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w2 -o w --output-format csv -- python3 bench.py --workload configs2 --steps 1 --warmup 0 --gen 4 --no-cpu-baseline --no-fp8 --no-side > /dev/null 2> $O/write2.err
     python3 tools/pmc_summary.py $(find $O/f2 -name "*counter_collection.csv" | head -1) $(find $O/w2 -name "*counter_collection.csv" | head -1) $O/pmc_traffic_configs2.json > /dev/null
     rm -rf $O/t2 $O/f2 $O/w2
+    ;;
+  table34)
+    for w in configs3 configs4; do
+      g=32; [ $w = configs4 ] && g=32
+      B="--workload $w --steps 1 --warmup 1 --gen $g --no-cpu-baseline"
+      rm -rf $O/t $O/f $O/w
+      rocprofv3 --kernel-trace --stats -d $O/t -o t --output-format csv -- python3 bench.py $B > $O/stats_$w.json 2> $O/stats_$w.err
+      cp $(find $O/t -name "*kernel_stats.csv" | head -1) $O/kernel_stats_${w}_steps1_gen$g.csv && head -24 $O/kernel_stats_${w}_steps1_gen$g.csv | cut -c1-180
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 bench.py --workload $w --steps 1 --warmup 0 --gen 4 --no-cpu-baseline > /dev/null 2> $O/fetch_$w.err
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 bench.py --workload $w --steps 1 --warmup 0 --gen 4 --no-cpu-baseline > /dev/null 2> $O/write_$w.err
+      python3 tools/pmc_summary.py $(find $O/f -name "*counter_collection.csv" | head -1) $(find $O/w -name "*counter_collection.csv" | head -1) $O/pmc_traffic_$w.json | head -14
+      rm -rf $O/t $O/f $O/w
+    done
     ;;
   py) python3 "$@" 2>&1 | tee $O/py.txt | tail -60 ;;
   *) echo "unknown job $job"; exit 2 ;;

@@ -14,7 +14,11 @@ import argparse
 import collections
 import csv
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_roles import FAMILIES      # one table of kernel names for bench.py and this tool (tools/kernel_roles.py)
 
 HBM_PEAK = 8000.0      # GB/s
 MFMA_PEAK = 2500.0     # TFLOP/s dense bf16
@@ -22,11 +26,7 @@ MFMA_PEAK = 2500.0     # TFLOP/s dense bf16
 
 def kind_of(name):
     """(family, epilogue code or None) of a kernel name (mangled or demangled)"""
-    for fam in ("gemm8p_kernel", "gemm8_kernel", "gemm_kernel", "gemv_rows_norm_loop_kernel", "gemv_rows_norm_kernel", "gemv_rows_longk_kernel",
-                "gemv_rows_kernel", "gemv_xs_split_kernel", "gemv_xs_kernel", "gemv_pk_kernel", "gemv_kernel", "attn_decode_dma_kernel",
-                "attn_decode_multi_kernel", "attn_decode_kernel", "attn_merge_kernel", "attn2_kernel", "attn_kernel", "vit_qknorm_kernel",
-                "vit_qk_sumsq_kernel", "resid_rmsnorm_kernel", "rmsnorm_kernel", "layernorm_kernel", "rope_kv_kernel", "gather_rows_kernel",
-                "argmax_stage1_kernel", "argmax_stage2_kernel", "im2col_kernel", "vit_assemble_kernel", "copy_rows_kernel"):
+    for fam in FAMILIES:
         if fam in name:
             epi = None
             if fam.startswith("gemm8"):
