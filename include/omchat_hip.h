@@ -208,6 +208,33 @@ int omchat_mha_fwd_varlen(const void* qkv, int B, int S, int H, int D, const int
  * (8-byte epilogue accesses); bias and ls 8-byte aligned; EPI_SWIGLU: N % 32 == 0 and C is [M, N / 2]. */
 int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                    const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, void* stream);
+/* Round 6: the vision tower's norms folded into its GEMMs (csrc/model.hip vit_layer_fused; InternVisionEncoderLayer.forward,
+ * modeling_intern_vit.py:210-222 with InternRMSNorm :39-44 and the joint-head q / k norm :143-148).  Op-level entries of its pieces:
+ * omchat_op_gemm_fused = omchat_op_gemm with (a) a per-row factor on the fp32 accumulators, C = epi(s[m] * (A W^T) ...) -- the RMSNorm in front
+ * of a projection -- given either finished (row_scale [M] fp32) or as the producer's statistics slots (rs_stats, s[m] = rsqrt(sum of slots
+ * [0, rs_nslots) / rs_dim + rs_eps), finished per tile inside the launch); both null = no factor; (b) epi 7 (= 2, layer-scale + residual) /
+ * 8 (= 0) that also leave stats fp32: per row and per wave-column block ("slot") the sum of squares of the 16-bit values stored.  ALL statistics
+ * buffers are SLOT-MAJOR: element (slot s, row m) at [s * ld + m], ld >= M (the 16 rows of an MFMA fragment are one 64-byte run for the producer,
+ * and a consumer's wave reads 64 consecutive rows of a slot); *nslots = the number of slots written (one per wave tile of the tile kernel(s) that
+ * ran: 64 or 112 columns each; epi 8 runs on 64-column wave tiles only, so the thirds of a fused q | k | v output own whole slots).  omchat_op_stats_finish: for group g < ngroups, t_g = sum of slots
+ * [slot0 + g * nslots, slot0 + (g + 1) * nslots) of a row; dim > 0: out[m * ngroups + g] = rsqrt(t_g / dim + eps), dim == 0: out = t_g (a
+ * stand-alone finishing launch: tests and callers outside the fused layer).  omchat_op_row_sumsq: stats[m] = sum_c x[m][c]^2 (slot 0).
+ * omchat_op_fold_cols: out[r][c] = T(W[r][c] * n[c]) (a norm weight folded into the columns of the linear map behind it).
+ * omchat_op_vit_knorm_slots: the K half of the joint-head norm from the qkv GEMM's slots (q slots [0, nslots), k slots [nslots, 2 nslots),
+ * nslots <= 64): k = T(w_k * T(k * rsqrt(sum k slots / C_total + eps))) in place on rows of stride ld, sumsq_q[m] = sum of the q slots.
+ * omchat_op_mha_qnorm: omchat_mha_fwd on packed qkv [B, S, 3, H, 128] whose Q is RAW -- q = T(T(w_q * T(q * rstd_q)) * q_scale) is applied
+ * where the kernel loads Q, rstd_q from sumsq[(b * S + s) * stride]. */
+int omchat_op_gemm_fused(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                         const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, const float* row_scale,
+                         const float* rs_stats, int rs_ld, int rs_nslots, int rs_dim, float rs_eps,
+                         float* stats, int stats_ld, int* nslots, void* stream);
+int omchat_op_stats_finish(const float* stats, int ld, int slot0, int nslots, int ngroups, int rows, int dim, float eps, float* out, void* stream);
+int omchat_op_row_sumsq(int dtype, const void* x, int ldx, int rows, int H, float* stats, void* stream);
+int omchat_op_fold_cols(int dtype, const void* W, const void* n, void* out, int rows, int cols, void* stream);
+int omchat_op_vit_knorm_slots(int dtype, void* k, int ld, const void* wk, int rows, int C, int C_total, float eps, const float* stats, int stats_ld,
+                              int nslots, float* sumsq_q, void* stream);
+int omchat_op_mha_qnorm(int dtype, const void* qkv, int B, int Sq, int H, const float* sumsq, int stride, int dim, const void* wq,
+                        float eps, float q_scale, void* out, void* stream);
 /* same with the stream-K tail enabled: ws from omchat_op_gemm_sk_ws() bytes of device memory; stream_k 0 = auto, 1 = required */
 /* experiment knobs -- PROCESS-GLOBAL test / measurement hooks shared by every context of the process: refused (error return) unless the
  * process environment has OMCHAT_ALLOW_TUNING=1; nothing in the product sets a key.  (key 0: start skew of the 256x256 GEMM workgroups, in units of ~1024 cycles; key 1: 1 = skinny GEMM
@@ -259,6 +286,11 @@ int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, int ldw, vo
  * where the slice count changes);
  * key 35 (experiments build): a rank context whose exchanges are no-ops takes the one-GPU launch structures on its shard widths (measurement);
  * key 36 (experiments build): 2 = the MHA prefill attention splits the keys between two wave groups of an eight-wave workgroup (measured slower);
+ * key 43: 1 (default) = the MFMA GEMMs issue no operand reads and no MFMAs for 64-row blocks / waves that lie wholly beyond M (the 13th row tile of the
+ * 3-tile ViT holds 3 valid rows of 256), 0 = full issue (same bits; in the model -0.7 % of the ViT, inside the noise: profiles/r06_a_gemm_dead_row_skip_ab.txt);
+ * key 44: 1 (default) = the RMSNorm vision tower at TP = 1 runs the fused layer of round 6 (norm1 / norm2 as a row scale of the qkv / fc1 GEMM with the
+ * norm weight folded into the GEMM weight, statistics from the producing GEMM's epilogue finished per tile inside the consuming GEMM, q norm on load in the
+ * attention kernel, K norm from the qkv epilogue's statistics: six launches), 0 = the eight launches of round 5;
  * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits);
  * key 38: (gate, up) pairs per wave of the batch-1 gate|up GEMV's non-loop norm form: 1 (default: thousands of small workgroups that the dispatcher
  * re-balances over the XCDs; decode 2.650 -> 2.597 ms per token against the loop form), 2, 3 (same bits); 16 x n sets the e4m3 replica's form

@@ -9,6 +9,7 @@ _lib = None
 
 F16, BF16, F32 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_LS_RESID, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3, 4
+EPI_LS_RESID_STATS, EPI_NONE_STATS = 7, 8      # round 6: the same epilogues + per-row sum-of-squares slots (kernels.h)
 PAD_ROW = -(2 ** 31)
 PROF_DECODE_GATEUP, PROF_PREFILL_GATEUP, PROF_VIT_FC1 = 0, 1, 2
 
@@ -63,6 +64,12 @@ _SIGS = {
     "omchat_mha_fwd": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "omchat_mha_fwd_varlen": (_i, [_vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _i, _vp]),
     "omchat_op_gemm": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "omchat_op_gemm_fused": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
+    "omchat_op_stats_finish": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "omchat_op_row_sumsq": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "omchat_op_fold_cols": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
+    "omchat_op_vit_knorm_slots": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp]),
+    "omchat_op_mha_qnorm": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _f, _vp, _vp]),
     "omchat_op_set_tuning": (_i, [_i, _i]),
     "omchat_gemm_tune_load": (_i, [C.c_char_p]),
     "omchat_gemm_tune_dump": (_i, [C.c_char_p]),

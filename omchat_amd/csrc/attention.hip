@@ -403,6 +403,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = ld8<T>(qp + s * 16 + hh * 8);
   }
+  // q norm on load (MHA, round 6): the row's finished sum of squares and this lane's slice of w_q are requested with Q
+  [[maybe_unused]] float qn_ss = 0.f;
+  [[maybe_unused]] frag_t qn_wv[(!GQA && D == 128) ? KS : 1];
+  if constexpr (!GQA && D == 128) {
+    if (p.qn_sumsq) {
+      const int rr = qrow < p.Sq ? qrow : p.Sq - 1;
+      qn_ss = p.qn_sumsq[((size_t)b * p.Sq + rr) * p.qn_stride];
+      const T* wq = (const T*)p.qn_w + (size_t)hq * D;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qn_wv[s] = ld8<T>(wq + s * 16 + hh * 8);
+    }
+  }
 
   f32x16 o[DB];
 #pragma unroll
@@ -472,6 +484,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const int g_begin = KG == 1 ? t_begin : t_begin + kg * steps;
   const int g_end = KG == 1 ? t_end : (kg == 0 ? t_begin + steps : t_end);
   if (g_end > g_begin) issue_tile(g_begin, 0);
+  // (the q norm's arithmetic sits HERE, behind the first tile's LDS-DMA: its statistic / weight loads were requested with Q, in front of the DMA, so
+  // waiting for them does not wait for the tile, and its ~400 VALU instructions run while the tile is in flight)
+  if constexpr (!GQA && D == 128) {
+    if (p.qn_sumsq) {
+      // InternAttention's q norm (modeling_intern_vit.py:143-148) on the fragments just loaded, with vit_qknorm_kernel's rounding points:
+      // T(T(w_q * T(q * rstd)) * scale)
+      const float inv = rsqrtf(qn_ss / (float)p.qn_dim + p.qn_eps);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        frag_t nq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nq[j] = fromf<T>(rnd<T>(tof(qn_wv[s][j]) * rnd<T>(tof(qf[s][j]) * inv)) * p.qn_scale);
+        qf[s] = nq;
+      }
+    }
+  }
   for (int it = 0; it < steps; ++it) {
     const int t = g_begin + it;
     const int cur = it & 1;
@@ -1382,6 +1410,11 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
+  if (a.qn_sumsq) {      // Q half of the ViT's joint-head norm on load (attn2_kernel, MHA, head dim 128)
+    OM_CHECK(a.q_heads == a.kv_heads && hd == 128 && g_attn_v2 && !a.causal && a.qn_w && a.qn_stride >= 1 && a.qn_dim > 0,
+             "q norm on load: MHA at head dim 128 on the second-generation kernel");
+    p.qn_sumsq = a.qn_sumsq; p.qn_stride = a.qn_stride; p.qn_dim = a.qn_dim; p.qn_w = a.qn_w; p.qn_eps = a.qn_eps; p.qn_scale = a.qn_scale;
+  }
   // MHA on the second-generation kernel: query blocks of a (head, sequence) pair 8 workgroup ids apart = on one XCD (attn2_kernel; key 33 = 0: the
   // three-dimensional grid)
   dim3 grid_x = grid;

@@ -28,6 +28,11 @@ struct AttnP {
   // key_mask[b * mask_sb + j] != 0 (rows zero-padded to mask_sb, a multiple of 64), and the new token is rotated to pos[b] -- not to the
   // slot it is appended at (kv_len - 1)
   const unsigned char* key_mask; int64_t mask_sb;
+  // prefill, MHA (the ViT, round 6): the Q half of InternAttention's joint-head q / k RMSNorm (modeling_intern_vit.py:143-148) applied where
+  // the kernel loads Q -- q = T(T(w_q * T(q * rstd_q)) * qn_scale) with rstd_q = rsqrt(qn_sumsq[m * qn_stride] / qn_dim + qn_eps),
+  // m = batch * Sq + query: the row's sum of squares over all heads' q channels, finished from the per-wave-column partials the qkv GEMM's
+  // epilogue left (gemm.hip EPI_NONE_STATS -> launch_stats_finish).  null = Q is used as stored.
+  const float* qn_sumsq = nullptr; int qn_stride = 0, qn_dim = 0; const void* qn_w = nullptr; float qn_eps = 0.f, qn_scale = 1.f;
 #if OMCHAT_EXPERIMENTS
   unsigned long long* dbg;      // measurement only: clock stamps of the layer (model.hip dbg_stamps), else null
 #endif

@@ -16,6 +16,48 @@ extern "C" int omchat_op_gemm(int dtype, const void* A, int lda, const void* W, 
   return launch_gemm(dtype, g, S(stream));
 }
 
+// round 6: the GEMM with the folded-norm row scale and / or the statistics epilogues (epi 7 = LS_RESID + stats, 8 = NONE + stats);
+// *nslots (host int, may be null) receives the number of statistics slots the launch wrote (one per wave tile of the tile kernel that ran)
+extern "C" int omchat_op_gemm_fused(int dtype, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                    const void* bias, const void* ls, const void* resid, int ldr, int epi, int force_tile, const float* row_scale,
+                                    const float* rs_stats, int rs_ld, int rs_nslots, int rs_dim, float rs_eps,
+                                    float* stats, int stats_ld, int* nslots, void* stream) {
+  GemmArgs g{A, lda, W, ldw, C, ldc, M, N, K, bias, ls, resid, ldr, epi, force_tile, nullptr, 0, -1};
+  g.row_scale = row_scale; g.stats = stats; g.stats_ld = stats_ld; g.stats_nslots = nslots;
+  g.rs_stats = rs_stats; g.rs_ld = rs_ld; g.rs_nslots = rs_nslots; g.rs_dim = rs_dim; g.rs_eps = rs_eps;
+  return launch_gemm(dtype, g, S(stream));
+}
+extern "C" int omchat_op_stats_finish(const float* stats, int ld, int slot0, int nslots, int ngroups, int rows, int dim, float eps, float* out, void* stream) {
+  return launch_stats_finish(stats, ld, slot0, nslots, ngroups, rows, dim, eps, out, S(stream));
+}
+extern "C" int omchat_op_row_sumsq(int dtype, const void* x, int ldx, int rows, int H, float* stats, void* stream) {
+  return launch_row_sumsq(dtype, x, ldx, rows, H, stats, S(stream));
+}
+extern "C" int omchat_op_fold_cols(int dtype, const void* W, const void* n, void* out, int rows, int cols, void* stream) {
+  return launch_fold_cols(dtype, W, n, out, rows, cols, S(stream));
+}
+// the K half of the joint-head q / k norm straight from the qkv GEMM's statistics slots (q slots [0, nslots), k slots [nslots, 2 nslots)); leaves the q sums
+extern "C" int omchat_op_vit_knorm_slots(int dtype, void* k, int ld, const void* wk, int rows, int C, int C_total, float eps, const float* stats, int stats_ld,
+                                         int nslots, float* sumsq_q, void* stream) {
+  return launch_vit_knorm_slots(dtype, k, ld, wk, rows, C, C_total, eps, stats, stats_ld, nslots, sumsq_q, S(stream));
+}
+// omchat_mha_fwd on a packed qkv [B, S, 3, H, 128] whose Q is still RAW: the Q half of InternAttention's joint-head norm is applied on load from
+// sumsq [B * S][stride] (element 0 of a row: the sum of squares of its q channels; K must already be normalised: omchat_op_vit_knorm_slots)
+extern "C" int omchat_op_mha_qnorm(int dtype, const void* qkv, int B, int Sq, int H, const float* sumsq, int stride, int dim, const void* wq,
+                                   float eps, float q_scale, void* out, void* stream) {
+  OM_CHECK(qkv && out && sumsq && wq, "null argument");
+  AttnArgs a{};
+  const int64_t row = (int64_t)3 * H * 128;
+  a.Q = qkv; a.q_sb = Sq * row; a.q_sh = 128; a.q_sr = row;
+  a.K = (const char*)qkv + (size_t)H * 128 * 2; a.k_sb = a.q_sb; a.k_sh = 128; a.k_sr = row;
+  a.V = (const char*)qkv + (size_t)2 * H * 128 * 2; a.v_sb = a.q_sb; a.v_sh = 128; a.v_sr = row;
+  a.O = out; a.o_sb = (int64_t)Sq * H * 128; a.o_sh = 128; a.o_sr = (int64_t)H * 128;
+  a.batch = B; a.q_heads = H; a.kv_heads = H; a.Sq = Sq; a.Skv = Sq; a.kv_len = nullptr; a.causal = 0; a.q_pos0 = 0;
+  a.scale = 1.0f;
+  a.qn_sumsq = sumsq; a.qn_stride = stride; a.qn_dim = dim; a.qn_w = wq; a.qn_eps = eps; a.qn_scale = q_scale;
+  return launch_attn_prefill(dtype, a, S(stream));
+}
+
 // The tuning keys are PROCESS-GLOBAL switches for tests and measurements (A/B of kernel forms, launch shapes): they mutate state shared by
 // every context of the process, so production callers must not touch them -- the call is refused unless the process opted in with
 // OMCHAT_ALLOW_TUNING=1 in its environment (tests/conftest.py, bench.py --tuning and tools/gpu_job.sh set it).  Nothing in omchat_amd/ sets a key.
@@ -56,6 +98,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 36) { attn_set_kg(value); return 0; }
   if (key == 37) { gemm_set_wide_store(value); return 0; }
   if (key == 43) { gemm_set_skip_dead(value); return 0; }
+  if (key == 44) { model_set_vit_fused(value); return 0; }
   if (key == 38) { gemv_set_gu_rr(value); return 0; }
   if (key == 39) { gemv_set_longk_direct(value); return 0; }
   if (key == 40) { norm_set_wave(value); return 0; }

@@ -308,13 +308,13 @@ __global__ __launch_bounds__(NORM_THREADS) void resid_rmsnorm_kernel(T* x, int l
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void vit_qknorm_kernel(T* qkv, int ld, const T* wq, const T* wk, int C, int C_total,
-                                                                  float eps, float q_scale, const float* sumsq_in) {
+                                                                  float eps, float q_scale, const float* sumsq_in, int part0) {
   typedef typename V8<T>::type v8;
   __shared__ float red[NORM_THREADS / 64];
   const int row = blockIdx.x;
   const int nchunk = C >> 3;
   {
-    const int part = blockIdx.y;               // 0 = q, 1 = k: one workgroup each (twice the rows in flight, half the serial chain)
+    const int part = blockIdx.y + part0;       // 0 = q, 1 = k: one workgroup each (twice the rows in flight, half the serial chain); part0 = 1: K alone
     T* xr = qkv + (size_t)row * ld + part * C;
     const T* w = part == 0 ? wq : wk;
     v8 xv[NORM_MAXC];
@@ -407,6 +407,101 @@ __global__ __launch_bounds__(256) void vit_qknorm_wave_kernel(T* qkv, int ld, co
 }
 
 #endif
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 6: the ViT's norms folded into its GEMMs (model.hip vit_run, fused form).  The sum of squares of a row is left by the PRODUCING GEMM's
+// epilogue as one partial per wave-column block ("slot", gemm.hip EPI_*_STATS); these kernels are what is left of the norm launches:
+//   stats_finish_kernel   rstd[m] = rsqrt(sum of a row's slots / dim + eps)  -> the next GEMM's row scale (InternRMSNorm statistics, :39-44)
+//   row_sumsq_kernel      the statistics of a residual stream no GEMM produced (layer 0: the embeddings)
+//   vit_knorm_stats_kernel  k = T(w_k * T(k * rstd_k)) in place with rstd_k from the qkv GEMM's slots (the K half of the joint q / k norm,
+//                         modeling_intern_vit.py:143-146; the Q half is applied where the attention kernel loads Q: attention.hip)
+// Slots are summed in slot order by one thread (or one fixed tree): deterministic.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fold_cols_kernel(const T* W, const T* n, T* out, long chunks, int cols8) {
+  typedef typename V8<T>::type v8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cols8);
+    const v8 w = ld8<T>(W + i * 8), nv = ld8<T>(n + c * 8);
+    v8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(w[j]) * tof(nv[j]));
+    st8<T>(out + i * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_finish_kernel(const float* stats, int ld, int slot0, int nslots, int ngroups, int rows, float inv_dim, float eps,
+                                                           float* out) {
+  // slot-major statistics [slot][ld]: one thread per row walks its slots in slot order, every wave load one contiguous run
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  for (int g = 0; g < ngroups; ++g) {
+    const float* p = stats + (size_t)(slot0 + g * nslots) * ld + row;
+    float t = 0.f;
+    for (int c0 = 0; c0 < nslots; c0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = c0 + k < nslots ? p[(size_t)(c0 + k) * ld] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += v[k];
+    }
+    out[(size_t)row * ngroups + g] = inv_dim > 0.f ? rsqrtf(t * inv_dim + eps) : t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void row_sumsq_kernel(const T* x, int ldx, int H, float* stats) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  const T* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < (H >> 3); c += NORM_THREADS) {
+    const v8 v = ld8<T>(xr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = tof(v[j]); ss += f * f; }
+  }
+  const float t = block_sum(ss, red);
+  if (threadIdx.x == 0) stats[row] = t;      // slot 0 of the slot-major statistics
+}
+
+// K half of the joint-head q / k norm straight from the qkv GEMM's statistics slots (round 6): wave 0 sums the row's k slots, wave 1 its q slots
+// (<= 64 each, one per lane, a fixed shuffle tree), k = T(w_k * T(k * rstd_k)) in place, and the q sum is left in sumsq_q[row] for the attention
+// kernel, which applies the Q half where it loads Q.  No finishing launch: the row's loads and both slot loads are requested together.
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void vit_knorm_slots_kernel(T* k, int ld, const T* wk, int C, int C_total, float eps, const float* stats, int stats_ld,
+                                                                       int nslots, float* sumsq_q) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[2];
+  const int row = blockIdx.x;
+  const int nchunk = C >> 3;
+  T* xr = k + (size_t)row * ld;
+  v8 xv[NORM_MAXC], wv[NORM_MAXC];
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) { xv[i] = ld8<T>(xr + c * 8); wv[i] = ld8<T>(wk + c * 8); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < 2) {       // q slots [0, nslots), k slots [nslots, 2 nslots)
+    const float part = lane < nslots ? stats[(size_t)((wave == 0 ? nslots : 0) + lane) * stats_ld + row] : 0.f;      // slot-major
+    const float t = wave_sum(part);
+    if (lane == 0) red[wave] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sumsq_q[row] = red[1];
+  const float inv = rsqrtf(red[0] / (float)C_total + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[i][j]) * rnd<T>(tof(xv[i][j]) * inv));
+      st8<T>(xr + c * 8, o);
+    }
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv, int ld, int C, float* out) {
@@ -696,19 +791,57 @@ int launch_quant_rows_q8(int dtype, const void* x, int ldx, void* y8, int ldy, f
 }
 
 int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total, float eps,
-                      float q_scale, const float* sumsq_in, hipStream_t s) {
+                      float q_scale, const float* sumsq_in, hipStream_t s, int only_k) {
   OM_CHECK(C % 8 == 0 && C <= NORM_THREADS * NORM_MAXC * 8 && ld % 8 == 0, "C % 8, C <= 16384, ld % 8");
+  OM_CHECK(!only_k || sumsq_in, "the K half alone takes its statistics from sumsq_in");
   if (rows == 0) return 0;
 #if OMCHAT_EXPERIMENTS
-  if (g_norm_wave && rows >= NORM_WAVE_ROWS && C <= NORM_WAVE_H) {
+  if (!only_k && g_norm_wave && rows >= NORM_WAVE_ROWS && C <= NORM_WAVE_H) {
     DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_wave_kernel<T>, dim3((rows + 3) / 4, 2), dim3(256), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk, rows,
                                        C, C_total, eps, q_scale, sumsq_in));
     OM_LAUNCH_CHECK();
     return 0;
   }
 #endif
-  DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows, 2), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
-                                     C, C_total, eps, q_scale, sumsq_in));
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_qknorm_kernel<T>, dim3(rows, only_k ? 1 : 2), dim3(NORM_THREADS), 0, s, (T*)qkv, ld, (const T*)wq, (const T*)wk,
+                                     C, C_total, eps, q_scale, sumsq_in, only_k ? 1 : 0));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fold_cols(int dtype, const void* W, const void* n, void* out, int rows, int cols, hipStream_t s) {
+  OM_CHECK(cols % 8 == 0 && W && n && out, "cols % 8");
+  const long chunks = (long)rows * (cols / 8);
+  if (chunks == 0) return 0;
+  const int grid = (int)std::min<long>((chunks + 255) / 256, 8192);
+  DISPATCH(dtype, hipLaunchKernelGGL(fold_cols_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)W, (const T*)n, (T*)out, chunks, cols / 8));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_stats_finish(const float* stats, int ld, int slot0, int nslots, int ngroups, int rows, int dim, float eps, float* out, hipStream_t s) {
+  OM_CHECK(stats && out && nslots >= 1 && ngroups >= 1 && slot0 >= 0 && ld >= rows && dim >= 0, "bad argument");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, stats, ld, slot0, nslots, ngroups, rows, dim > 0 ? 1.0f / (float)dim : 0.f, eps, out);
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_sumsq(int dtype, const void* x, int ldx, int rows, int H, float* stats, hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && ldx % 8 == 0 && stats, "H % 8, ldx % 8");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(row_sumsq_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (const T*)x, ldx, H, stats));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_vit_knorm_slots(int dtype, void* k, int ld, const void* wk, int rows, int C, int C_total, float eps, const float* stats, int stats_ld, int nslots,
+                           float* sumsq_q, hipStream_t s) {
+  OM_CHECK(C % 8 == 0 && ld % 8 == 0 && C <= NORM_THREADS * NORM_MAXC * 8, "C % 8, ld % 8, C <= 16384");
+  OM_CHECK(stats && sumsq_q && nslots >= 1 && nslots <= 64 && stats_ld >= rows, "statistics: slot-major [2 * nslots][stats_ld >= rows], 1..64 q slots followed by as many k slots");
+  if (rows == 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(vit_knorm_slots_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)k, ld, (const T*)wk, C, C_total, eps, stats, stats_ld,
+                                     nslots, sumsq_q));
   OM_LAUNCH_CHECK();
   return 0;
 }
@@ -762,6 +895,8 @@ int launch_vit_assemble(int dtype, const void* pe, const void* cls, const void* 
 template <typename T>
 __global__ __launch_bounds__(256) void tp_finish_kernel(const float* __restrict__ sum, const T* __restrict__ bias, const T* __restrict__ ls,
                                                         const T* resid, T* out, long total4, int N, int epi) {
+  // no contraction: resid + T(T(sum + b) * ls) must keep the rounding of the product (see gemm.hip gemm_epilogue, round 6)
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     const long e = i * 4;
     const int col = (int)(e % N);

@@ -31,6 +31,11 @@ struct GemmP {
   const float* a_scale; const float* w_scale;      // fp8 x fp8 kernel: per-row scales of A and W (null otherwise)
   int wide_store;                                  // 16-byte epilogue stores (gemm_epilogue)
   int skip_dead;                                   // ragged M: skip the MFMAs of row blocks beyond M (gemm8_segment, gemm_kernel)
+  const float* row_scale;                          // [M] or null: the accumulators of row m are multiplied by row_scale[m] first (folded RMSNorm)
+  float* stats; int stats_ld;                      // EPI_*_STATS: slot-major [slots][stats_ld >= M] partial sums of squares of the stored outputs, slot = colu / (NR * 16)
+  // the row scale finished INSIDE the launch from the producer's statistics slots: rstd[m] = rsqrt(sum_{s < rs_nslots} rs_stats[m][s] * rs_inv_dim + rs_eps),
+  // computed once per tile into LDS after the K loop (no finishing launch between the producing GEMM and this one); slot-major: rs_stats[s * rs_ld + m]
+  const float* rs_stats; int rs_ld, rs_nslots; float rs_inv_dim, rs_eps;
 };
 
 // Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
@@ -82,11 +87,38 @@ template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
   return unpack4<T>(*reinterpret_cast<const u32x2*>(p));
 }
 
-template <typename T, int MR, int NR, int EPI, bool F8 = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int rowu_, int colu_, int fg, int fr) {
+template <typename T, int MR, int NR, int EPI_, bool F8 = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][NR], int rowu_, int colu_, int fg, int fr, const float* rs_lds = nullptr) {
+  // No contraction in the epilogue (round 6): resid + T(T(acc + b) * ls) is an expression over 16-bit values, the compiler narrows it to 16-bit
+  // fmul / fadd and -ffp-contract=fast then fuses the product into the add -- an fma that SKIPS the rounding of branch * ls (N8): 6.5 % of the
+  // layer-scale + residual outputs were 1 ulp off the reference's rounding points (tools/dbg_r6.py; the statistics variant of the same epilogue,
+  // whose extra use of the value blocked the narrowing, matched the fp32 restatement exactly).  GELU's polynomial uses explicit fma builtins.
+#pragma clang fp contract(off)
+  constexpr bool STATS = EPI_ == EPI_LS_RESID_STATS || EPI_ == EPI_NONE_STATS;
+  constexpr int EPI = EPI_ == EPI_LS_RESID_STATS ? EPI_LS_RESID : (EPI_ == EPI_NONE_STATS ? EPI_NONE : EPI_);
+  // One statistics slot per WAVE TILE (64 columns on the 256^2 kernels, 112 on the 192 x 224 ones; a two-launch form leaves the slots of its second
+  // launch behind those of the first).  A row's statistic is the sum of its slots in slot order: deterministic for a given problem, but the grouping
+  // follows the tile kernel tuned for the problem SIZE, so the same tile of pixels in another batch size may see its rstd differ in the last fp32 bit
+  // (as the reference's own GEMM library does per shape).  Two forms that made the grouping size-independent were measured and dropped: the 192 x 224
+  // family for every M (-1.6 % ViT at 3 tiles, +4 % at 24) and one slot per 16-column block (the 200-slot read per tile cost what the fusion saves).
   const int rowu = __builtin_amdgcn_readfirstlane(rowu_), colu = __builtin_amdgcn_readfirstlane(colu_);      // SGPRs: scalar offsets, scalar resources
   const int rows_valid = p.M - rowu < MR * 16 ? p.M - rowu : MR * 16;
   if (rows_valid <= 0) return;                                                   // wave-uniform
+  if (p.row_scale || rs_lds) {        // folded RMSNorm: y = rstd[m] * (x W'^T); wave-uniform branch, one 4-byte load per row fragment
+    float rs[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int row = rowu + i * 16 + fr;
+      rs[i] = rs_lds ? rs_lds[i * 16 + fr] : p.row_scale[row < p.M ? row : p.M - 1];      // (rs_lds: this wave's rows, finished by tile_row_scale)
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] *= rs[i];
+  }
+  float ssq[MR];            // STATS: this lane's part of sum_c out[row][c]^2 over the wave tile's valid columns
+#pragma unroll
+  for (int i = 0; i < MR; ++i) ssq[i] = 0.f;
   if constexpr (F8) {       // fp8 x fp8 operands: the accumulators are sums of unscaled e4m3 products
     float sa[MR];
 #pragma unroll
@@ -188,6 +220,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
             o[r] = v;
           }
         }
+        if constexpr (STATS) {
+          // the statistics are those of the STORED values (the reference's norm reads the 16-bit tensor); columns beyond N do not count
+          if (colu + j * 16 + 4 * fg < p.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float f = rnd<T>(o[r]); ssq[i] = __builtin_fmaf(f, f, ssq[i]); }
+          }
+        }
         return pack4<T>(o[0], o[1], o[2], o[3]);
       };
       // Wide stores (round 5): the PMC passes read 1.6-1.7 x the output bytes in WRITE_SIZE for these epilogues (fc1 133 MB for 78.7 MB): a 128-byte
@@ -228,7 +267,54 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
       }
       }
     }
+    if constexpr (STATS) {
+      // the four lanes (fr, fg = 0..3) of a row meet by two xor steps (fixed order); lane fg == 0 writes the row's partial of this wave tile
+      if (colu < p.N) {
+        const int slot = colu / (NR * 16);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          float v = ssq[i];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          const int row = rowu + i * 16 + fr;
+          if (fg == 0 && row < p.M) p.stats[(size_t)slot * p.stats_ld + row] = v;      // slot-major: the 16 rows of a fragment are one 64-byte run
+        }
+      }
+    }
   }
+}
+
+// rstd of the tile's BM rows from the producer's statistics slots, into LDS (the stage buffers are dead: every wave is behind its last LDS read).
+// Two threads per row take the even / the odd slots -- all of a thread's loads are requested before the first add -- and meet by one lane swap:
+// a fixed order.  Returns with a workgroup barrier behind the LDS writes.
+template <int BM, int NT>
+__device__ __forceinline__ void tile_row_scale(const GemmP& p, int m0, float* L) {
+  // slot-major statistics [slot][rs_ld]: a thread walks the slots of ONE row, so every load of a wave is one contiguous 256-byte run (a first form
+  // with row-major slots -- 32 rows per load instruction -- cost the qkv GEMM 11 us per launch: profiles/r06_c).  Two threads per row when the
+  // workgroup has them: the first / the second half of the slots, each in slot order, halves added last -- ONE fixed order for every tile kernel.
+  constexpr int TPR = NT >= 2 * BM ? 2 : 1;
+  const int tid = threadIdx.x, h = tid / BM, r = tid % BM;
+  if (h < TPR) {
+    int row = m0 + r; row = row < p.M ? row : p.M - 1;
+    const int per = (p.rs_nslots + TPR - 1) / TPR, s0 = h * per, s1 = s0 + per < p.rs_nslots ? s0 + per : p.rs_nslots;
+    const float* base = p.rs_stats + row;
+    float t = 0.f;
+    for (int c0 = s0; c0 < s1; c0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = c0 + k < s1 ? base[(size_t)(c0 + k) * p.rs_ld] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += v[k];
+    }
+    L[h * BM + r] = t;
+  }
+  __syncthreads();
+  if (tid < BM) {
+    float t = L[tid];
+    if (TPR == 2) t += L[BM + tid];
+    L[tid] = rsqrtf(t * p.rs_inv_dim + p.rs_eps);
+  }
+  __syncthreads();
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
@@ -325,7 +411,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     }
   }
 
-  gemm_epilogue<T, MR, NR, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fg, fr);
+  const float* rs_lds = nullptr;
+  if (p.rs_stats) {        // wave-uniform; the barrier in front: a faster wave must not overwrite a stage another wave still reads
+    __syncthreads();
+    tile_row_scale<BM, NT>(p, m0, reinterpret_cast<float*>(smem));
+    rs_lds = reinterpret_cast<const float*>(smem) + wm * WTM;
+  }
+  gemm_epilogue<T, MR, NR, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fg, fr, rs_lds);
 }
 
 
@@ -548,7 +640,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   gemm8_segment<T, F8>(p, m0, n0, 0, p.K / (F8 ? 128 : 64), smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fg = lane >> 4;
-  gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr);
+  const float* rs_lds = nullptr;
+  if (p.rs_stats) {        // wave-uniform (gemm8_segment returns with every LDS read of both wave groups retired)
+    __syncthreads();
+    tile_row_scale<256, 512>(p, m0, reinterpret_cast<float*>(smem));
+    rs_lds = reinterpret_cast<const float*>(smem) + wm * 128;
+  }
+  gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr, rs_lds);
 }
 
 // Persistent form for multi-round launches (round 3): one workgroup per CU walks tiles w, w + G, w + 2G, ... and issues the NEXT tile's
@@ -696,8 +794,9 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+  if (a.stats_nslots) *a.stats_nslots = cdiv(a.N, 64);      // one slot per 64-column wave tile
   const int KT = a.K / 64;
   const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
   int R = tiles % G;
@@ -705,11 +804,11 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   // stream-K only pays when the last round is visibly under-filled and every workgroup still gets a few K-tiles
   // measured on MI355X (r01, tools/bench_gemm.py t20 vs t2): the under-filled GEMMs of this model are operand-fetch bound,
   // not balance bound, and the slab exchange costs more than the idle CUs: stream-K only runs when explicitly requested
-  const bool use_sk = a.stream_k > 0 && have_ws && R > 0 && R * 10 < G * 9 && (long)R * KT >= 4L * G && KT >= 8;
+  const bool use_sk = a.stream_k > 0 && have_ws && !a.rs_stats && R > 0 && R * 10 < G * 9 && (long)R * KT >= 4L * G && KT >= 8;
   if (a.stream_k > 0 && !use_sk && !have_ws) { omchat_set_error("launch_gemm: stream-K requested without workspace"); return 1; }
   if (!use_sk) R = 0;
   const int n_dp = tiles - R;
-  if (n_dp > G && g_gemm_persist && R == 0 && G >= 8) hipLaunchKernelGGL(kern_p, dim3(G & ~7), dim3(512), LDS, stream, p, n_dp);
+  if (n_dp > G && g_gemm_persist && R == 0 && G >= 8 && !a.rs_stats) hipLaunchKernelGGL(kern_p, dim3(G & ~7), dim3(512), LDS, stream, p, n_dp);
   else if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
   if (R > 0) {
     unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
@@ -732,9 +831,9 @@ int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store, g_gemm_skip_dead};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
-  if (tiles > n_cu && g_gemm_persist && n_cu >= 8) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
+  if (tiles > n_cu && g_gemm_persist && n_cu >= 8 && !a.rs_stats) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
   else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
   OM_LAUNCH_CHECK();
   return 0;
@@ -746,8 +845,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI>;
   static PerDeviceOnce attr_set;
   if (attr_set.first()) OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
   const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
+  if (a.stats_nslots) *a.stats_nslots = cdiv(a.N, BN / WN);      // one slot per wave tile
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
   OM_LAUNCH_CHECK();
   return 0;
@@ -813,9 +913,13 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
           if (a.bias) t.bias = (const char*)a.bias + (size_t)n_main * es;
           if (a.ls) t.ls = (const char*)a.ls + (size_t)n_main * es;
           if (a.resid) t.resid = (const char*)a.resid + (size_t)n_main * es;
-          const int rc = launch_cfg8<T, EPI>(m, stream);
+          int ns_main = 0, ns_tail = 0;
+          if (a.stats) { t.stats = a.stats + (size_t)(n_main / 64) * a.stats_ld; m.stats_nslots = &ns_main; t.stats_nslots = &ns_tail; }      // the tail's slots behind the main launch's
+          int rc = launch_cfg8<T, EPI>(m, stream);
           if (rc) return rc;
-          return t.force_tile == 10 ? launch_cfg<T, 192, 224, 4, 2, EPI>(t, stream) : launch_cfg<T, 192, 224, 6, 2, EPI>(t, stream);
+          rc = t.force_tile == 10 ? launch_cfg<T, 192, 224, 4, 2, EPI>(t, stream) : launch_cfg<T, 192, 224, 6, 2, EPI>(t, stream);
+          if (a.stats_nslots) *a.stats_nslots = ns_main + ns_tail;
+          return rc;
         }
       }
       break;
@@ -827,6 +931,12 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_t(const GemmArgs& a, hipStream_t stream) {
   switch (a.epi) {
+    case EPI_LS_RESID_STATS: return launch_epi<T, EPI_LS_RESID_STATS>(a, stream);
+    case EPI_NONE_STATS: {      // the fused qkv output: 64-column wave tiles only, so that no slot straddles the q / k / v thirds (multiples of 64)
+      GemmArgs b = a;
+      if (b.force_tile != 2 && b.force_tile != 6 && b.force_tile != 8 && b.force_tile != 9 && b.force_tile != 7) b.force_tile = 2;
+      return launch_epi<T, EPI_NONE_STATS>(b, stream);
+    }
     case EPI_NONE: return launch_epi<T, EPI_NONE>(a, stream);
     case EPI_GELU: return launch_epi<T, EPI_GELU>(a, stream);
     case EPI_LS_RESID: return launch_epi<T, EPI_LS_RESID>(a, stream);
@@ -894,6 +1004,12 @@ long gemm_tune_runs() { return g_tune_runs; }
 static std::map<std::array<int, 5>, int> g_guess;
 
 static int tuned_tile(int dtype, const GemmArgs& a, hipStream_t stream) {
+  if (a.epi == EPI_LS_RESID_STATS || a.epi == EPI_NONE_STATS) {      // the class (and the measurement) of the base epilogue
+    GemmArgs b = a;
+    b.epi = a.epi == EPI_NONE_STATS ? EPI_NONE : EPI_LS_RESID;
+    b.stats = nullptr;
+    return tuned_tile(dtype, b, stream);
+  }
   const std::array<int, 5> key{dtype * 8 + a.epi, cdiv(a.M, 256), a.N, a.K, a.ldc};
   std::lock_guard<std::mutex> lock(g_tune_mu);
   auto it = g_tuned.find(key);
@@ -1001,7 +1117,9 @@ int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
            "C / residual: 8-byte aligned base, row stride a multiple of 4 elements (8-byte epilogue accesses)");
   OM_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "A/W must be 16-byte aligned");
   OM_CHECK(a.epi != EPI_SWIGLU || a.N % 32 == 0, "SwiGLU epilogue needs N % 32 == 0");
-  OM_CHECK(a.epi != EPI_LS_RESID || a.ls, "layer-scale epilogue needs ls");
+  OM_CHECK((a.epi != EPI_LS_RESID && a.epi != EPI_LS_RESID_STATS) || a.ls, "layer-scale epilogue needs ls");
+  OM_CHECK((a.epi != EPI_LS_RESID_STATS && a.epi != EPI_NONE_STATS) || (a.stats && a.stats_ld >= a.M), "statistics epilogue: stats [slots][stats_ld] (slot-major), stats_ld >= M");
+  OM_CHECK(!a.rs_stats || (a.rs_nslots >= 1 && a.rs_ld >= a.M && a.rs_dim > 0 && !a.row_scale), "row statistics: slot-major [rs_nslots][rs_ld >= M], rs_dim > 0, not together with row_scale");
   OM_CHECK(a.N % 4 == 0 && ((uintptr_t)a.bias & 7) == 0 && ((uintptr_t)a.ls & 7) == 0,
            "N must be a multiple of 4 and bias / layer-scale 8-byte aligned (the epilogue owns four consecutive columns per lane)");
   OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16, "bad dtype");

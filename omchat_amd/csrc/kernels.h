@@ -38,6 +38,11 @@ enum {
   EPI_PARTIAL = 5,   // skinny GEMM only: raw fp32 K-slice sums Y[ksplit][b][ldy] (split-K across workgroups)
   EPI_F32OUT = 6,    // MFMA GEMM only: C is float [M, ldc]: the raw fp32 accumulators (tensor parallelism: row-parallel partial sums that are
                      // all-reduced in fp32 and finished by launch_tp_finish; ldc % 4 == 0, C 16-byte aligned)
+  // round 6 (the ViT's norms folded into its GEMMs): the same epilogues that ALSO leave, per row and per wave-column block ("slot"), the sum of
+  // squares of the 16-bit values they store -- GemmArgs.stats, SLOT-MAJOR fp32 [slots][stats_ld >= M], slot = first column of the wave tile / its width.  The
+  // consumer (the next GEMM's row scale, the ViT q / k norm) sums a row's slots in slot order: a fixed order, so the statistics are deterministic
+  EPI_LS_RESID_STATS = 7,
+  EPI_NONE_STATS = 8,
 };
 struct GemmArgs {
   const void* A; int lda;
@@ -57,8 +62,22 @@ struct GemmArgs {
   // steps: the same LDS bytes per step as the 16-bit kernel feed twice the MFMAs.
   int f8;
   const float* a_scale; const float* w_scale;
+  // round 6: C = epi(row_scale[m] * (A W^T) + bias ...): the RMSNorm in front of a ViT projection as a per-row factor on the fp32 accumulators
+  // (x * rsqrt(mean x^2 + eps) commutes with the product; the norm WEIGHT is folded into W's columns at load time: model.hip fold_norm_weights)
+  const float* row_scale = nullptr;
+  // ... or finished inside the launch from the producing GEMM's statistics slots: row_scale[m] = rsqrt(sum_{s < rs_nslots} rs_stats[s * rs_ld + m] / rs_dim + rs_eps)
+  // (once per tile, into LDS, after the K loop: no launch between the producer and this GEMM)
+  const float* rs_stats = nullptr; int rs_ld = 0, rs_nslots = 0, rs_dim = 0; float rs_eps = 0.f;
+  // EPI_*_STATS: per-row partial sums of squares of the stored outputs (slot-major); *stats_nslots receives the number of slots the launch(es) wrote
+  float* stats = nullptr; int stats_ld = 0; int* stats_nslots = nullptr;
 };
 int launch_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
+// finishes the per-slot partials of an EPI_*_STATS GEMM (or of launch_row_sumsq); statistics are SLOT-MAJOR, stats[slot * ld + m], ld >= rows:
+// for group g < ngroups, t_g = sum_{s < nslots} stats[(slot0 + g * nslots + s) * ld + m] in slot order;  dim > 0: out[m * ngroups + g] = rsqrt(t_g / dim + eps) (a GEMM row scale),
+// dim == 0: out[m * ngroups + g] = t_g (the [rows, 2] sums launch_vit_qknorm and the attention's q norm take)
+int launch_stats_finish(const float* stats, int ld, int slot0, int nslots, int ngroups, int rows, int dim, float eps, float* out, hipStream_t s);
+// stats[m] = sum_c x[m][c]^2 (slot 0 of slot-major statistics): the statistics of a residual stream that no GEMM epilogue produced (the ViT's embeddings)
+int launch_row_sumsq(int dtype, const void* x, int ldx, int rows, int H, float* stats, hipStream_t s);
 size_t gemm_sk_ws_bytes();
 void gemm_set_skew(int v);
 void gemm_set_persist(int v);
@@ -114,6 +133,9 @@ void model_set_ar_min_rows(int v);
 void model_set_tp_f32(int v);
 void model_set_pack_replica(int v);
 void model_set_norm_in_gemv(int v);
+void model_set_vit_fused(int v);        // tuning key 44
+// out[r][c] = T(W[r][c] * n[c]): a norm weight folded into the columns of the linear map that follows it (model.hip ensure_vit_folded)
+int launch_fold_cols(int dtype, const void* W, const void* n, void* out, int rows, int cols, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------ norms
 // y = T(w * T(x * rsqrt(mean(x^2) + eps)))  (InternRMSNorm / Qwen2RMSNorm), rows of width H (H % 8 == 0, H <= 16384)
@@ -131,9 +153,13 @@ int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks,
 // multiplied by q_scale with the reference's rounding (modeling_intern_vit.py:143-148).
 // sumsq_in: optional [rows,2] fp32 externally reduced sum of squares (tensor parallel); C_total = divisor.
 int launch_vit_qknorm(int dtype, void* qkv, int ld, const void* wq, const void* wk, int rows, int C, int C_total,
-                      float eps, float q_scale, const float* sumsq_in, hipStream_t s);
+                      float eps, float q_scale, const float* sumsq_in, hipStream_t s, int only_k = 0);      // only_k: the K half alone (round 6: Q is normed where the attention loads it)
 int launch_vit_qk_sumsq(int dtype, const void* qkv, int ld, int rows, int C, float* sumsq_out, hipStream_t s);
-
+// round 6: the K half of that norm straight from the qkv GEMM's statistics slots (slot-major stats [2 * nslots][stats_ld >= rows]: q slots [0, nslots),
+// k slots [nslots, 2 nslots), nslots <= 64): k (the K columns of the fused buffer, row stride ld) = T(w_k * T(k * rsqrt(sum of the k slots / C_total + eps))) in place, and
+// sumsq_q[row] = sum of the q slots for the attention kernel's q norm on load (AttnArgs.qn_sumsq)
+int launch_vit_knorm_slots(int dtype, void* k, int ld, const void* wk, int rows, int C, int C_total, float eps, const float* stats, int stats_ld, int nslots,
+                           float* sumsq_q, hipStream_t s);
 // ------------------------------------------------------------------------------------------------ attention
 struct AttnArgs {
   const void* Q; int64_t q_sb, q_sh, q_sr;     // strides in elements: batch, head, row(token)
@@ -148,6 +174,8 @@ struct AttnArgs {
   int q_pos0;               // absolute position of query row 0 (0 for a fresh prefill)
   float scale;              // applied to scores in fp32
   int head_dim;             // 128 (0 = 128) or 64 (InternViT-300M)
+  // round 6, MHA only (q_heads == kv_heads, head_dim 128): the Q half of the ViT's joint-head q / k norm applied on load -- see attn_common.h AttnP
+  const float* qn_sumsq = nullptr; int qn_stride = 0, qn_dim = 0; const void* qn_w = nullptr; float qn_eps = 0.f, qn_scale = 1.f;
 };
 int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s);
 // query rows i < kv_start[b] of a left-padded batch (no visible key): O = sum_j T(1 / Skv) * V[j] over ALL Skv keys, the reference's eager

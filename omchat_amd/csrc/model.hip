@@ -151,6 +151,13 @@ struct omchat_ctx {
   void *vw_cols = nullptr, *vw_pe = nullptr, *vw_x = nullptr, *vw_x2 = nullptr, *vw_xn = nullptr, *vw_qkv = nullptr, *vw_ao = nullptr,
        *vw_h = nullptr, *vw_feat = nullptr, *vw_proj = nullptr;
   float* vw_sumsq = nullptr;
+  // round 6, fused ViT layer (vit_run): statistics slots left by the GEMM epilogues, the row scale finished from them, and the copies of
+  // the qkv / fc1 weights with norm1 / norm2's weight folded into their columns (W'[n][k] = T(W[n][k] * w_norm[k])); rebuilt after a reload
+  float *vw_stats_x = nullptr, *vw_stats_qk = nullptr, *vw_rstd = nullptr;
+  int vw_stats_x_ld = 0, vw_stats_qk_ld = 0, vw_stats_x_ld_used = 1;      // (_used: slots of x's statistics written by the last producer)
+  struct VitFold { void *wqkv = nullptr, *w1 = nullptr; };
+  std::vector<VitFold> vfold;
+  bool vfold_stale = true;
   void *tw_x = nullptr, *tw_x2 = nullptr, *tw_xn = nullptr, *tw_qkv = nullptr, *tw_ao = nullptr, *tw_act = nullptr, *tw_last = nullptr;
   float* tw_logits = nullptr;
   void* sk_ws = nullptr; size_t sk_ws_bytes = 0;      // stream-K slabs + flags of the MFMA GEMM
@@ -382,6 +389,11 @@ int build(omchat_ctx* ctx) {
     TRY(ctx->alloc(&ctx->vw_feat, M * C * 2));
     TRY(ctx->alloc(&ctx->vw_proj, M * c.t_hidden * 2));
     TRY(ctx->alloc((void**)&ctx->vw_sumsq, M * 2 * 4 + 64));
+    // statistics slots (slot-major [slot][M]): one per wave-column block of the producing GEMM, at least 48 columns wide (gemm.hip launch_epi_stats)
+    ctx->vw_stats_x_ld = ctx->vw_stats_qk_ld = (int)((M + 63) / 64 * 64);
+    TRY(ctx->alloc((void**)&ctx->vw_stats_x, (size_t)(cdiv(C, 48) + 2) * ctx->vw_stats_x_ld * 4));            // one slot per wave tile (>= 48 columns)
+    TRY(ctx->alloc((void**)&ctx->vw_stats_qk, (size_t)(cdiv(3 * ctx->v_Cq, 64) + 1) * ctx->vw_stats_qk_ld * 4));   // qkv: one per 64
+    TRY(ctx->alloc((void**)&ctx->vw_rstd, M * 4 + 64));
   }
   if (c.t_layers > 0) {
     const size_t R = std::max<size_t>(32, (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch));      // >= 32: packed decode operands
@@ -451,6 +463,7 @@ int place(omchat_ctx* ctx, Route& r, const void* src_t) {
     OM_HIP(hipMemcpy2D(d, 32 * rowb, src_t, 16 * rowb, 16 * rowb, (size_t)r.rows / 16, hipMemcpyDefault));
   }
   r.loaded = true;
+  ctx->vfold_stale = true;      // (any tensor: the folded qkv / fc1 copies of the vision tower are rebuilt before the next tower pass)
   return 0;
 }
 
@@ -664,10 +677,100 @@ static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W
   return 0;
 }
 
+int g_vit_fused = 1;      // omchat_op_set_tuning key 44: 1 = the ViT layer with its norms folded into the GEMMs (round 6), 0 = the round-5 launches
+void model_set_vit_fused(int v) { g_vit_fused = v; }
+
+// The fused ViT layer needs norm1 / norm2's WEIGHT inside the qkv / fc1 weights: y = w * (x * rstd) feeds a linear map, so
+// (w * x * rstd) W^T = rstd * (x (W diag(w))^T): W' = T(W * w) column-wise, once per load; rstd becomes the GEMM's row scale.
+static int ensure_vit_folded(omchat_ctx* ctx, hipStream_t s) {
+  if (!ctx->vfold_stale && !ctx->vfold.empty()) return 0;
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, I = c.v_mlp, Cq = ctx->v_Cq;
+  if (ctx->vfold.empty()) {
+    ctx->vfold.resize(c.v_layers);
+    for (auto& f : ctx->vfold) {
+      TRY(ctx->alloc(&f.wqkv, (size_t)3 * Cq * C * 2));
+      TRY(ctx->alloc(&f.w1, (size_t)I * C * 2));
+    }
+  }
+  for (int j = 0; j < c.v_layers; ++j) {
+    TRY(launch_fold_cols(ctx->dt, ctx->vl[j].wqkv, ctx->vl[j].n1, ctx->vfold[j].wqkv, 3 * Cq, C, s));
+    TRY(launch_fold_cols(ctx->dt, ctx->vl[j].w1, ctx->vl[j].n2, ctx->vfold[j].w1, I, C, s));
+  }
+  ctx->vfold_stale = false;
+  return 0;
+}
+
+static int gemm_x(omchat_ctx* ctx, GemmArgs g, hipStream_t s) { return launch_gemm(ctx->dt, g, s); }
+
+// One InternVisionEncoderLayer (modeling_intern_vit.py:210-222) as SIX launches (round 6; TP = 1, RMSNorm tower):
+//   qkv GEMM (A = raw x, W' = Wqkv diag(norm1.w), row scale rstd1 finished per tile from x's slots, epilogue leaves the q / k sum-of-squares slots)
+//   K norm (from its slots; leaves the q sums)   attention (Q normed + scaled where it is loaded)   proj GEMM (+b, *ls1, +x; leaves x's slots)
+//   fc1 GEMM (A = raw x, W' = W1 diag(norm2.w), row scale rstd2 from x's slots, +b, GELU)   fc2 GEMM (+b, *ls2, +x; leaves x's slots)
+// against the round-5 layer's rmsnorm, qkv, q/k norm, attention, proj, rmsnorm, fc1, fc2: two 39 MB norm passes and half of the 79 MB
+// q / k pass are gone, and nothing was added between the GEMMs (a first form with three statistics-finishing launches of 4.8 us each gave
+// the whole gain back: profiles/r06_c).  Numerics: x * rstd is no longer rounded to 16 bits before the product (one rounding FEWER than the reference,
+// N2) and the norm weight is rounded into W' instead of into the activation; the q / k norm keeps the reference's rounding points, its
+// statistics are summed per 64-column block first (fp32 order).  Guarded by the reference goldens and the full-depth oracle fixture.
+static int vit_layer_fused(omchat_ctx* ctx, int j, void* x, int B, bool last, hipStream_t s) {
+  const omchat_config& c = ctx->c;
+  const int C = c.v_hidden, I = c.v_mlp, Cq = ctx->v_Cq, ntok = ctx->v_ntok, M = B * ntok, hd = ctx->v_hd;
+  auto& L = ctx->vl[j];
+  auto& F = ctx->vfold[j];
+  const float qscale = 0.08838834764831845f;      // head_dim ** -0.5 (modeling_intern_vit.py:118), head dim 128
+  int ns_x = 0;
+  if (j == 0) {      // the embeddings came from vit_assemble: one slot
+    TRY(launch_row_sumsq(ctx->dt, x, C, M, C, ctx->vw_stats_x, s));
+    ctx->vw_stats_x_ld_used = 1;
+  }
+  {
+    GemmArgs g{x, C, F.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, nullptr, nullptr, 0, EPI_NONE_STATS, 2, nullptr, 0, -1};
+    // norm1 as the row scale, finished per tile from the slots x's producer left
+    g.rs_stats = ctx->vw_stats_x; g.rs_ld = ctx->vw_stats_x_ld; g.rs_nslots = ctx->vw_stats_x_ld_used; g.rs_dim = C; g.rs_eps = c.v_eps;
+    g.stats = ctx->vw_stats_qk; g.stats_ld = ctx->vw_stats_qk_ld;
+    TRY(gemm_x(ctx, g, s));      // (tile 2: 64-column slots, so q = slots [0, Cq / 64), k = [Cq / 64, 2 Cq / 64))
+  }
+  // K is normalised in place from its slots; the q slots' sum goes to vw_sumsq [M] for the attention kernel's q norm on load
+  const int qs = Cq / 64;
+  TRY(launch_vit_knorm_slots(ctx->dt, (char*)ctx->vw_qkv + (size_t)Cq * 2, 3 * Cq, L.kn, M, Cq, c.v_qk_channels, c.v_eps, ctx->vw_stats_qk, ctx->vw_stats_qk_ld, qs,
+                             ctx->vw_sumsq, s));
+  AttnArgs a{};
+  a.scale = 1.0f;
+  a.Q = ctx->vw_qkv; a.q_sb = (int64_t)ntok * 3 * Cq; a.q_sh = hd; a.q_sr = 3 * Cq;
+  a.K = (const char*)ctx->vw_qkv + (size_t)Cq * 2; a.k_sb = a.q_sb; a.k_sh = hd; a.k_sr = 3 * Cq;
+  a.V = (const char*)ctx->vw_qkv + (size_t)2 * Cq * 2; a.v_sb = a.q_sb; a.v_sh = hd; a.v_sr = 3 * Cq;
+  a.O = ctx->vw_ao; a.o_sb = (int64_t)ntok * Cq; a.o_sh = hd; a.o_sr = Cq;
+  a.batch = B; a.q_heads = c.v_heads; a.kv_heads = c.v_heads; a.Sq = ntok; a.Skv = ntok; a.kv_len = nullptr; a.causal = 0; a.q_pos0 = 0;
+  a.head_dim = hd;
+  a.qn_sumsq = ctx->vw_sumsq; a.qn_stride = 1; a.qn_dim = c.v_qk_channels; a.qn_w = L.qn; a.qn_eps = c.v_eps; a.qn_scale = qscale;
+  TRY(launch_attn_prefill(ctx->dt, a, s));
+  {
+    GemmArgs g{ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID_STATS, 0, nullptr, 0, -1};
+    g.stats = ctx->vw_stats_x; g.stats_ld = ctx->vw_stats_x_ld; g.stats_nslots = &ns_x;
+    TRY(gemm_x(ctx, g, s));
+  }
+  ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
+  {
+    GemmArgs g{x, C, F.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, 0, nullptr, 0, -1};
+    g.rs_stats = ctx->vw_stats_x; g.rs_ld = ctx->vw_stats_x_ld; g.rs_nslots = ns_x; g.rs_dim = C; g.rs_eps = c.v_eps;      // norm2
+    TRY(gemm_x(ctx, g, s));
+  }
+  ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
+  {
+    GemmArgs g{ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, last ? EPI_LS_RESID : EPI_LS_RESID_STATS, 0, nullptr, 0, -1};
+    if (!last) { g.stats = ctx->vw_stats_x; g.stats_ld = ctx->vw_stats_x_ld; g.stats_nslots = &ns_x; }
+    TRY(gemm_x(ctx, g, s));
+    if (!last) ctx->vw_stats_x_ld_used = ns_x;
+  }
+  return 0;
+}
+
 static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hipStream_t s, void** x_out) {
   const omchat_config& c = ctx->c;
   const int C = c.v_hidden, I = c.v_mlp, Cq = ctx->v_Cq, np = ctx->v_np, ntok = ctx->v_ntok, M = B * ntok;
   const bool lead = ctx->tp_rank == 0;
+  const bool fused = g_vit_fused && ctx->tp_size == 1 && c.v_norm_type == 0 && !c.v_no_qk_norm && ctx->v_hd == 128 && Cq % 64 == 0 && Cq / 64 <= 256;
+  if (fused) TRY(ensure_vit_folded(ctx, s));
   // InternVisionEmbeddings.forward (modeling_intern_vit.py:90-102)
   TRY(launch_im2col(ctx->dt, pixels, ctx->vw_cols, B, c.v_image, c.v_patch, ctx->v_kpad, s));
   TRY(gemm(ctx, ctx->vw_cols, ctx->v_kpad, ctx->v_wpatch, ctx->v_kpad, ctx->vw_pe, C, B * np, C, ctx->v_kpad, ctx->v_bpatch, nullptr, nullptr, 0, EPI_NONE, s));
@@ -675,6 +778,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
   void* x = ctx->vw_x;
   void* y = ctx->vw_x2;
   for (int j = 0; j < n_layers; ++j) {
+    if (fused) { TRY(vit_layer_fused(ctx, j, x, B, j + 1 == n_layers, s)); continue; }
     auto& L = ctx->vl[j];
     // InternVisionEncoderLayer.forward (modeling_intern_vit.py:210-222)
     const int hd = ctx->v_hd;

@@ -40,8 +40,15 @@ def test_full_size_tower_determinism_and_batch_independence(eng13b):
     assert a.shape == (3, 1024, 3584) and torch.isfinite(a.float()).all()
     assert torch.equal(a, b)
     one = eng13b.encode_images(px[1:2]); sync()
-    # same arithmetic per row whatever the batch: the GEMM tiles over rows, attention over (tile, head)
-    assert rel(one[0], a[1]) < 1e-6
+    # The same tile in another batch.  The GEMMs tile over rows and the attention over (tile, head), so every dot product is summed in the same
+    # order whatever the batch; since round 6 the statistics of the folded norms are the exception: a row's sum of squares is added up in the
+    # wave-tile grouping of the tile kernel tuned for the problem SIZE (gemm.hip gemm_epilogue), so rstd may differ in its last fp32 bit
+    # between a 1-tile and a 3-tile launch and 45 layers of 16-bit rounding amplify that to the noise of one evaluation (f16 measured 2e-3;
+    # the reference's own GEMM library picks kernels per shape in the same way).  A tile leaking into another would be O(1).
+    assert rel(one[0], a[1]) < {"f16": 5e-3, "bf16": 4e-2}[eng13b.dt_name]
+    # ... and inside ONE launch the tiles are independent bit for bit: the same picture three times gives three identical feature blocks
+    same = eng13b.encode_images(px[1:2].repeat(3, 1, 1, 1)); sync()
+    assert torch.equal(same[0], same[1]) and torch.equal(same[0], same[2])
 
 
 def test_full_size_splice_prefill_decode_consistency(eng13b):
