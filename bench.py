@@ -725,6 +725,7 @@ def main():
     }
     if shard:
         res["shard_of"] = shard
+        res["comm_stats"] = eng.comm_stats()      # sp_reduce_scatters > 0: the sequence-parallel form ran (tools/tp_projection.py prices it)
         res["config"]["parallelism"] = f"rank 0 of tp{shard}, exchanges removed (omchat_allreduce_noop)"
         res["shard_note"] = ("ONE rank's share of a TP group on one GPU: shard shapes and launch sequence, no communication; every *_frac is "
                              "this rank's algorithmic share (1 / N of the FLOPs / bytes) over its own time.  Not a throughput claim.")

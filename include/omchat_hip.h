@@ -291,6 +291,7 @@ int omchat_op_mha_qnorm(int dtype, const void* qkv, int B, int Sq, int H, const 
  * key 44: 1 (default) = the RMSNorm vision tower at TP = 1 runs the fused layer of round 6 (norm1 / norm2 as a row scale of the qkv / fc1 GEMM with the
  * norm weight folded into the GEMM weight, statistics from the producing GEMM's epilogue finished per tile inside the consuming GEMM, q norm on load in the
  * attention kernel, K norm from the qkv epilogue's statistics: six launches), 0 = the eight launches of round 5;
+ * key 45: 1 (default) = sequence-parallel norms under tensor parallelism (omchat_ctx_sp_stats), 0 = one all-reduce per sub-block and replicated norms;
  * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits);
  * key 38: (gate, up) pairs per wave of the batch-1 gate|up GEMV's non-loop norm form: 1 (default: thousands of small workgroups that the dispatcher
  * re-balances over the XCDs; decode 2.650 -> 2.597 ms per token against the loop form), 2, 3 (same bits); 16 x n sets the e4m3 replica's form
@@ -435,6 +436,13 @@ void omchat_peer_destroy(omchat_peer* p);
  * or when the context has no RCCL communicator */
 int omchat_ctx_set_peer(omchat_ctx* ctx, omchat_peer* peer, size_t max_bytes, int all_sizes);
 int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rccl_calls);
+/* Sequence-parallel norms under tensor parallelism (round 6; default on, tuning key 45 = 0 restores the all-reduce form): a row-parallel
+ * projection of the vision tower / the prefill ends in a reduce-scatter over row blocks (rank r receives the summed rows it owns: block r of
+ * ceil(rows / tp_size) rows per chunk), the owner adds the residual and normalises ITS rows, an all-gather hands every rank the normalised
+ * activation; the residual stream stays row-sharded between sub-blocks and is gathered once at the end.  Same link bytes as the all-reduce, the
+ * replicated RMSNorm / LayerNorm work divided by tp_size.  RCCL: ncclReduceScatter / ncclAllGather in place; hook / peer transports emulate both
+ * with all-reduces.  The counters say which form ran. */
+int omchat_ctx_sp_stats(omchat_ctx* ctx, long* reduce_scatters, long* all_gathers);
 /* in-place sum of a caller buffer over the context's tensor-parallel group (same transports as the model's own all-reduces); used for
  * the data-parallel vision tower: every rank encodes its share of the tiles into a zero-filled feature buffer and the sum gathers them */
 int omchat_ctx_allreduce(omchat_ctx* ctx, void* buf, size_t count, int dtype, void* stream);

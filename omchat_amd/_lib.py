@@ -70,6 +70,7 @@ _SIGS = {
     "omchat_op_fold_cols": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "omchat_op_vit_knorm_slots": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _vp]),
     "omchat_op_mha_qnorm": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _f, _f, _vp, _vp]),
+    "omchat_ctx_sp_stats": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "omchat_op_set_tuning": (_i, [_i, _i]),
     "omchat_gemm_tune_load": (_i, [C.c_char_p]),
     "omchat_gemm_tune_dump": (_i, [C.c_char_p]),

@@ -503,6 +503,71 @@ __global__ __launch_bounds__(NORM_THREADS) void vit_knorm_slots_kernel(T* k, int
   }
 }
 
+// Sequence-parallel tensor parallelism (round 6, model.hip gemm_sp): the rows of the residual stream a rank OWNS after the reduce-scatter of a
+// row-parallel projection.  x = T(x + y) in place (y = the 16-bit sum over the ranks of the projection's partials, bias / layer scale already inside
+// them), then xn = RMSNorm(x) * w, or LayerNorm(x) * w + b when b is given, or nothing when w is null -- Qwen2RMSNorm / InternRMSNorm / nn.LayerNorm with
+// the rounding points of rmsnorm_kernel / layernorm_kernel.  One workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void resid16_norm_kernel(T* x, int ldx, const T* y, int ldy, const T* w, const T* b, T* xn, int ldn, int H, float eps) {
+  typedef typename V8<T>::type v8;
+  __shared__ float red[NORM_THREADS / 64];
+  const int row = blockIdx.x;
+  T* xr = x + (size_t)row * ldx;
+  const T* yr = y + (size_t)row * ldy;
+  const int nchunk = H >> 3;
+  float xv[NORM_MAXC][8];
+  float ss = 0.f, sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 a = ld8<T>(xr + c * 8), d = ld8<T>(yr + c * 8);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = rnd<T>(tof(a[j]) + tof(d[j])); xv[i][j] = f; o[j] = fromf<T>(f); ss += f * f; sm += f; }
+      st8<T>(xr + c * 8, o);
+    }
+  }
+  if (!w) return;
+  if (b) {      // LayerNorm (intern_vit_300m NORM2FN): mean, then the variance of the centred values, as layernorm_kernel
+    const float mean = block_sum(sm, red) / (float)H;
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; sv += d * d; }
+      }
+    }
+    const float inv = rsqrtf(block_sum(sv, red) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int c = threadIdx.x + i * NORM_THREADS;
+      if (c < nchunk) {
+        const v8 wv = ld8<T>(w + c * 8), bv = ld8<T>(b + c * 8);
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fromf<T>((xv[i][j] - mean) * inv * tof(wv[j]) + tof(bv[j]));
+        st8<T>(xn + (size_t)row * ldn + c * 8, o);
+      }
+    }
+    return;
+  }
+  const float inv = rsqrtf(block_sum(ss, red) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int c = threadIdx.x + i * NORM_THREADS;
+    if (c < nchunk) {
+      const v8 wv = ld8<T>(w + c * 8);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof(wv[j]) * rnd<T>(xv[i][j] * inv));
+      st8<T>(xn + (size_t)row * ldn + c * 8, o);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void vit_qk_sumsq_kernel(const T* qkv, int ld, int C, float* out) {
   typedef typename V8<T>::type v8;
@@ -842,6 +907,16 @@ int launch_vit_knorm_slots(int dtype, void* k, int ld, const void* wk, int rows,
   if (rows == 0) return 0;
   DISPATCH(dtype, hipLaunchKernelGGL(vit_knorm_slots_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)k, ld, (const T*)wk, C, C_total, eps, stats, stats_ld,
                                      nslots, sumsq_q));
+  OM_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_resid16_norm(int dtype, void* x, int ldx, const void* y, int ldy, const void* w, const void* b, void* xn, int ldn, int rows, int H, float eps,
+                        hipStream_t s) {
+  OM_CHECK(H % 8 == 0 && H <= NORM_THREADS * NORM_MAXC * 8 && ldx % 8 == 0 && ldy % 8 == 0 && (!w || (xn && ldn % 8 == 0)), "H % 8, H <= 16384, ld % 8");
+  if (rows <= 0) return 0;
+  DISPATCH(dtype, hipLaunchKernelGGL(resid16_norm_kernel<T>, dim3(rows), dim3(NORM_THREADS), 0, s, (T*)x, ldx, (const T*)y, ldy, (const T*)w, (const T*)b,
+                                     (T*)xn, ldn, H, eps));
   OM_LAUNCH_CHECK();
   return 0;
 }

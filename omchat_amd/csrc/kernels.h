@@ -134,6 +134,7 @@ void model_set_tp_f32(int v);
 void model_set_pack_replica(int v);
 void model_set_norm_in_gemv(int v);
 void model_set_vit_fused(int v);        // tuning key 44
+void model_set_tp_sp(int v);            // tuning key 45
 // out[r][c] = T(W[r][c] * n[c]): a norm weight folded into the columns of the linear map that follows it (model.hip ensure_vit_folded)
 int launch_fold_cols(int dtype, const void* W, const void* n, void* out, int rows, int cols, hipStream_t s);
 
@@ -149,6 +150,10 @@ int launch_quant_rows_q8(int dtype, const void* x, int ldx, void* y8, int ldy, f
 // decode: x = T(x + T(sum_s part[s])) in place, then xn = rmsnorm(x) * w (w == null: skip the norm).  part fp32 [ks][rows][H]
 int launch_resid_rmsnorm(int dtype, void* x, int ldx, const float* part, int ks, const void* w, void* xn, int ldn, int rows, int H, float eps,
                          hipStream_t s, int pack_nb = 0);
+// sequence-parallel tensor parallelism (round 6): x = T(x + y) in place on `rows` rows (y: the 16-bit sum of a row-parallel projection's partials),
+// then xn = RMSNorm(x) * w (b == null), LayerNorm(x) * w + b, or nothing (w == null)
+int launch_resid16_norm(int dtype, void* x, int ldx, const void* y, int ldy, const void* w, const void* b, void* xn, int ldn, int rows, int H, float eps,
+                        hipStream_t s);
 // ViT joint-head q/k RMSNorm in place on the fused qkv buffer [rows, 3C] (q = cols [0,C), k = [C,2C)); q is also
 // multiplied by q_scale with the reference's rounding (modeling_intern_vit.py:143-148).
 // sumsq_in: optional [rows,2] fp32 externally reduced sum of squares (tensor parallel); C_total = divisor.

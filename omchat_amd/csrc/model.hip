@@ -220,6 +220,10 @@ struct omchat_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_chunk[AR_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_comm_done = nullptr;
+  // sequence-parallel form: the all-gather of row chunk i is done (communication stream); the NEXT column-parallel GEMM is issued per row chunk
+  // behind these events, so the exchange of chunk i + 1 also runs under the consumer's chunk i (gemm_sp / gemm_after_sp)
+  hipEvent_t ev_ag[AR_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+  int sp_pend_nch = 0, sp_pend_rows_per = 0;
   // transports of the tensor-parallel sum, in order of precedence: the test hook; the peer (IPC / xGMI) all-reduce of comm.hip for
   // messages up to peer_max bytes (one-shot: decode-sized) or for every size when there is no RCCL communicator / peer_all is set;
   // RCCL otherwise.  Every buffer passed here is context-owned with >= 16 bytes of slack, so the peer path may round the count up
@@ -257,6 +261,40 @@ struct omchat_ctx {
     }
     if (tp_size > 1) { const int rc = allreduce_any(part, (size_t)ks * rows * H, OMCHAT_F32, s); if (rc) return rc; }
     return launch_resid_rmsnorm(dt, x, ldx, part, ks, w, xn, ldn, rows, H, eps, s, pack_nb);
+  }
+  // Sequence-parallel form (round 6): buf = [tp_size][blk_rows][N] 16-bit rows.  reduce_scatter_rows: afterwards block tp_rank holds the sum over
+  // the ranks (the other blocks are undefined); all_gather_rows: every rank contributes block tp_rank, afterwards all blocks are whole everywhere.
+  // RCCL: ncclReduceScatter / ncclAllGather in place -- together the bytes of ONE all-reduce.  Hook and peer transports (tests; messages under
+  // the one-shot limit) have all-reduce only: reduce-scatter = all-reduce (every block comes back summed), all-gather = zero the foreign blocks, then
+  // all-reduce (x + 0 is exact): the same values, twice the bytes.
+  long n_rs = 0, n_ag = 0;
+  bool sp_native(size_t bytes) const { return !hook && comm && !(peer && (bytes <= peer_max || peer_all)); }
+  int reduce_scatter_rows(void* buf, int blk_rows, int N, hipStream_t s) {
+    if (tp_size == 1) return 0;
+    ++n_rs;
+    const size_t blk = (size_t)blk_rows * N;
+    if (!sp_native(blk * tp_size * 2)) return allreduce_any(buf, blk * tp_size, dt, s);
+    ++n_ar_rccl;
+    ncclResult_t r = ncclReduceScatter(buf, (char*)buf + (size_t)tp_rank * blk * 2, blk, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, ncclSum, comm, s);
+    if (r != ncclSuccess) { omchat_set_error(std::string("ncclReduceScatter: ") + ncclGetErrorString(r)); return 3; }
+    return 0;
+  }
+  int all_gather_rows(void* buf, int blk_rows, int N, hipStream_t s) {
+    if (tp_size == 1) return 0;
+    ++n_ag;
+    const size_t blk = (size_t)blk_rows * N;
+    if (!sp_native(blk * tp_size * 2)) {
+      if (hook == omchat_allreduce_noop) return 0;      // bench.py --shard-of: one rank's compute with the exchanges removed
+      if (tp_rank > 0 && hipMemsetAsync(buf, 0, (size_t)tp_rank * blk * 2, s) != hipSuccess) { omchat_set_error("all_gather_rows: memset"); return 2; }
+      if (tp_rank + 1 < tp_size && hipMemsetAsync((char*)buf + (size_t)(tp_rank + 1) * blk * 2, 0, (size_t)(tp_size - 1 - tp_rank) * blk * 2, s) != hipSuccess) {
+        omchat_set_error("all_gather_rows: memset"); return 2;
+      }
+      return allreduce_any(buf, blk * tp_size, dt, s);
+    }
+    ++n_ar_rccl;
+    ncclResult_t r = ncclAllGather((char*)buf + (size_t)tp_rank * blk * 2, buf, blk, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, comm, s);
+    if (r != ncclSuccess) { omchat_set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r)); return 3; }
+    return 0;
   }
   int allreduce(void* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, dt, s); }
   int allreduce_f32(float* buf, size_t count, hipStream_t s) { return allreduce_any(buf, count, OMCHAT_F32, s); }
@@ -380,9 +418,10 @@ int build(omchat_ctx* ctx) {
     const size_t Bm = (size_t)c.max_tiles, M = Bm * ctx->v_ntok;
     TRY(ctx->alloc(&ctx->vw_cols, Bm * ctx->v_np * ctx->v_kpad * 2));
     TRY(ctx->alloc(&ctx->vw_pe, Bm * ctx->v_np * C * 2));
-    TRY(ctx->alloc(&ctx->vw_x, M * C * 2));
-    TRY(ctx->alloc(&ctx->vw_x2, M * C * 2));
-    TRY(ctx->alloc(&ctx->vw_xn, M * C * 2));
+    const size_t SL = 64;      // row slack: the last row block of a sequence-parallel reduce-scatter reaches up to tp_size - 1 rows beyond M
+    TRY(ctx->alloc(&ctx->vw_x, (M + SL) * C * 2));
+    TRY(ctx->alloc(&ctx->vw_x2, (M + SL) * C * 2));
+    TRY(ctx->alloc(&ctx->vw_xn, (M + SL) * C * 2));
     TRY(ctx->alloc(&ctx->vw_qkv, M * 3 * ctx->v_Cq * 2));
     TRY(ctx->alloc(&ctx->vw_ao, M * ctx->v_Cq * 2));
     TRY(ctx->alloc(&ctx->vw_h, M * I * 2));
@@ -397,9 +436,9 @@ int build(omchat_ctx* ctx) {
   }
   if (c.t_layers > 0) {
     const size_t R = std::max<size_t>(32, (size_t)(c.max_prefill_rows > c.max_batch ? c.max_prefill_rows : c.max_batch));      // >= 32: packed decode operands
-    TRY(ctx->alloc(&ctx->tw_x, R * H * 2));
-    TRY(ctx->alloc(&ctx->tw_x2, R * H * 2));
-    TRY(ctx->alloc(&ctx->tw_xn, R * H * 2));
+    TRY(ctx->alloc(&ctx->tw_x, (R + 64) * H * 2));       // (+ 64 rows: slack of the sequence-parallel row blocks, see vw_x)
+    TRY(ctx->alloc(&ctx->tw_x2, (R + 64) * H * 2));
+    TRY(ctx->alloc(&ctx->tw_xn, (R + 64) * H * 2));
     TRY(ctx->alloc(&ctx->tw_qkv, R * ctx->t_qkvdim * 2));
     TRY(ctx->alloc(&ctx->tw_ao, R * ctx->t_qdim * 2));
     TRY(ctx->alloc(&ctx->tw_act, R * It * 2));
@@ -492,6 +531,7 @@ extern "C" int omchat_ctx_create(const omchat_config* cfg, int tp_rank, int tp_s
     auto mk = [&]() -> int {
       OM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
       for (auto& e : ctx->ev_chunk) OM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto& e : ctx->ev_ag) OM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       OM_HIP(hipEventCreateWithFlags(&ctx->ev_comm_done, hipEventDisableTiming));
       return 0;
     };
@@ -514,6 +554,7 @@ extern "C" void omchat_ctx_destroy(omchat_ctx* ctx) {
   if (ctx->graph_ev_out) (void)hipEventDestroy(ctx->graph_ev_out);
   if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
   for (hipEvent_t e : ctx->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_ag) if (e) (void)hipEventDestroy(e);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
   if (ctx->tp_f32_ws) (void)hipFree(ctx->tp_f32_ws);
   if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
@@ -677,6 +718,114 @@ static int gemm_allreduce(omchat_ctx* ctx, const void* A, int lda, const void* W
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sequence-parallel norms (round 6; tuning key 45, default on under tensor parallelism).  The all-reduce form above leaves the WHOLE residual
+// stream on every rank, and every rank then normalises all M rows: RMSNorm (2 x 88 us per ViT layer at 24 tiles) does not shrink with the group
+// size -- 16 % of a TP = 8 ViT layer (profiles/r03_a).  Here a row-parallel projection ends in a reduce-scatter over ROW BLOCKS: rank r receives the
+// summed rows it owns, adds the residual and normalises THOSE rows (M / tp_size of them, one launch), and an all-gather hands every rank the
+// normalised activation the next column-parallel GEMM needs.  Same bytes on the links as the all-reduce (reduce-scatter + all-gather ARE its two
+// halves), the replicated norm work divided by the group size.  The residual stream itself stays row-sharded between sub-blocks (rank r's copy is
+// current on its own rows only) and is gathered once at the end of the tower / the prefill.  Megatron-LM's sequence parallelism restricted to the
+// norms: the GEMMs and the attention keep their head / column shards.  No reference counterpart (builder.py:22-25 is device_map="auto").
+//   rows of a chunk [r0, r0 + rows): block = cdiv(rows, tp_size) rows per rank; rank r owns [r0 + r * block, r0 + min((r + 1) * block, rows))
+//   partials: every rank T(T(acc + (rank 0 ? bias : 0)) * ls) (ViT) or T(acc) (decoder); the owner adds the residual AFTER the sum -- one rounding
+//   point moved against the all-reduce form (rank 0 added it before), inside the evaluation-order noise of 16-bit TP
+// ---------------------------------------------------------------------------------------------------------
+int g_tp_sp = 1;
+void model_set_tp_sp(int v) { g_tp_sp = v; }
+
+struct SpPlan { int nch, rows_per; };
+static SpPlan sp_plan(omchat_ctx* ctx, int M, int N) {      // the chunk rule of gemm_allreduce (a chunk must still fill the GPU)
+  int nch = M >= 3 * g_ar_min_rows ? 4 : (M >= g_ar_min_rows ? 2 : 1);
+  if (!ctx->comm_stream) nch = 1;
+  if (g_ar_min_rows >= 256) {
+    const int n_cu = device_cus();
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+    while (nch > 1 && tiles / nch < n_cu) nch >>= 1;
+  }
+  const int unit = 8 * ctx->tp_size;                                    // whole row blocks inside every chunk but the last
+  const int align = g_ar_min_rows >= 256 ? cdiv(256, unit) * unit : unit;
+  const int rows_per = nch == 1 ? M : cdiv(cdiv(M, nch), align) * align;
+  return {nch, rows_per};
+}
+
+// x (the residual stream, current on this rank's rows) <- x + sum over ranks of epi'(A W^T);  xn <- norm(x) on every row of every rank (nw == null: none)
+static int gemm_sp(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* P, void* x, int N, int M, int K, const void* bias_all, const void* ls,
+                   int epi, const void* nw, const void* nb, void* xn, float eps, hipStream_t s) {
+  const bool lead = ctx->tp_rank == 0;
+  const SpPlan pl = sp_plan(ctx, M, N);
+  const bool pipe = pl.nch > 1;
+  hipStream_t cs = pipe ? ctx->comm_stream : s;
+  int i = 0;
+  for (int r0 = 0; r0 < M; r0 += pl.rows_per, ++i) {
+    const int rows = std::min(pl.rows_per, M - r0);
+    const int blk = cdiv(rows, ctx->tp_size);
+    char* p = (char*)P + (size_t)r0 * N * 2;
+    // the partial: bias on rank 0 only, layer scale on every rank (it distributes over the sum), NO residual
+    TRY(gemm(ctx, (const char*)A + (size_t)r0 * lda * 2, lda, W, ldw, p, N, rows, N, K, lead ? bias_all : nullptr, ls, nullptr, 0,
+             epi == EPI_LS_RESID ? EPI_LS_RESID : EPI_NONE, s));
+    if (pipe) {
+      OM_HIP(hipEventRecord(ctx->ev_chunk[i], s));
+      OM_HIP(hipStreamWaitEvent(cs, ctx->ev_chunk[i], 0));
+    }
+    TRY(ctx->reduce_scatter_rows(p, blk, N, cs));
+    const int o0 = ctx->tp_rank * blk, on = std::max(0, std::min(blk, rows - o0));      // my rows of this chunk
+    char* xo = (char*)x + (size_t)(r0 + o0) * N * 2;
+    char* no = nw ? (char*)xn + (size_t)(r0 + o0) * N * 2 : nullptr;
+    TRY(launch_resid16_norm(ctx->dt, xo, N, p + (size_t)o0 * N * 2, N, nw, nb, no, N, on, N, eps, cs));
+    if (nw) TRY(ctx->all_gather_rows((char*)xn + (size_t)r0 * N * 2, blk, N, cs));
+    if (pipe && nw) OM_HIP(hipEventRecord(ctx->ev_ag[i], cs));
+  }
+  if (pipe && nw) {
+    // the launch stream does NOT wait here: the consumer of xn (the next column-parallel GEMM: gemm_after_sp) goes out per row chunk behind
+    // ev_ag[i], so chunk i + 1's reduce-scatter / norm / all-gather also runs under the consumer's GEMM of chunk i
+    ctx->sp_pend_nch = pl.nch; ctx->sp_pend_rows_per = pl.rows_per;
+  } else if (pipe) {
+    OM_HIP(hipEventRecord(ctx->ev_comm_done, cs));
+    OM_HIP(hipStreamWaitEvent(s, ctx->ev_comm_done, 0));
+  }
+  return 0;
+}
+
+// every exchange of a pending sequence-parallel sub-block is behind the launch stream (no consumer took it chunk by chunk)
+static int sp_drain(omchat_ctx* ctx, hipStream_t s) {
+  for (int i = 0; i < ctx->sp_pend_nch; ++i) OM_HIP(hipStreamWaitEvent(s, ctx->ev_ag[i], 0));
+  ctx->sp_pend_nch = 0;
+  return 0;
+}
+
+// C = epi(A W^T + bias) where A [M, lda] is the normalised activation a sequence-parallel sub-block is still gathering: one GEMM per row chunk of
+// its plan, each behind that chunk's all-gather (a chunk holds >= 256 tiles of the producer, so the consumer's chunk fills the GPU too)
+static int gemm_after_sp(omchat_ctx* ctx, const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias, int epi,
+                         hipStream_t s) {
+  // a consumer chunk must hold two whole rounds of tiles: below that the partial last round of every chunk costs more than the exchange it hides
+  // (bench.py --shard-of 4, configs[2]: the ViT's fc1 as four chunks of 312 tiles 380 ms per rank against 372 with one launch)
+  const long chunk_tiles = (long)cdiv(ctx->sp_pend_rows_per, 256) * cdiv(N, 256);
+  if (ctx->sp_pend_nch <= 1 || chunk_tiles < 2L * device_cus()) {
+    TRY(sp_drain(ctx, s));
+    return gemm(ctx, A, lda, W, ldw, C, ldc, M, N, K, bias, nullptr, nullptr, 0, epi, s);
+  }
+  const int nch = ctx->sp_pend_nch, rows_per = ctx->sp_pend_rows_per;
+  ctx->sp_pend_nch = 0;
+  int i = 0;
+  for (int r0 = 0; r0 < M; r0 += rows_per, ++i) {
+    const int rows = std::min(rows_per, M - r0);
+    OM_HIP(hipStreamWaitEvent(s, ctx->ev_ag[i < nch ? i : nch - 1], 0));
+    TRY(gemm(ctx, (const char*)A + (size_t)r0 * lda * 2, lda, W, ldw, (char*)C + (size_t)r0 * ldc * 2, ldc, rows, N, K, bias, nullptr, nullptr, 0, epi, s));
+  }
+  return 0;
+}
+
+// the row-sharded residual stream made whole on every rank (end of the tower / of the prefill): one all-gather per chunk of the same plan
+static int sp_gather_x(omchat_ctx* ctx, void* x, int N, int M, hipStream_t s) {
+  const SpPlan pl = sp_plan(ctx, M, N);
+  for (int r0 = 0; r0 < M; r0 += pl.rows_per) {
+    const int rows = std::min(pl.rows_per, M - r0);
+    TRY(ctx->all_gather_rows((char*)x + (size_t)r0 * N * 2, cdiv(rows, ctx->tp_size), N, s));
+  }
+  return 0;
+}
+
 int g_vit_fused = 1;      // omchat_op_set_tuning key 44: 1 = the ViT layer with its norms folded into the GEMMs (round 6), 0 = the round-5 launches
 void model_set_vit_fused(int v) { g_vit_fused = v; }
 
@@ -777,6 +926,7 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
   TRY(launch_vit_assemble(ctx->dt, ctx->vw_pe, ctx->v_cls, ctx->v_pos, ctx->vw_x, B, np, C, s));
   void* x = ctx->vw_x;
   void* y = ctx->vw_x2;
+  const bool sp = g_tp_sp && ctx->tp_size > 1 && !g_tp_f32;      // sequence-parallel norms: gemm_sp
   for (int j = 0; j < n_layers; ++j) {
     if (fused) { TRY(vit_layer_fused(ctx, j, x, B, j + 1 == n_layers, s)); continue; }
     auto& L = ctx->vl[j];
@@ -787,8 +937,9 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
       if (c.v_norm_type == 1) return launch_layernorm(ctx->dt, x, C, w, b, ctx->vw_xn, C, M, C, c.v_eps, s);
       return launch_rmsnorm(ctx->dt, x, C, w, ctx->vw_xn, C, M, C, c.v_eps, s);
     };
-    TRY(norm(L.n1, L.n1b));
-    TRY(gemm(ctx, ctx->vw_xn, C, L.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, nullptr, nullptr, 0, EPI_NONE, s));
+    if (!sp || j == 0) TRY(norm(L.n1, L.n1b));      // (sequence-parallel: the previous layer's fc2 left norm1(x) in vw_xn)
+    if (sp) TRY(gemm_after_sp(ctx, ctx->vw_xn, C, L.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, EPI_NONE, s));
+    else TRY(gemm(ctx, ctx->vw_xn, C, L.wqkv, C, ctx->vw_qkv, 3 * Cq, M, 3 * Cq, C, nullptr, nullptr, nullptr, 0, EPI_NONE, s));
     AttnArgs a{};
     if (!c.v_no_qk_norm) {
       const float* sumsq = nullptr;
@@ -811,21 +962,30 @@ static int vit_run(omchat_ctx* ctx, const void* pixels, int B, int n_layers, hip
     TRY(launch_attn_prefill(ctx->dt, a, s));
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_ao, Cq, L.wproj, Cq, x, C, M, C, Cq, L.bproj, L.ls1, x, C, EPI_LS_RESID, s));
+    } else if (sp) {
+      TRY(gemm_sp(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, x, C, M, Cq, L.bproj, L.ls1, EPI_LS_RESID, L.n2, L.n2b, ctx->vw_xn, c.v_eps, s));
     } else {
       TRY(gemm_allreduce(ctx, ctx->vw_ao, Cq, L.wproj, Cq, y, C, M, Cq, L.bproj, L.ls1, x, EPI_LS_RESID, s));
       std::swap(x, y);
     }
-    TRY(norm(L.n2, L.n2b));
+    if (!sp) TRY(norm(L.n2, L.n2b));
     ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
-    TRY(gemm(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, s));
+    if (sp) TRY(gemm_after_sp(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, EPI_GELU, s));
+    else TRY(gemm(ctx, ctx->vw_xn, C, L.w1, C, ctx->vw_h, I, M, I, C, L.b1, nullptr, nullptr, 0, EPI_GELU, s));
     ctx->prof_mark(OMCHAT_PROF_VIT_FC1, s);
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->vw_h, I, L.w2, I, x, C, M, C, I, L.b2, L.ls2, x, C, EPI_LS_RESID, s));
+    } else if (sp) {
+      const bool more = j + 1 < n_layers;      // the next layer's norm1 on the owned rows; after the last layer the stream is gathered instead
+      TRY(gemm_sp(ctx, ctx->vw_h, I, L.w2, I, y, x, C, M, I, L.b2, L.ls2, EPI_LS_RESID, more ? ctx->vl[j + 1].n1 : nullptr, more ? ctx->vl[j + 1].n1b : nullptr,
+                  ctx->vw_xn, c.v_eps, s));
+      if (!more) TRY(sp_gather_x(ctx, x, C, M, s));
     } else {
       TRY(gemm_allreduce(ctx, ctx->vw_h, I, L.w2, I, y, C, M, I, L.b2, L.ls2, x, EPI_LS_RESID, s));
       std::swap(x, y);
     }
   }
+  TRY(sp_drain(ctx, s));
   *x_out = x;
   return 0;
 }
@@ -1103,6 +1263,8 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
   void* x = ctx->tw_x;
   void* y = ctx->tw_x2;
   OM_HIP(hipMemcpyAsync(x, embeds, (size_t)rows * H * 2, hipMemcpyDeviceToDevice, s));
+  // sequence-parallel norms (gemm_sp): not with the fp8 prefill (its norm writes e4m3 + scales) nor with fp32 partial sums (tuning key 29)
+  const bool sp = g_tp_sp && ctx->tp_size > 1 && !g_tp_f32 && !(ctx->fp8_prefill && !ctx->dl8.empty() && !ctx->fp8_stale);
   for (int i = 0; i < c.t_layers; ++i) {
     auto& L = ctx->dl[i];
     char* kc = (char*)ctx->kcache + (size_t)i * ctx->cache_layer_stride() * 2;
@@ -1119,8 +1281,9 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
       TRY(launch_rmsnorm_q8(ctx->dt, x, H, L.ln1, ctx->tw_q8, H, ctx->tw_q8s, rows, H, c.t_eps, s));
       TRY(gemm_f8(ctx->dl8[i].wqkv, ctx->dl8[i].sqkv, ctx->tw_qkv, qkvd, qkvd, L.bqkv, EPI_NONE));
     } else {
-      TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, rows, H, c.t_eps, s));
-      TRY(gemm(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, nullptr, nullptr, 0, EPI_NONE, s));
+      if (!sp || i == 0) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln1, ctx->tw_xn, H, rows, H, c.t_eps, s));      // (sequence-parallel: down_proj of layer i - 1 left it)
+      if (sp) TRY(gemm_after_sp(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, EPI_NONE, s));
+      else TRY(gemm(ctx, ctx->tw_xn, H, L.wqkv, H, ctx->tw_qkv, qkvd, rows, qkvd, H, L.bqkv, nullptr, nullptr, 0, EPI_NONE, s));
     }
     RopeArgs r{ctx->tw_qkv, qkvd, rows, S, c.t_heads, c.t_kv_heads, nullptr, 0, ctx->rope, c.max_seq, kc, vc, ctx->cache_sb(), ctx->cache_sh()};
     TRY(launch_rope_kv(ctx->dt, r, s));
@@ -1139,23 +1302,31 @@ static int prefill_impl(omchat_ctx* ctx, const void* embeds, int b, int S, const
     if (left && ctx->tp_size == 1) TRY(launch_attn_uniform_rows(ctx->dt, a, s));
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_ao, qd, L.wo, qd, x, H, rows, H, qd, nullptr, nullptr, x, H, EPI_RESID, s));
+    } else if (sp) {
+      TRY(gemm_sp(ctx, ctx->tw_ao, qd, L.wo, qd, y, x, H, rows, qd, nullptr, nullptr, EPI_RESID, L.ln2, nullptr, ctx->tw_xn, c.t_eps, s));
     } else {
       TRY(gemm_allreduce(ctx, ctx->tw_ao, qd, L.wo, qd, y, H, rows, qd, nullptr, nullptr, x, EPI_RESID, s));
       std::swap(x, y);
     }
     if (f8p) TRY(launch_rmsnorm_q8(ctx->dt, x, H, L.ln2, ctx->tw_q8, H, ctx->tw_q8s, rows, H, c.t_eps, s));
-    else TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
+    else if (!sp) TRY(launch_rmsnorm(ctx->dt, x, H, L.ln2, ctx->tw_xn, H, rows, H, c.t_eps, s));
     ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
     if (f8p) TRY(gemm_f8(ctx->dl8[i].wgu, ctx->dl8[i].sgu, ctx->tw_act, It, 2 * It, nullptr, EPI_SWIGLU));
+    else if (sp) TRY(gemm_after_sp(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, EPI_SWIGLU, s));
     else TRY(gemm(ctx, ctx->tw_xn, H, L.wgu, H, ctx->tw_act, It, rows, 2 * It, H, nullptr, nullptr, nullptr, 0, EPI_SWIGLU, s));
     ctx->prof_mark(OMCHAT_PROF_PREFILL_GATEUP, s);
     if (ctx->tp_size == 1) {
       TRY(gemm(ctx, ctx->tw_act, It, L.wd, It, x, H, rows, H, It, nullptr, nullptr, x, H, EPI_RESID, s));
+    } else if (sp) {
+      const bool more = i + 1 < c.t_layers;
+      TRY(gemm_sp(ctx, ctx->tw_act, It, L.wd, It, y, x, H, rows, It, nullptr, nullptr, EPI_RESID, more ? ctx->dl[i + 1].ln1 : nullptr, nullptr, ctx->tw_xn, c.t_eps, s));
+      if (!more) TRY(sp_gather_x(ctx, x, H, rows, s));
     } else {
       TRY(gemm_allreduce(ctx, ctx->tw_act, It, L.wd, It, y, H, rows, It, nullptr, nullptr, x, EPI_RESID, s));
       std::swap(x, y);
     }
   }
+  TRY(sp_drain(ctx, s));
   if (hidden_out) TRY(launch_rmsnorm(ctx->dt, x, H, ctx->t_norm, hidden_out, H, rows, H, c.t_eps, s));
   if (logits_last) {
     // only the last valid position feeds generation (Qwen2ForCausalLM.forward :462-465 projects all; same values)
@@ -1678,6 +1849,14 @@ extern "C" int omchat_ctx_comm_stats(omchat_ctx* ctx, long* peer_calls, long* rc
   OM_CHECK(ctx, "null ctx");
   if (peer_calls) *peer_calls = ctx->n_ar_peer + ctx->n_fused_norm;
   if (rccl_calls) *rccl_calls = ctx->n_ar_rccl;
+  return 0;
+}
+
+// sequence-parallel exchanges so far: reduce-scatters and all-gathers over row blocks (model.hip gemm_sp; 0 / 0 = the all-reduce form ran)
+extern "C" int omchat_ctx_sp_stats(omchat_ctx* ctx, long* reduce_scatters, long* all_gathers) {
+  OM_CHECK(ctx, "null ctx");
+  if (reduce_scatters) *reduce_scatters = ctx->n_rs;
+  if (all_gathers) *all_gathers = ctx->n_ag;
   return 0;
 }
 

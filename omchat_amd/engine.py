@@ -146,7 +146,9 @@ class Engine:
     def comm_stats(self):
         a, b = C.c_long(0), C.c_long(0)
         check(self.lib.omchat_ctx_comm_stats(self.h, C.byref(a), C.byref(b)))
-        return dict(peer_allreduces=a.value, rccl_allreduces=b.value)
+        rs, ag = C.c_long(0), C.c_long(0)
+        check(self.lib.omchat_ctx_sp_stats(self.h, C.byref(rs), C.byref(ag)))
+        return dict(peer_allreduces=a.value, rccl_allreduces=b.value, sp_reduce_scatters=rs.value, sp_all_gathers=ag.value)
 
     def enable_fp8_decode(self, on=True):
         """Weight-only OCP e4m3 replica of the decode-streamed decoder weights (quantised on first call); batch-1 decode only."""
