@@ -801,7 +801,7 @@ static int gemm_after_sp(omchat_ctx* ctx, const void* A, int lda, const void* W,
   // a consumer chunk must hold two whole rounds of tiles: below that the partial last round of every chunk costs more than the exchange it hides
   // (bench.py --shard-of 4, configs[2]: the ViT's fc1 as four chunks of 312 tiles 380 ms per rank against 372 with one launch)
   const long chunk_tiles = (long)cdiv(ctx->sp_pend_rows_per, 256) * cdiv(N, 256);
-  if (ctx->sp_pend_nch <= 1 || chunk_tiles < 2L * device_cus()) {
+  if (ctx->sp_pend_nch <= 1 || (g_ar_min_rows >= 256 && chunk_tiles < 2L * device_cus())) {      // (tests lower g_ar_min_rows: the rule is skipped there)
     TRY(sp_drain(ctx, s));
     return gemm(ctx, A, lda, W, ldw, C, ldc, M, N, K, bias, nullptr, nullptr, 0, epi, s);
   }

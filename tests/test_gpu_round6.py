@@ -219,3 +219,64 @@ def test_fused_vit_layer_equals_the_round5_launches_within_one_op_tolerance(gpu_
         assert rel(outs[key][0], ref) < TOL_DEEP[dt], (key, rel(outs[key][0], ref))
     assert rel(outs[1][0], outs[0][0]) < TOL_DEEP[dt]
     assert rel(outs[1][1], outs[0][1]) < TOL_DEEP[dt]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sequence-parallel norms under tensor parallelism (model.hip gemm_sp, tuning key 45)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("min_rows", [0, 8])
+def test_tp2_sequence_parallel_norms_vs_all_reduce_form_and_oracle(gpu_lib, dt, min_rows):
+    """two rank contexts on one GPU (the hook harness of test_gpu_tp_single.py): the tower and the prefill with the row-parallel projections ending
+    in reduce-scatter -> residual + norm on the owned rows -> all-gather (counters say the form ran; min_rows = 8: several row chunks on the
+    communication stream, the consumer GEMMs behind the per-chunk gather events) against the all-reduce form (key 45 = 0) and the oracle; ragged
+    row blocks: 2 tiles x 17 tokens = 34 tower rows, 38 prefill rows over 2 ranks"""
+    import ctypes as C
+    import oracle
+    from omchat_amd import synth
+    from omchat_amd.config import tiny
+    from omchat_amd.engine import Engine
+    from gpu_util import TOL_DEEP
+    from test_gpu_tp_single import Group, _run_ranks, T32
+    cfg = tiny(q_heads=4, kv_heads=2, heads_v=3)
+    sd = synth.state_dict(cfg, 13)
+    px = T32(synth.pixels(2, 56, 1))
+    ids = torch.tensor([[3, -200, 17, -200, 19, 20, 21]])
+    res = {}
+    try:
+        if min_rows:
+            gpu_lib.omchat_op_set_tuning(4, min_rows)
+        for key in (1, 0):
+            gpu_lib.omchat_op_set_tuning(45, key)
+            grp = Group(2)
+            engines, hooks = [], []
+            for r in range(2):
+                e = Engine(cfg, dtype=dt, max_seq=128, max_batch=1, max_tiles=2, tp_rank=r, tp_size=2, comm=C.c_void_p(1))
+                h = grp.hook_for(r)
+                _lib.check(gpu_lib.omchat_set_allreduce_hook(e.h, C.cast(h, C.c_void_p), None))
+                e.load_state_dict(sd)
+                engines.append(e); hooks.append(h)
+
+            def run(r):
+                e = engines[r]
+                feats = e.encode_images(px)
+                embeds, lengths, _ = e.splice(ids, None, feats)
+                logits, hid = e.prefill(embeds, lengths, want_hidden=True)
+                torch.cuda.synchronize()
+                return feats.float().cpu(), logits.float().cpu(), hid.float().cpu()
+            out = _run_ranks(run, 2)
+            st = engines[0].comm_stats()
+            assert (st["sp_reduce_scatters"] > 0) == (key == 1) and (st["sp_all_gathers"] > 0) == (key == 1), st
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2])      # both ranks hold the same gathered stream
+            res[key] = out[0]
+            for e in engines:
+                e.close()
+    finally:
+        gpu_lib.omchat_op_set_tuning(45, 1)
+        gpu_lib.omchat_op_set_tuning(4, 1024)
+    sdt = {k: T32(v) for k, v in sd.items()}
+    ref_feats = oracle.encode_images(px, sdt, cfg.vision)
+    for key in (1, 0):
+        assert rel(res[key][0], ref_feats) < TOL_DEEP[dt], (key, rel(res[key][0], ref_feats))
+    # the two forms differ by where the residual joins the sum (one rounding point): equal within one multi-layer tolerance
+    assert rel(res[1][0], res[0][0]) < TOL_DEEP[dt] and rel(res[1][2], res[0][2]) < TOL_DEEP[dt]
