@@ -36,6 +36,7 @@ struct GemmP {
   // the row scale finished INSIDE the launch from the producer's statistics slots: rstd[m] = rsqrt(sum_{s < rs_nslots} rs_stats[m][s] * rs_inv_dim + rs_eps),
   // computed once per tile into LDS after the K loop (no finishing launch between the producing GEMM and this one); slot-major: rs_stats[s * rs_ld + m]
   const float* rs_stats; int rs_ld, rs_nslots; float rs_inv_dim, rs_eps;
+  int rs_dma;                                      // 1: the tile's slots are fetched by LDS-DMA BEFORE the K loop into the LDS behind the stage buffers
 };
 
 // Workgroup -> tile.  (1) bijective XCD remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
@@ -287,12 +288,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MR][N
 // rstd of the tile's BM rows from the producer's statistics slots, into LDS (the stage buffers are dead: every wave is behind its last LDS read).
 // Two threads per row take the even / the odd slots -- all of a thread's loads are requested before the first add -- and meet by one lane swap:
 // a fixed order.  Returns with a workgroup barrier behind the LDS writes.
+// The slots of the tile's BM rows requested by LDS-DMA at the START of the kernel (no registers, nothing to wait for): they land in the LDS behind
+// the stage buffers, Ls[slot * BM + r], while the K loop runs -- the K loop's first counted vmcnt wait retires them, they are older than its own
+// loads.  (Fetched after the K loop they were a cold round trip at the end of every tile of every round: +8 us on the ViT's fc1, +10 on its qkv.)
 template <int BM, int NT>
-__device__ __forceinline__ void tile_row_scale(const GemmP& p, int m0, float* L) {
+__device__ __forceinline__ void tile_row_scale_prefetch(const GemmP& p, int m0, float* Ls) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  constexpr int G = (BM + 63) / 64;                    // 64-row groups of the tile
+  for (int pc = wave; pc < p.rs_nslots * G; pc += NT / 64) {
+    const int sl = pc / G, g = pc - sl * G;
+    int r = g * 64 + lane; r = r < BM ? r : BM - 1;   // (a last partial group re-reads the tile's last row: in-bounds, unused)
+    int row = m0 + r; row = row < p.M ? row : p.M - 1;
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.rs_stats + (size_t)sl * p.rs_ld + row), (lptr_t)(Ls + sl * (G * 64) + g * 64), 4, 0, 0);
+  }
+}
+
+template <int BM, int NT>
+__device__ __forceinline__ void tile_row_scale(const GemmP& p, int m0, float* L, const float* Ls) {
   // slot-major statistics [slot][rs_ld]: a thread walks the slots of ONE row, so every load of a wave is one contiguous 256-byte run (a first form
   // with row-major slots -- 32 rows per load instruction -- cost the qkv GEMM 11 us per launch: profiles/r06_c).  Two threads per row when the
-  // workgroup has them: the first / the second half of the slots, each in slot order, halves added last -- ONE fixed order for every tile kernel.
+  // workgroup has them: the first / the second half of the slots, each in slot order, halves added last -- ONE fixed order for every tile kernel
+  // and for both sources (Ls != null: the slots were prefetched into LDS, Ls[slot * G64 + r]).
   constexpr int TPR = NT >= 2 * BM ? 2 : 1;
+  constexpr int G64 = (BM + 63) / 64 * 64;
   const int tid = threadIdx.x, h = tid / BM, r = tid % BM;
   if (h < TPR) {
     int row = m0 + r; row = row < p.M ? row : p.M - 1;
@@ -302,7 +320,7 @@ __device__ __forceinline__ void tile_row_scale(const GemmP& p, int m0, float* L)
     for (int c0 = s0; c0 < s1; c0 += 16) {
       float v[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = c0 + k < s1 ? base[(size_t)(c0 + k) * p.rs_ld] : 0.f;
+      for (int k = 0; k < 16; ++k) v[k] = c0 + k < s1 ? (Ls ? Ls[(c0 + k) * G64 + r] : base[(size_t)(c0 + k) * p.rs_ld]) : 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += v[k];
     }
@@ -388,6 +406,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
     for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / 64;
+  float* const rs_ls = reinterpret_cast<float*>(smem + 2 * STAGE);      // behind the two stages (launch_cfg requests the bytes when rs_dma)
+  if (p.rs_stats && p.rs_dma) tile_row_scale_prefetch<BM, NT>(p, m0, rs_ls);
   // ragged M (round 6, same rule as gemm8_segment): a wave whose rows all lie beyond M reads no operands and issues no MFMA
   const bool wave_live = !p.skip_dead || m0 + wm * WTM < p.M;
   stage(0, 0);
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmP p) {
   const float* rs_lds = nullptr;
   if (p.rs_stats) {        // wave-uniform; the barrier in front: a faster wave must not overwrite a stage another wave still reads
     __syncthreads();
-    tile_row_scale<BM, NT>(p, m0, reinterpret_cast<float*>(smem));
+    tile_row_scale<BM, NT>(p, m0, reinterpret_cast<float*>(smem), p.rs_dma ? rs_ls : nullptr);
     rs_lds = reinterpret_cast<const float*>(smem) + wm * WTM;
   }
   gemm_epilogue<T, MR, NR, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fg, fr, rs_lds);
@@ -636,6 +656,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
     const int d = (id & 3) + ((id >> 2) & 3);
     for (int i = 0; i < d * skew; ++i) __builtin_amdgcn_s_sleep(16);
   }
+  float* const rs_ls = reinterpret_cast<float*>(smem + 2 * 4 * 128 * 128);      // behind the stage buffers (launch_cfg8 requests the bytes when rs_dma)
+  if (p.rs_stats && p.rs_dma) tile_row_scale_prefetch<256, 512>(p, m0, rs_ls);
   f32x4 acc[8][4];
   gemm8_segment<T, F8>(p, m0, n0, 0, p.K / (F8 ? 128 : 64), smem, acc);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmP p, int skew) {
   const float* rs_lds = nullptr;
   if (p.rs_stats) {        // wave-uniform (gemm8_segment returns with every LDS read of both wave groups retired)
     __syncthreads();
-    tile_row_scale<256, 512>(p, m0, reinterpret_cast<float*>(smem));
+    tile_row_scale<256, 512>(p, m0, reinterpret_cast<float*>(smem), p.rs_dma ? rs_ls : nullptr);
     rs_lds = reinterpret_cast<const float*>(smem) + wm * 128;
   }
   gemm_epilogue<T, 8, 4, EPI, F8>(p, acc, m0 + wm * 128, n0 + wn * 64, fg, fr, rs_lds);
@@ -790,13 +812,17 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   static PerDeviceOnce attr_set;
   const int n_cu = device_cus();
   if (attr_set.first()) {
-    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      // stage buffers + prefetched row statistics
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps, 0};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   if (a.stats_nslots) *a.stats_nslots = cdiv(a.N, 64);      // one slot per 64-column wave tile
+  // row statistics through LDS-DMA when the tile's slots fit behind the stage buffers (160 KiB per workgroup): 29 slots x 256 rows = 29 KiB
+  const int rs_bytes = a.rs_stats ? a.rs_nslots * 256 * 4 : 0;
+  p.rs_dma = rs_bytes > 0 && LDS + rs_bytes <= 160 * 1024;
+  const int lds_main = p.rs_dma ? LDS + rs_bytes : LDS;
   const int KT = a.K / 64;
   const int G = n_cu < SK_MAX_WG ? n_cu : SK_MAX_WG;
   int R = tiles % G;
@@ -809,7 +835,7 @@ int launch_cfg8(const GemmArgs& a, hipStream_t stream) {
   if (!use_sk) R = 0;
   const int n_dp = tiles - R;
   if (n_dp > G && g_gemm_persist && R == 0 && G >= 8 && !a.rs_stats) hipLaunchKernelGGL(kern_p, dim3(G & ~7), dim3(512), LDS, stream, p, n_dp);
-  else if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), LDS, stream, p, g_gemm_skew);
+  else if (n_dp > 0) hipLaunchKernelGGL(kern, dim3(n_dp), dim3(512), lds_main, stream, p, g_gemm_skew);
   if (R > 0) {
     unsigned* flags = reinterpret_cast<unsigned*>((char*)a.sk_ws + (size_t)G * SK_SLAB_BYTES);
     OM_HIP(hipMemsetAsync(flags, 0, 4096, stream));
@@ -831,7 +857,7 @@ int launch_cfg8_f8(const GemmArgs& a, hipStream_t stream) {
     OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     OM_HIP(hipFuncSetAttribute((const void*)kern_p, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, a.a_scale, a.w_scale, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps, 0};
   const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
   if (tiles > n_cu && g_gemm_persist && n_cu >= 8 && !a.rs_stats) hipLaunchKernelGGL(kern_p, dim3(n_cu & ~7), dim3(512), LDS, stream, p, tiles);
   else hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, p, 0);
@@ -844,11 +870,14 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   auto kern = gemm_kernel<T, BM, BN, WM, WN, EPI>;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps};
+  constexpr int LDS_MAX = LDS + 32 * 1024 <= 160 * 1024 ? LDS + 32 * 1024 : 160 * 1024;
+  if (attr_set.first()) OM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  GemmP p{a.A, a.W, a.C, a.bias, a.ls, a.resid, a.lda, a.ldw, a.ldc, a.ldr, a.M, a.N, a.K, nullptr, nullptr, g_gemm_wide_store, g_gemm_skip_dead, a.row_scale, a.stats, a.stats_ld, a.rs_stats, a.rs_ld, a.rs_nslots, a.rs_dim > 0 ? 1.0f / (float)a.rs_dim : 0.f, a.rs_eps, 0};
   const int grid = cdiv(a.M, BM) * cdiv(a.N, BN);
   if (a.stats_nslots) *a.stats_nslots = cdiv(a.N, BN / WN);      // one slot per wave tile
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, stream, p);
+  const int rs_bytes = a.rs_stats ? a.rs_nslots * ((BM + 63) / 64 * 64) * 4 : 0;      // row statistics prefetched by LDS-DMA behind the two stages
+  p.rs_dma = rs_bytes > 0 && LDS + rs_bytes <= LDS_MAX;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), p.rs_dma ? LDS + rs_bytes : LDS, stream, p);
   OM_LAUNCH_CHECK();
   return 0;
 }

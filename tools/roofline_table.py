@@ -64,9 +64,16 @@ def label(seq):
             out[i] = "decode attention merge"
         elif f == "vit_qknorm_kernel":
             out[i] = "ViT q/k norm"
+        elif f == "vit_knorm_slots_kernel":
+            out[i] = "ViT K norm (from the qkv slots; leaves the q sums)"
         elif f in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel"):
             nxt2 = fam[i + 2] if i + 2 < len(seq) else None
-            if nxt in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel") or (nxt in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel") and nxt2 in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel")
+            if nxt == "vit_knorm_slots_kernel":                 # round 6, fused layer: qkv (row scale + statistics) -> K norm -> attention
+                ctx = "vit"
+                out[i] = "ViT qkv GEMM"
+            elif ctx == "vit" and i and out[i - 1] == "ViT proj GEMM" and prev in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel"):
+                out[i] = "ViT fc1 GEMM (GELU)"                    # fused layer: no norm launch between proj and fc1
+            elif nxt in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel") or (nxt in ("gemm8_kernel", "gemm8p_kernel", "gemm_kernel") and nxt2 in ("vit_qknorm_kernel", "vit_qk_sumsq_kernel")
                                                                        and prev == "rmsnorm_kernel"):
                 out[i] = "ViT qkv GEMM"
             elif nxt == "rope_kv_kernel":
@@ -116,7 +123,7 @@ def work(tiles, text, gen):
     return {
         "ViT qkv GEMM": (F, 2.0 * M * 3 * C * C), "ViT proj GEMM": (F, 2.0 * M * C * C), "ViT fc1 GEMM (GELU)": (F, 2.0 * M * I * C),
         "ViT fc2 GEMM": (F, 2.0 * M * C * I), "ViT attention (MHA)": (F, 4.0 * tiles * Hv * ntok * ntok * 128),
-        "ViT q/k norm": (B, M * 2 * C * 2 * 2.0), "RMSNorm (ViT)": (B, M * C * 2 * 2.0), "RMSNorm (prefill)": (B, S * H * 2 * 2.0),
+        "ViT q/k norm": (B, M * 2 * C * 2 * 2.0), "ViT K norm (from the qkv slots; leaves the q sums)": (B, M * C * 2 * 2.0), "RMSNorm (ViT)": (B, M * C * 2 * 2.0), "RMSNorm (prefill)": (B, S * H * 2 * 2.0),
         "prefill qkv GEMM": (F, 2.0 * S * qkvd * H), "prefill o_proj GEMM": (F, 2.0 * S * H * qd), "prefill gate|up GEMM (SwiGLU)": (F, 2.0 * S * 2 * It * H),
         "prefill down_proj GEMM": (F, 2.0 * S * H * It), "prefill attention (causal GQA)": (F, 4.0 * S * S * 128 * 28 / 2),
         "prefill RoPE + KV write": (B, S * (qkvd * 2.0 * 2 + 1024 * 2.0)),
@@ -177,7 +184,7 @@ def main():
                 pr = r
     total = sum(us)
     print(f"# {a.trace}: {len(us)} dispatches, {total / 1e3:.2f} ms of kernel time; geometry: {a.tiles} tiles + {a.text} text ids, {a.gen} decode tokens")
-    print(f"{'role':36s} {'calls':>6s} {'avg us':>9s} {'% time':>7s} {'work / launch':>16s} {'achieved':>14s} {'frac':>6s} {'PMC traffic':>12s} {'x alg.':>7s}")
+    print(f"{'role':52s} {'calls':>6s} {'avg us':>9s} {'% time':>7s} {'work / launch':>16s} {'achieved':>14s} {'frac':>6s} {'PMC traffic':>12s} {'x alg.':>7s}")
     for r, v in sorted(t.items(), key=lambda kv: -sum(kv[1])):
         unit, w = W.get(r, (None, None))
         avg = sum(v) / len(v)
@@ -196,9 +203,9 @@ def main():
             ttxt = f"{per / 1e6:9.1f} MB"
             if w and unit == "GB/s":
                 rtxt = f"{per / w:.2f}"
-        print(f"{r:36s} {len(v):6d} {avg:9.2f} {100 * sum(v) / total:7.2f} {wtxt:>16s} {ach:>14s} {frac:>6s} {ttxt:>12s} {rtxt:>7s}")
+        print(f"{r:52s} {len(v):6d} {avg:9.2f} {100 * sum(v) / total:7.2f} {wtxt:>16s} {ach:>14s} {frac:>6s} {ttxt:>12s} {rtxt:>7s}")
     other = total - sum(sum(v) for v in t.values())
-    print(f"{'(unlabelled: fills, copies, argmax, front end)':36s} {'':6s} {'':9s} {100 * other / total:7.2f}")
+    print(f"{'(unlabelled: fills, copies, argmax, front end)':52s} {'':6s} {'':9s} {100 * other / total:7.2f}")
 
 
 if __name__ == "__main__":
