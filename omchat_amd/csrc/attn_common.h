@@ -199,13 +199,22 @@ __device__ __forceinline__ void attn_decode_tile(const AttnP& p, int split, int 
   if constexpr (KV8) {
     const float* ksp = p.k_scale + b * p.scale_sb + kvh * p.scale_sh;
     const float* vsp = p.v_scale + b * p.scale_sb + kvh * p.scale_sh;
+    if (key0 + KV_TILE <= kv_len) {      // whole tile (wave-uniform): the four keys of a score fragment are one 16-byte load (8 loads per tile instead of 32)
+      typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kt * 16 + 4 * fg + r, kc = key < kv_len ? key : kv_len - 1;
-        ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
+      for (int kt = 0; kt < 4; ++kt) {
+        const f32x4u kv = *reinterpret_cast<const f32x4u*>(ksp + key0 + kt * 16 + 4 * fg), vv = *reinterpret_cast<const f32x4u*>(vsp + key0 + kt * 16 + 4 * fg);
+        ksc[kt] = (f32x4){kv[0], kv[1], kv[2], kv[3]}; vsc[kt] = (f32x4){vv[0], vv[1], vv[2], vv[3]};
       }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + kt * 16 + 4 * fg + r, kc = key < kv_len ? key : kv_len - 1;
+          ksc[kt][r] = ksp[kc]; vsc[kt][r] = vsp[kc];
+        }
+    }
   }
   if constexpr (WAVE_ONLY) {
     __builtin_amdgcn_sched_barrier(0);
