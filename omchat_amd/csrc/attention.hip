@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[qt][kt][r] = (kt * 16 + r < rel && kt * 16 + r >= rel_lo) ? s[qt][kt][r] : NEG_BIG;
       }
-      // VALU is the bound of this kernel (MFMA and VALU issue do not overlap on a SIMD: tools/tune_pipes.hip), so the
+      // VALU is the bound of this kernel (MFMA and VALU issue do not overlap on a SIMD: tools/experiments/tune_pipes.hip), so the
       // softmax is written for instruction count: v_max3 chain, v_pk_fma / v_pk_add on register pairs
       float mx = max3(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
       mx = max3(mx, s[qt][0][3], s[qt][1][0]);

@@ -12,7 +12,7 @@
 //
 // Why (measured on MI355X, profiles/r04_*): a dependent kernel boundary of this step costs ~4 us (2.4 us between empty kernels + the first
 // memory round trip of the next kernel + the tail of the previous one), six of them per layer = a quarter of the 91 us layer; an
-// all-to-all hand-off of an activation row inside a launch costs 2.1-2.3 us (tools/tune_handoff.hip), and -- because a CU's memory pipe
+// all-to-all hand-off of an activation row inside a launch costs 2.1-2.3 us (tools/experiments/tune_handoff.hip), and -- because a CU's memory pipe
 // returns in order -- the polls of a hand-off wait behind whatever that CU has in flight.  So every hand-off here is
 //     publish results -> issue the FIRST loads of the next phase's weights -> sweep
 // and the sweep's latency runs under weight bytes that had to be loaded anyway.  The K / V tile of the attention is requested at kernel

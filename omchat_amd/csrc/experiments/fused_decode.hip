@@ -16,7 +16,7 @@
 //               x + T(row) in place.
 // Hand-off = 8-byte {tag, value} granules written with ONE sc1 (write-through) store each and swept with sc1 loads until every tag equals
 // this launch's tag (cdna_hip_programming.md section 6 Guideline 16, form R2: the data is the flag; no fence, no counter; placement
-// independent).  Measured on MI355X (tools/tune_handoff.hip, profiles/r04_a_handoff.txt): 2.1-2.3 us per all-to-all edge of up to 16 KB
+// independent).  Measured on MI355X (tools/experiments/tune_handoff.hip, profiles/r04_a_handoff.txt): 2.1-2.3 us per all-to-all edge of up to 16 KB
 // of granules on a quiet chip.  Every spin is bounded by the wall clock (s_memrealtime) and reports through a sticky error word
 // (omchat_fused_status); the launch needs all its workgroups resident at once: grid = number of CUs, one workgroup per CU (84 KB of LDS
 // requested), nothing else of this kind running beside it.
@@ -43,7 +43,7 @@ struct FusedP {
   unsigned tag_a, tag_b;
   unsigned* err;
   u64 timeout_ticks;            // s_memrealtime ticks (100 MHz)
-  u64* dbg;                     // diagnostic build only (tools/tune_fused.hip, OMCHAT_FUSED_STAMPS): [gridDim.x][16] phase stamps
+  u64* dbg;                     // diagnostic build only (tools/experiments/tune_fused.hip, OMCHAT_FUSED_STAMPS): [gridDim.x][16] phase stamps
 };
 
 // phase stamps of the diagnostic build: lane 0 of wave 7 (slots 0..7) and of wave 0 (slots 8..15) store s_memrealtime (100 MHz) into a

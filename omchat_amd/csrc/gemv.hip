@@ -202,7 +202,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 // fragment-shaped operands (16 rows x 64 B per wave instruction) for W AND for x; at b = 32 the x loads (L2 hits, as many bytes
 // as the weights) make it address-path bound: 3.2 TB/s on gate|up.  Here x arrives packed from its producer (RMSNorm, attention
 // merge, SwiGLU epilogue) and W optionally from the packed replica, so every wave load is 1 KiB contiguous; NTILE row tiles share
-// each x fragment.  Measured (tools/tune_gemv32.hip, MI355X, b = 32): gate|up 84 -> 66 us with packed x, -> 53 us with packed W
+// each x fragment.  Measured (tools/experiments/tune_gemv32.hip, MI355X, b = 32): gate|up 84 -> 66 us with packed x, -> 53 us with packed W
 // too (5.1 TB/s); down_proj 50 -> 28 us; qkv 17.7 -> 12.2; o_proj 13.8 -> 9.0; lm_head 318 -> 207.
 // Wave w of a workgroup walks K chunks (64 wide) c_lo + UNROLL * (w + WAVES * i) + u; partial tiles are summed through LDS in a
 // fixed order by all waves, which also apply the epilogue.
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_kernel(GemvP p) {
 // ---------------------------------------------------------------------------------------------------------
 // x-stationary form of the packed batched GEMV for the long launches (gate|up, lm_head; K = 64 * 8 * NCH, no split-K).  In gemv_pk_kernel
 // every workgroup re-reads the whole packed x (229 KB at K = 3584, NB = 2): as many bytes through the CU's load path as its share of
-// the weights (tools/tune_gemv32.hip: with x served from L1 gate|up takes 47.6 instead of 53.3 us).  Here one persistent workgroup per
+// the weights (tools/experiments/tune_gemv32.hip: with x served from L1 gate|up takes 47.6 instead of 53.3 us).  Here one persistent workgroup per
 // CU keeps x in REGISTERS -- wave w owns K chunks w, w + 8, ... for the whole launch -- and walks 16-row weight tiles with stride
 // gridDim.x; the eight partial tiles meet in LDS (parity double buffer: one barrier per tile) and the NEXT tile's weight fragments are
 // loaded before the current tile is reduced, so the weight stream never stops.  Measured in the harness: gate|up 53.3 -> 48.6 us,
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pk_kernel(GemvP p) {
   }
   const T* xbase = (const T*)p.X + lane * 8;
   // lanes whose batch row (16 nb + fr) does not exist load nothing: the x re-read of every workgroup (half of the CU-side traffic at
-  // b = 32, tools/tune_gemv32.hip) then scales with b instead of with the 16-row padding of the packed layout
+  // b = 32, tools/experiments/tune_gemv32.hip) then scales with b instead of with the 16-row padding of the packed layout
   bool xrow[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) xrow[nb] = nb * 16 + fr < p.b;
@@ -549,7 +549,7 @@ __global__ void pack_w_kernel(const T* W, int ldw, int N, int K, T* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// b = 1: whole-row streaming + packed dot products.  Measured on MI355X (tools/tune_rowdot.hip): 6.5-6.8 TB/s on the
+// b = 1: whole-row streaming + packed dot products.  Measured on MI355X (tools/experiments/tune_rowdot.hip): 6.5-6.8 TB/s on the
 // gate|up shape against 5.5 TB/s for the MFMA form above, whose 16-row x 64-B fragment reads reach ~6.0 TB/s at best; here
 // every wave instruction reads 1 KiB of ONE row (non-temporal).  x (this workgroup's K slice) sits in registers; a wave
 // takes R rows at a time (all R x NCH loads in flight), v_dot2 per 32 bits, butterfly over the wave, lane 0 applies the
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(256) void gemv_rows_norm_loop_kernel(GemvP p, int p
 // Dynamic form of the loop kernel (round 4).  The loop form deals every workgroup the same number of outputs and ends when the SLOWEST
 // workgroup ends -- and the eight XCDs of this chip do not stream at the same rate: with equal shares the gate|up phase of a CU took
 // 32.8 / 39.9 / 34.7 / 37.8 / 33.0 / 38.2 / 35.1 / 38.1 us by blockIdx % 8 (= the XCD group under round-robin dispatch; phase stamps of
-// tools/tune_layer.hip), i.e. the launch waits ~10 % for three of the XCDs.  Here the outputs are cut into chunks of DYN_CH and dealt by
+// tools/experiments/tune_layer.hip), i.e. the launch waits ~10 % for three of the XCDs.  Here the outputs are cut into chunks of DYN_CH and dealt by
 // atomic counters: DYN_POOLS pools (workgroup b starts at pool b % DYN_POOLS, so pool p is drained by one XCD group, p % 8), a wave takes
 // chunks from its pool and, when that is empty, from the following pools -- the fast XCDs end up with more chunks.  (Eight pools measured
 // 80 us per launch: a counter under streaming load answers ~15 tickets per us, not the 88 of an idle chip.)
@@ -1497,7 +1497,7 @@ void launch_rows_r(const GemvP& p, hipStream_t s) {
   grid = grid > 2048 ? 2048 : grid;
   hipLaunchKernelGGL((gemv_rows_kernel<T, EPI, RR, 4, F8>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
 }
-// rows per wave-group from tools/tune_rows.hip (MI355X, r01): short outputs (fused qkv) are latency-bound and want the most
+// rows per wave-group from tools/experiments/tune_rows.hip (MI355X, r01): short outputs (fused qkv) are latency-bound and want the most
 // waves (R = 1: 7.8 vs 8.8 us), everything else is flat in R; 4 waves per workgroup beat 8.  fp8 rows are half as many
 // bytes: the wide lm_head takes 8 rows per group, the split-K shapes measured flat (o_proj slightly worse) and keep 4.
 template <typename T, int EPI>
@@ -1534,7 +1534,7 @@ void launch_rows(const GemvP& p, hipStream_t s) {
   else launch_rows_r<T, EPI, 4, false>(p, s);
 }
 
-// Launch shapes measured with tools/tune_gemv.hip on MI355X (r01): plain loads beat non-temporal ones for this access
+// Launch shapes measured with tools/experiments/tune_gemv.hip on MI355X (r01): plain loads beat non-temporal ones for this access
 // shape (gate|up 54.9 -> 49.4 us), split-K slices prefer 4 waves x 8 chunks in flight when a slice is short.
 template <typename T>
 int launch_t(const GemvArgs& a, hipStream_t s) {
@@ -1550,7 +1550,7 @@ int launch_t(const GemvArgs& a, hipStream_t s) {
     return 1;
   }
   if (a.x_packed) {
-    // launch shapes from tools/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
+    // launch shapes from tools/experiments/tune_gemv32.hip (MI355X): <NTILE, WAVES, UNROLL> per shape class
 #define OM_PK(NT_, EPI_, WV_, UN_)                                                                                                  \
   do {                                                                                                                              \
     const dim3 grid(cdiv(cdiv(a.N, 16), NT_), ks);                                                                                  \

@@ -11,7 +11,7 @@
 #include "common.h"
 #if OMCHAT_EXPERIMENTS
 // TIMING PROBE ONLY (tuning key 41, experiments build): every kernel launch of the library goes out with hipExtAnyOrderLaunch.  On this GPU the flag does not
-// let a kernel overtake its predecessor (tools/tune_anyorder.hip: it still starts after the predecessor's last wave) but the boundary shrinks from 2.5 to
+// let a kernel overtake its predecessor (tools/experiments/tune_anyorder.hip: it still starts after the predecessor's last wave) but the boundary shrinks from 2.5 to
 // 0.3 us -- the release / acquire cache maintenance between the two is what goes.  Without it a consumer on another XCD may read stale lines, so results
 // under this key are NOT valid; it prices what boundaries without cache maintenance would return.
 #include <hip/hip_ext.h>
@@ -99,7 +99,7 @@ struct GemvArgs {
   int force_mfma;           // 1 = always the MFMA form (tests / A-B); default: b == 1 uses the whole-row streaming form
   const float* w_scale;     // non-null: W is OCP e4m3 bytes [N][ldw] with one fp32 scale per row (weight-only fp8, b == 1 only)
   // batched decode (b <= 32) with operands in MFMA fragment order (common.h: packed_x_index / packed_w_index): every wave load is 1 KiB
-  // contiguous instead of 16 rows x 64 B (measured, tools/tune_gemv32.hip: gate|up at b = 32 84 -> 53 us, down 50 -> 28 us)
+  // contiguous instead of 16 rows x 64 B (measured, tools/experiments/tune_gemv32.hip: gate|up at b = 32 84 -> 53 us, down 50 -> 28 us)
   int x_packed;             // X is packed with NB = b > 16 ? 2 : 1 (ldx ignored)
   int w_packed;             // W is the packed replica (ldw ignored); needs x_packed
   int y_packed;             // EPI_SWIGLU only: write Y in the packed x layout of the consumer (same NB; ldy ignored)
@@ -254,7 +254,7 @@ struct FusedDecodeArgs {
   void* x; int H, qd;
   void* ws; unsigned epoch;
   unsigned* err; int timeout_ms;
-  void* dbg = nullptr;      // diagnostic build of tools/tune_fused.hip only: phase stamps [CUs][16]; the library never sets it
+  void* dbg = nullptr;      // diagnostic build of tools/experiments/tune_fused.hip only: phase stamps [CUs][16]; the library never sets it
 };
 size_t fused_decode_ws_bytes(int q_heads);
 bool attn_oproj_fused_ok(const AttnDecodeArgs& a, int H, int qd);

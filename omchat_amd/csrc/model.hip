@@ -1459,7 +1459,7 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
   const bool fused = b <= 32;
   // K slices: batch 1 (whole-row streaming form) wants <= 8 chunks of 512 per slice and >= ~2500 waves in the grid;
   // the MFMA form (b > 1) wants ~2-3 workgroups per CU
-  // (tools/tune_rows.hip: down_proj 18944 -> 8 slices 23.3 us vs 5 slices 27.6 us; o_proj is latency-bound, 1-3 slices alike)
+  // (tools/experiments/tune_rows.hip: down_proj 18944 -> 8 slices 23.3 us vs 5 slices 27.6 us; o_proj is latency-bound, 1-3 slices alike)
   auto ks_rows = [&](int K) { const int nch = cdiv(K, 512); return nch >= 16 ? std::min(DEC_KS_MAX, nch) : std::max(1, std::min(3, nch)); };
   // batched o_proj: K = 3584 cuts into two exact slices for the x-stationary form (40 + 16 chunks, gemv_xs_split_kernel) when the packed
   // replica is in use; otherwise ~2 workgroups per CU for the MFMA form

@@ -1,6 +1,6 @@
 // Debug harness (not product): the one-launch decoder layer against the separate launches, piece by piece: q/k/v values, split-KV partials
 // (O, m, l), merged attention row, x + attn.   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dbg_layer_parts.hip omchat_amd/csrc/{attention,gemv}.hip
-#include "../omchat_amd/csrc/experiments/decode_layer.hip"
+#include "../../omchat_amd/csrc/experiments/decode_layer.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -2,7 +2,7 @@
 // (28 / 4 heads, 3584 wide, ~3.6 k keys), timed back to back and with in-kernel phase stamps (s_memrealtime, 100 MHz) of wave 7 and wave 0 of
 // every workgroup.  Compiled WITH the stamps (OMCHAT_FUSED_STAMPS); the library build has none.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DOMCHAT_FUSED_STAMPS tools/tune_fused.hip -o tools/bin/tune_fused
-#include "../omchat_amd/csrc/experiments/fused_decode.hip"
+#include "../../omchat_amd/csrc/experiments/fused_decode.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>

@@ -1,6 +1,6 @@
 // Tuning harness (not product): sweeps weight-streaming GEMV variants on the decode shapes of Qwen2-7B.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/tune_gemv.hip -o /tmp/tune_gemv && /tmp/tune_gemv
-#include "../omchat_amd/csrc/gemv.hip"
+#include "../../omchat_amd/csrc/gemv.hip"
 #include <cstdio>
 #include <vector>
 void omchat_set_error(const std::string& s) { fprintf(stderr, "ERR %s\n", s.c_str()); }

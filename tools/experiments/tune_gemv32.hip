@@ -3,7 +3,7 @@
 // order ([chunk][half][nb][lane][8]: every wave load is 1 KiB contiguous), W row-major vs W PACKED ([tile16][chunk][half][lane][8]),
 // NTILE row tiles per workgroup, K chunks in flight per wave.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/tune_gemv32.hip -o /tmp/tune_gemv32 && /tmp/tune_gemv32
-#include "../omchat_amd/csrc/common.h"
+#include "../../omchat_amd/csrc/common.h"
 #include <cstdio>
 #include <vector>
 void omchat_set_error(const std::string& s) { fprintf(stderr, "ERR %s\n", s.c_str()); }

@@ -2,7 +2,7 @@
 // widths, ~3.6 k keys): back-to-back time per launch over 28 different layers' weights (cold, as in the model) and in-kernel phase stamps
 // (s_memrealtime, 100 MHz) of wave 7 and wave 0 of every workgroup.  Compiled WITH the stamps (OMCHAT_FUSED_STAMPS); the library has none.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DOMCHAT_FUSED_STAMPS tools/tune_layer.hip -o tools/bin/tune_layer
-#include "../omchat_amd/csrc/experiments/decode_layer.hip"
+#include "../../omchat_amd/csrc/experiments/decode_layer.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>

@@ -1,5 +1,5 @@
 // Tuning harness (not product): whole-row streaming GEMV variants on the decode shapes.
-#include "../omchat_amd/csrc/gemv.hip"
+#include "../../omchat_amd/csrc/gemv.hip"
 #include <cstdio>
 #include <vector>
 void omchat_set_error(const std::string& s) { fprintf(stderr, "ERR %s\n", s.c_str()); }
