@@ -4,7 +4,7 @@ batch-1 o_proj, behind the split-KV merge, waiting on the merge's completion fla
 logits; key 41 = 0 twice (run-to-run determinism), key 41 = 1 three times; every step's logits compared bit for bit with the first run."""
 import os, sys
 os.environ["OMCHAT_ALLOW_TUNING"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from omchat_amd import _lib
 from omchat_amd.config import omchat13b

@@ -3,7 +3,7 @@ last wave's end), ordered launches (key 42 = 16) and with the out-of-order o_pro
 when fused_status() is called."""
 import os, sys
 os.environ["OMCHAT_ALLOW_TUNING"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from omchat_amd import _lib
 from omchat_amd.config import omchat13b
