@@ -427,8 +427,8 @@ def test_tp_projection_tool_reproduces_the_committed_curve():
     c1, c2 = rows[("configs1", 8)], rows[("configs2", 8)]
     assert abs(float(c1.split("|")[2].split()[1]) - 2.04) < 0.01
     assert abs(float(c2.split("|")[2].split()[1]) - 2.85) < 0.01 and "3.53" in c2
-    design = open(os.path.join(root, "DESIGN.md")).read()
-    assert "| 1 | 1.18 | 1.61 | **2.04** | 2.08 |" in design and "| 1 | 1.17 | 1.93 | **2.85** | **3.53** |" in design
+    log = open(os.path.join(root, "LOG.md")).read()          # (the round-3 table moved from DESIGN.md to LOG.md in round 6)
+    assert "| 1 | 1.18 | 1.61 | **2.04** | 2.08 |" in log and "| 1 | 1.17 | 1.93 | **2.85** | **3.53** |" in log
 
 
 def test_tp_projection_of_round_5_shard_lines():
@@ -443,6 +443,26 @@ def test_tp_projection_of_round_5_shard_lines():
     c2 = rows[("configs2", 8)]
     assert abs(float(c2.split("|")[2].split()[1]) - 3.12) < 0.01 and "3.94" in c2
     assert abs(float(rows[("configs2", 8)].split("|")[0].split()[4]) - 1.578) < 1e-3          # rank decode ms per step (round 4: 2.026)
+
+
+def test_tp_projection_of_round_6_sequence_parallel_shard_lines():
+    """round 6: per-rank shard lines with sequence-parallel norms (profiles/r06_e_*; comm_stats carry sp_reduce_scatters > 0, so every exchange is priced as
+    reduce-scatter + all-gather) and the all-reduce form beside them; the figures DESIGN.md section 5 quotes are what the tool prints for the committed files"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = lambda f: os.path.join(root, "profiles", f)
+    run = lambda files: subprocess.run([sys.executable, os.path.join(root, "tools", "tp_projection.py")] + files, capture_output=True, text=True, check=True).stdout
+    sp = run([P("r06_h_bench_n1.json")] + [P(f"r06_e_bench_shard{n}.json") for n in (2, 4, 8)])
+    ar = run([P("r06_h_bench_n1.json")] + [P(f"r06_e_bench_shard{n}_allreduce_form.json") for n in (2, 4, 8)])
+    committed = open(P("r06_e_tp_projection.txt")).read()
+    assert sp.strip() in committed and "\n".join(ar.strip().splitlines()[-5:]) in committed
+    row = lambda out, wl, n: next(l for l in out.splitlines() if l.startswith(wl) and l.split()[1].rstrip("*") == str(n))
+    up = lambda l: float(l.split("|")[2].split()[1])
+    assert "*" in row(sp, "configs2", 8).split()[1] and "*" not in row(ar, "configs2", 8).split()[1]
+    assert abs(up(row(sp, "configs2", 8)) - 3.18) < 0.01 and abs(up(row(ar, "configs2", 8)) - 3.10) < 0.01
+    assert up(row(sp, "configs2", 8)) > up(row(ar, "configs2", 8)) and up(row(sp, "configs2", 4)) > up(row(ar, "configs2", 4))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    assert "| 1.30 (1.17) | 2.08 (2.00) | **3.18 (3.10)** |" in design
 
 
 def test_pmc_traffic_picks_the_manifest_file_and_refuses_a_renamed_kernel(tmp_path, capsys):

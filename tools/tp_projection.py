@@ -99,7 +99,8 @@ def main():
             print(f"{wl:10s}  {n:3d}{'*' if sp else ' '} {s['vit_ms_p50']:7.1f}  {s['prefill_ms_p50']:9.1f}  {dec:12.3f} | {exp_vit*1e3:7.1f}  {exp_pre*1e3:7.1f}  {dec_comm*1e3:9.3f}     | {step:8.1f}  {t1/step:8.2f}     ({step_dp:8.1f}, {t1/step_dp:5.2f})")
 
 
-    print("(* = sequence-parallel norms: every exchange priced as reduce-scatter + all-gather)")
+    if any((d.get("comm_stats") or {}).get("sp_reduce_scatters") for d in shards.values()):
+        print("(* = sequence-parallel norms: every exchange priced as reduce-scatter + all-gather)")
 
 
 if __name__ == "__main__":
