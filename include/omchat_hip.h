@@ -422,6 +422,12 @@ int omchat_peer_set_mode(omchat_peer* p, int fast, size_t oneshot_max_bytes, int
 size_t omchat_peer_capacity(omchat_peer* p);
 /* in-place sum over the ranks, `count` elements of OMCHAT_F16 / BF16 / F32; buf 16-byte aligned, byte count % 16 == 0 */
 int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, int dtype, void* stream);
+/* the two halves of that all-reduce as collectives of their own (round 6, sequence-parallel norms): buf = [size][blk_count] elements (dtype as
+ * above; block bytes a multiple of 16).  reduce_scatter: block `rank` of buf becomes the sum over the ranks of their block `rank` (rank order,
+ * fp32, one rounding: the bits of omchat_peer_allreduce), the other blocks are left unchanged.  all_gather: block `rank` of every rank is copied into
+ * block `rank` of every other rank's buf.  Same stream / ordering rules as omchat_peer_allreduce. */
+int omchat_peer_reduce_scatter(omchat_peer* p, void* buf, size_t blk_count, int dtype, void* stream);
+int omchat_peer_all_gather(omchat_peer* p, void* buf, size_t blk_count, int dtype, void* stream);
 /* Tensor-parallel decode, the all-reduce fused with its consumer: part = this rank's fp32 split-K slices [ks][rows][H] of a row-parallel
  * projection (ks <= 8, rows <= 128, ks * rows * H * 4 <= capacity).  On return (stream order) x[rows, H] = T(x + T(sum over ranks and
  * slices)) on every rank and, when w != NULL, xn = T(w * T(x * rsqrt(mean(x^2) + eps))) (pack_nb != 0: in the packed x layout of the

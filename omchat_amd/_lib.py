@@ -118,6 +118,8 @@ _SIGS = {
     "omchat_peer_set_mode": (_i, [_vp, _i, _sz, _i]),
     "omchat_peer_capacity": (_sz, [_vp]),
     "omchat_peer_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "omchat_peer_reduce_scatter": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "omchat_peer_all_gather": (_i, [_vp, _vp, _sz, _i, _vp]),
     "omchat_peer_resid_rmsnorm": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "omchat_peer_error": (_i, [_vp, C.POINTER(_i)]),
     "omchat_peer_destroy": (None, [_vp]),

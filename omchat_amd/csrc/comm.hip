@@ -179,6 +179,46 @@ __global__ __launch_bounds__(PEER_THREADS) void peer_twoshot_kernel(PeerK k, voi
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The two halves of the two-shot all-reduce as collectives of their own (round 6: sequence-parallel norms, model.hip gemm_sp).  The message is
+// `size` SEGMENTS -- segment r = seg_bytes at buf + r * seg_stride: the row block rank r owns --
+//   reduce-scatter: every rank copies all its segments into its slot, barrier, rank r sums segment r over the slots (rank order, fp32, one rounding:
+//                   the bits of the two-shot all-reduce) into ITS segment of buf; the other segments of buf are left as they were;
+//   all-gather:     every rank copies its own segment into its slot's result area, barrier, every rank reads the other segments.
+// One barrier per call, slots alternate with the call parity exactly as for the all-reduce kernels (same ordering requirement).  Piece i of a
+// segment is touched by the same block index on every rank in both stages (first piece + t0 + m * stride), which is what the per-block barrier orders.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(PEER_THREADS) void peer_reduce_scatter_kernel(PeerK k, void* buf, int seg_bytes, long seg_stride, int parity) {
+  const size_t slot = PEER_FLAG_BYTES + (size_t)parity * 2 * k.cap;
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(k.base[k.rank] + slot, 2 * k.cap);
+  const int n16 = seg_bytes >> 4;
+  const int stride = gridDim.x * PEER_THREADS, t0 = blockIdx.x * PEER_THREADS + threadIdx.x;
+  for (int r = 0; r < k.size; ++r) {
+    const u32x4_t* src = reinterpret_cast<const u32x4_t*>((const char*)buf + (size_t)r * seg_stride);
+    for (int i = t0; i < n16; i += stride) __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, r * seg_bytes + (i << 4), 0, AUX_SYS);
+  }
+  peer_barrier(k);
+  u32x4_t* dst = reinterpret_cast<u32x4_t*>((char*)buf + (size_t)k.rank * seg_stride);
+  for (int i = t0; i < n16; i += stride) dst[i] = peer_sum16<T>(k, slot, k.rank * seg_bytes + (i << 4));
+}
+
+__global__ __launch_bounds__(PEER_THREADS) void peer_all_gather_kernel(PeerK k, void* buf, int seg_bytes, long seg_stride, int parity) {
+  const size_t slot = PEER_FLAG_BYTES + (size_t)parity * 2 * k.cap;
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(k.base[k.rank] + slot, 2 * k.cap);
+  const int n16 = seg_bytes >> 4;
+  const int stride = gridDim.x * PEER_THREADS, t0 = blockIdx.x * PEER_THREADS + threadIdx.x;
+  const u32x4_t* src = reinterpret_cast<const u32x4_t*>((const char*)buf + (size_t)k.rank * seg_stride);
+  for (int i = t0; i < n16; i += stride) __builtin_amdgcn_raw_buffer_store_b128(src[i], mine, i << 4, 0, AUX_SYS);
+  peer_barrier(k);
+  for (int rr = 1; rr < k.size; ++rr) {
+    const int r = (k.rank + rr) % k.size;            // start with the next rank: spreads the reads over the links
+    const __amdgpu_buffer_rsrc_t theirs = rsrc_of(k.base[r] + slot, k.cap);
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>((char*)buf + (size_t)r * seg_stride);
+    for (int i = t0; i < n16; i += stride) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(theirs, i << 4, 0, AUX_SYS);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Tensor-parallel decode: the all-reduce of the split-K slices fused with the residual add + RMSNorm that consumes them.
 // Unfused, a row-parallel projection of a decode step is  GEMV (fp32 slices [ks][rows][H]) -> one-shot all-reduce of the slices ->
 // resid_rmsnorm_kernel (sums the ks slices, residual, norm): three latency-bound launches.  Here the second and third are one: workgroup
@@ -398,6 +438,41 @@ extern "C" int omchat_peer_allreduce(omchat_peer* p, void* buf, size_t count, in
   }
   return 0;
 }
+
+// buf = [size][blk_count] elements.  which = 0: reduce-scatter (block `rank` of buf becomes the sum over the ranks of their block `rank`; the other
+// blocks are unchanged), 1: all-gather (every rank's block `rank` is copied into block `rank` of every other rank's buf).  Blocks longer than the
+// slot capacity go through in pieces: the same sub-range of every block per launch.
+static int peer_rs_ag(omchat_peer* p, void* buf, size_t blk_count, int dtype, int which, void* stream) {
+  OM_CHECK(p && buf, "null argument");
+  OM_CHECK(dtype == OMCHAT_F16 || dtype == OMCHAT_BF16 || dtype == 2, "bad dtype");
+  if (p->size == 1 || blk_count == 0) return 0;
+  for (int r = 0; r < p->size; ++r) OM_CHECK(p->base[r], "peer group is not connected");
+  const size_t esz = dtype == 2 ? 4 : 2, blk_bytes = blk_count * esz;
+  OM_CHECK(((uintptr_t)buf & 15) == 0 && blk_bytes % 16 == 0, "buffer and block byte count must be multiples of 16");
+  hipStream_t s = (hipStream_t)stream;
+  if (peer_refuse_capture(s)) return 1;
+  PeerK k{};
+  for (int r = 0; r < p->size; ++r) k.base[r] = (char*)p->base[r];
+  k.ctr = p->ctr; k.err = p->err; k.rank = p->rank; k.size = p->size; k.fast = p->fast; k.cap = p->cap;
+  const size_t max_piece = (which == 0 ? p->cap / p->size : p->cap) & ~(size_t)15;      // the reduce-scatter parks ALL segments in one slot
+  OM_CHECK(max_piece >= 16, "peer slot capacity too small");
+  for (size_t done = 0; done < blk_bytes;) {
+    const size_t piece = blk_bytes - done < max_piece ? blk_bytes - done : max_piece;
+    const int parity = (int)(p->calls++ & 1);
+    char* b = (char*)buf + done;
+    int grid = (int)((piece / 16 + PEER_THREADS * 4 - 1) / (PEER_THREADS * 4));
+    grid = grid < 1 ? 1 : (grid > p->max_blocks ? p->max_blocks : grid);
+    if (which == 1) hipLaunchKernelGGL(peer_all_gather_kernel, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, (long)blk_bytes, parity);
+    else if (dtype == 2) hipLaunchKernelGGL(peer_reduce_scatter_kernel<float>, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, (long)blk_bytes, parity);
+    else if (dtype == OMCHAT_F16) hipLaunchKernelGGL(peer_reduce_scatter_kernel<f16>, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, (long)blk_bytes, parity);
+    else hipLaunchKernelGGL(peer_reduce_scatter_kernel<bf16>, dim3(grid), dim3(PEER_THREADS), 0, s, k, (void*)b, (int)piece, (long)blk_bytes, parity);
+    OM_LAUNCH_CHECK();
+    done += piece;
+  }
+  return 0;
+}
+extern "C" int omchat_peer_reduce_scatter(omchat_peer* p, void* buf, size_t blk_count, int dtype, void* stream) { return peer_rs_ag(p, buf, blk_count, dtype, 0, stream); }
+extern "C" int omchat_peer_all_gather(omchat_peer* p, void* buf, size_t blk_count, int dtype, void* stream) { return peer_rs_ag(p, buf, blk_count, dtype, 1, stream); }
 
 // x[rows, H] = T(x + T(sum over ranks and slices of part)) in place on every rank, then xn = RMSNorm(x) * w (w == NULL: skip): the fused
 // form of  omchat_peer_allreduce(part) + the residual / RMSNorm launch  for split-K slices part = fp32 [ks][rows][H] (ks <= 8)

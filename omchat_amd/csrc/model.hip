@@ -264,15 +264,17 @@ struct omchat_ctx {
   }
   // Sequence-parallel form (round 6): buf = [tp_size][blk_rows][N] 16-bit rows.  reduce_scatter_rows: afterwards block tp_rank holds the sum over
   // the ranks (the other blocks are undefined); all_gather_rows: every rank contributes block tp_rank, afterwards all blocks are whole everywhere.
-  // RCCL: ncclReduceScatter / ncclAllGather in place -- together the bytes of ONE all-reduce.  Hook and peer transports (tests; messages under
-  // the one-shot limit) have all-reduce only: reduce-scatter = all-reduce (every block comes back summed), all-gather = zero the foreign blocks, then
-  // all-reduce (x + 0 is exact): the same values, twice the bytes.
+  // RCCL: ncclReduceScatter / ncclAllGather in place -- together the bytes of ONE all-reduce; peer transport: the two halves of its two-shot
+  // all-reduce as kernels of their own (comm.hip omchat_peer_reduce_scatter / omchat_peer_all_gather).  The test hook has all-reduce only:
+  // reduce-scatter = all-reduce (every block comes back summed), all-gather = zero the foreign blocks, then all-reduce (x + 0 is exact).
   long n_rs = 0, n_ag = 0;
   bool sp_native(size_t bytes) const { return !hook && comm && !(peer && (bytes <= peer_max || peer_all)); }
+  bool sp_peer(size_t bytes) const { return !hook && peer && (bytes <= peer_max || !comm || peer_all); }
   int reduce_scatter_rows(void* buf, int blk_rows, int N, hipStream_t s) {
     if (tp_size == 1) return 0;
     ++n_rs;
     const size_t blk = (size_t)blk_rows * N;
+    if (sp_peer(blk * tp_size * 2)) { ++n_ar_peer; return omchat_peer_reduce_scatter(peer, buf, blk, dt, s); }
     if (!sp_native(blk * tp_size * 2)) return allreduce_any(buf, blk * tp_size, dt, s);
     ++n_ar_rccl;
     ncclResult_t r = ncclReduceScatter(buf, (char*)buf + (size_t)tp_rank * blk * 2, blk, dt == OMCHAT_F16 ? ncclFloat16 : ncclBfloat16, ncclSum, comm, s);
@@ -283,6 +285,7 @@ struct omchat_ctx {
     if (tp_size == 1) return 0;
     ++n_ag;
     const size_t blk = (size_t)blk_rows * N;
+    if (sp_peer(blk * tp_size * 2)) { ++n_ar_peer; return omchat_peer_all_gather(peer, buf, blk, dt, s); }
     if (!sp_native(blk * tp_size * 2)) {
       if (hook == omchat_allreduce_noop) return 0;      // bench.py --shard-of: one rank's compute with the exchanges removed
       if (tp_rank > 0 && hipMemsetAsync(buf, 0, (size_t)tp_rank * blk * 2, s) != hipSuccess) { omchat_set_error("all_gather_rows: memset"); return 2; }

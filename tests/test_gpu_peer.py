@@ -98,6 +98,28 @@ def _proc_selftest(rank, size, port, q, fast=False):
                     acc = acc + data[r].float()
                 if not torch.equal(x.cpu(), acc.to(dt)):
                     ok, detail = False, f"random payload case {i} differs from the ordered fp32 sum"
+        if ok:                 # round 6: the two halves of the all-reduce as collectives of their own (sequence-parallel norms), bit for bit
+            lib = _lib.lib()
+            for i, (dt, code, blk) in enumerate([(torch.bfloat16, _lib.BF16, 3200 * 3), (torch.float16, _lib.F16, 3584 * 5), (torch.float32, _lib.F32, 4 * 1000),
+                                                  (torch.bfloat16, _lib.BF16, 3200 * 241)]):       # the last one: 1.5 MB blocks, several pieces per call
+                data = [torch.randn(size, blk, generator=torch.Generator().manual_seed(1000 * r + i)).to(dt) for r in range(size)]
+                x = data[rank].cuda()
+                _lib.check(lib.omchat_peer_reduce_scatter(peer, _lib.ptr(x), blk, code, _lib.cur_stream()))
+                torch.cuda.synchronize()
+                acc = torch.zeros(blk, dtype=torch.float32)
+                for r in range(size):
+                    acc = acc + data[r][rank].float()
+                want = data[rank].clone(); want[rank] = acc.to(dt)                # my block summed in rank order, the others untouched
+                if not torch.equal(x.cpu(), want):
+                    ok, detail = False, f"reduce-scatter case {i}: block {rank} is not the ordered fp32 sum / another block changed"
+                # all-gather: every rank contributes its (summed) block; afterwards all ranks hold all summed blocks = the all-reduce
+                _lib.check(lib.omchat_peer_all_gather(peer, _lib.ptr(x), blk, code, _lib.cur_stream()))
+                torch.cuda.synchronize()
+                full = torch.zeros(size, blk, dtype=torch.float32)
+                for r in range(size):
+                    full = full + data[r].float()
+                if not torch.equal(x.cpu(), full.to(dt)):
+                    ok, detail = False, f"all-gather after reduce-scatter, case {i}: differs from the ordered all-reduce"
         dist.barrier()
         _lib.lib().omchat_peer_destroy(peer)
         q.put((rank, ok, detail))
