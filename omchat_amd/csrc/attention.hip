@@ -384,10 +384,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
   const int q0b = qb * QW;
   const int q0 = q0b + (GQA ? 0 : wave * 32);
   const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
-  int kmax = kv_len;
+  const int kv_start = p.kv_start ? p.kv_start[b] : 0;
+  // One key over a whole number of tiles (the ViT: 1025 = 16 x 64 + 1 keys): the odd key does not get a 17th tile step of its own -- 64-key MFMAs, a
+  // softmax pass and a barrier for ONE key, 5.9 % of the launch -- it INITIALISES the online softmax instead: m = q . k_last, l = 1, O = v_last (its
+  // probability is exp2(0) = 1 exactly, in the accumulator as in the 16-bit P operand), and the loop walks the whole tiles only (round 6, p.peel_last).
+  const bool peel = !GQA && KG == 1 && D == 128 && p.peel_last && !p.causal && kv_start == 0 && kv_len > KV_TILE && (kv_len & (KV_TILE - 1)) == 1;
+  int kmax = peel ? kv_len - 1 : kv_len;
   if (p.causal) { const int lim = q0b + QW + p.q_pos0; kmax = lim < kmax ? lim : kmax; }
   const int t_end = (kmax + KV_TILE - 1) / KV_TILE;
-  const int kv_start = p.kv_start ? p.kv_start[b] : 0;
   const int t_begin = kv_start / KV_TILE;
 
   const T* Kg = (const T*)p.K + b * p.k_sb + kvh * p.k_sh;
@@ -498,6 +502,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_kernel(AttnP p) {
         for (int j = 0; j < 8; ++j) nq[j] = fromf<T>(rnd<T>(tof(qn_wv[s][j]) * rnd<T>(tof(qf[s][j]) * inv)) * p.qn_scale);
         qf[s] = nq;
       }
+    }
+  }
+  if constexpr (!GQA && KG == 1 && D == 128) {
+    if (peel && wave_active) {
+      const T* kl = Kg + (int64_t)(kv_len - 1) * p.k_sr + hh * 8;
+      const T* vl = Vg + (int64_t)(kv_len - 1) * p.v_sr + 4 * hh;
+      float sd = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const frag_t kf = ld8<T>(kl + s * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sd = __builtin_fmaf(tof(qf[s][j]), tof(kf[j]), sd);
+      }
+      sd += __shfl_xor(sd, 32);                       // the query's two lanes hold the two halves of every 16-deep k-step
+      m_run = sd;
+      l_run = hh == 0 ? 1.f : 0.f;                    // (the final sum adds the two lanes)
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const typename V8<T>::half_type v4 = *reinterpret_cast<const typename V8<T>::half_type*>(vl + db * 32 + g * 8);      // O^T rows d = 32 db + 8 g + 4 hh + (0..3)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[db][4 * g + r] = tof(v4[r]);
+        }
     }
   }
   for (int it = 0; it < steps; ++it) {
@@ -1358,6 +1386,8 @@ static int launch_attn2(K kern, dim3 grid, int threads, int lds, hipStream_t s, 
 }
 #define OM_LAUNCH_ATTN2(KERN, GRID, THREADS, LDS)                                     \
   do { static PerDeviceOnce done_; const int rc_ = launch_attn2((KERN), (GRID), (THREADS), (LDS), s, p, &done_); if (rc_) return rc_; } while (0)
+int g_attn_peel = 1;          // key 46: 1 = MHA prefill attention with one key over whole tiles folds that key into the online softmax's initial state
+void attn_set_peel(int v) { g_attn_peel = v; }
 int g_attn_mha_xcd = 1;       // key 33: 1 = MHA prefill attention launches keep the query blocks of a head on one XCD (one-dimensional grid)
 void attn_set_mha_xcd(int v) { g_attn_mha_xcd = v; }
 int g_attn_hsplit = -1;       // key 30: heaviest causal block ranks of a GQA prefill attention launch issued as two head halves (-1 = a quarter of the ranks when the launch is <= one workgroup per CU, 0 = off, n > 0 = n ranks whatever the size)
@@ -1408,6 +1438,7 @@ int launch_attn_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
           a.kv_len, a.kv_start, a.q_heads, a.kv_heads, a.Sq, a.Skv, a.causal, a.q_pos0, 0, a.scale * 1.4426950408889634f, nullptr,
           nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, 0};
   dim3 grid(cdiv(a.Sq, 128), a.q_heads, a.batch);
+  p.peel_last = g_attn_peel;
   const int hd = a.head_dim ? a.head_dim : 128;
   OM_CHECK(hd == 128 || hd == 64, "head_dim must be 128 or 64");
   if (a.qn_sumsq) {      // Q half of the ViT's joint-head norm on load (attn2_kernel, MHA, head dim 128)

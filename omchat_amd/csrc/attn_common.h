@@ -33,6 +33,7 @@ struct AttnP {
   // m = batch * Sq + query: the row's sum of squares over all heads' q channels, finished from the per-wave-column partials the qkv GEMM's
   // epilogue left (gemm.hip EPI_NONE_STATS -> launch_stats_finish).  null = Q is used as stored.
   const float* qn_sumsq = nullptr; int qn_stride = 0, qn_dim = 0; const void* qn_w = nullptr; float qn_eps = 0.f, qn_scale = 1.f;
+  int peel_last = 0;      // prefill, MHA: a key count of whole tiles + 1 folds the last key into the online softmax's initial state (attn2_kernel)
 #if OMCHAT_EXPERIMENTS
   unsigned long long* dbg;      // measurement only: clock stamps of the layer (model.hip dbg_stamps), else null
 #endif

@@ -100,6 +100,7 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 43) { gemm_set_skip_dead(value); return 0; }
   if (key == 44) { model_set_vit_fused(value); return 0; }
   if (key == 45) { model_set_tp_sp(value); return 0; }
+  if (key == 46) { attn_set_peel(value); return 0; }
   if (key == 38) { gemv_set_gu_rr(value); return 0; }
   if (key == 39) { gemv_set_longk_direct(value); return 0; }
   if (key == 40) { norm_set_wave(value); return 0; }

@@ -196,6 +196,7 @@ void attn_set_dma_rot(int v);
 void attn_set_hsplit(int v);
 void attn_set_mha_xcd(int v);
 void attn_set_kg(int v);      // tuning key 36
+void attn_set_peel(int v);    // tuning key 46
 void attn_set_merge_mid_min(int v);
 void attn_set_merge_dg(int v);
 void gemv_set_norm_loop(int v);

@@ -374,3 +374,49 @@ def test_fp8_modes_error_per_layer_over_four_full_width_layers_16k_context(gpu_l
         # the decode step inherits the quantiser-boundary flips of the four prefill layers (kern_err[3]) and adds its own e4m3 weights / cache
         assert d < 1.5 * kern_err[L - 1], (d, kern_err)
     eL.close()
+
+
+def test_fp8_error_attribution_per_operand_over_four_full_width_layers(gpu_lib):
+    """WHICH e4m3 operand owns the fp8 modes' distance to the 16-bit path?  Four Qwen2-7B-width layers, 4 k tokens of context,
+    each mode switched on ALONE and all together: (w+a) fp8 x fp8 prefill GEMMs -- per-row e4m3 weights of q / k / v / gate / up AND per-token e4m3
+    activations behind both RMSNorms; (kv) the e4m3 KV cache under the decode steps; (w) the weight-only e4m3 replica of every decode GEMV.  Measured:
+    relative distance of the prefill's last hidden state and of a decode step's logits to the all-16-bit run of the same engine.  Independent error
+    sources add in quadrature, which the asserts check; the figures go to gpurun_out/fp8_attribution.json."""
+    import json, os
+    dt, L, S = "bf16", 4, 4096
+    cfg = omchat13b(); cfg.text["num_hidden_layers"] = L; cfg.text["vocab_size"] = 2048
+    sd = {k: T32(v) for k, v in synth_state_dict(cfg, 0, lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k).items()}
+    x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(2)) * 0.5).bfloat16().float()
+
+    def run(prefill8, kv8, dec8):
+        e = Engine(cfg, dtype=dt, max_seq=S + 16, max_batch=1, vision=False)
+        e.load_state_dict(sd)
+        if prefill8:
+            e.enable_fp8_prefill(True)
+        if kv8:
+            e.enable_fp8_kv(True)
+        _, hid = e.prefill(x, want_hidden=True, want_logits=False)
+        if dec8:
+            e.enable_fp8_decode(True)
+        _, lg = e.decode_step(torch.tensor([7]), want_logits=True); sync()
+        out = (hid[0, -1].float().cpu(), lg[0].float().cpu())
+        e.close()
+        return out
+    base = run(False, False, False)
+    modes = {"prefill w+a": (True, False, False), "kv cache": (False, True, False), "decode weights": (False, False, True), "all": (True, True, True)}
+    res = {}
+    for name, m in modes.items():
+        h, lg = run(*m)
+        res[name] = dict(prefill_hidden=rel(h, base[0]), decode_logits=rel(lg, base[1]))
+    print("\nfp8 error attribution, 4 full-width layers, S = 4096 (relative distance to the 16-bit run): " +
+          "; ".join(f"{k}: hidden {v['prefill_hidden']:.3e}, decode logits {v['decode_logits']:.3e}" for k, v in res.items()))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(res, open("gpurun_out/fp8_attribution.json", "w"), indent=1)
+    # the KV and decode-weight modes leave the prefill untouched
+    assert res["kv cache"]["prefill_hidden"] == 0.0 and res["decode weights"]["prefill_hidden"] == 0.0
+    assert res["all"]["prefill_hidden"] == res["prefill w+a"]["prefill_hidden"]
+    # every mode is visible in the decode step, none dominates beyond the e4m3 step per layer, and together they add like independent errors
+    parts = [res[k]["decode_logits"] for k in ("prefill w+a", "kv cache", "decode weights")]
+    assert all(1e-3 < p < 0.2 for p in parts), parts
+    quad = sum(p * p for p in parts) ** 0.5
+    assert 0.6 * quad < res["all"]["decode_logits"] < 1.5 * quad, (res["all"]["decode_logits"], quad)

@@ -280,3 +280,31 @@ def test_tp2_sequence_parallel_norms_vs_all_reduce_form_and_oracle(gpu_lib, dt, 
         assert rel(res[key][0], ref_feats) < TOL_DEEP[dt], (key, rel(res[key][0], ref_feats))
     # the two forms differ by where the residual joins the sum (one rounding point): equal within one multi-layer tolerance
     assert rel(res[1][0], res[0][0]) < TOL_DEEP[dt] and rel(res[1][2], res[0][2]) < TOL_DEEP[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,S,H", [(2, 1025, 25), (1, 65, 3), (3, 129, 2), (1, 1026, 2), (2, 64, 2)])
+def test_mha_odd_key_folded_into_the_initial_softmax_state(gpu_lib, dt, B, S, H):
+    """tuning key 46: a key count of whole 64-key tiles + 1 (the ViT's 1025) initialises the online softmax with the odd key (m = q . k, l = 1, O = v)
+    instead of running a tile step for it -- against the 17-step form (equal to 16-bit rounding: the odd key's probability is exact either way) and
+    against the fp32 softmax(q k^T) v (modeling_intern_vit.py:148-151); key counts that are not tiles + 1 take the old path bit for bit"""
+    qkv = rnd(randn((B, S, 3, H, 128), 1) * 0.7, dt)
+    d = dev(qkv, dt)
+    outs = {}
+    try:
+        for key in (1, 0):
+            gpu_lib.omchat_op_set_tuning(46, key)
+            o = torch.full((B, S, H, 128), float("nan"), dtype=DT[dt], device="cuda")
+            _lib.check(gpu_lib.omchat_mha_fwd(ptr(d), B, S, H, 128 ** -0.5, 0, ptr(o), CODE[dt], None))
+            sync()
+            outs[key] = o
+    finally:
+        gpu_lib.omchat_op_set_tuning(46, 1)
+    q, k, v = [qkv[:, :, i].transpose(1, 2) for i in range(3)]
+    ref = (torch.softmax((q @ k.transpose(-2, -1)) * 128 ** -0.5, dim=-1) @ v).transpose(1, 2)
+    assert torch.isfinite(outs[1].float()).all()
+    assert rel(outs[1], ref) < TOL[dt] and rel(outs[0], ref) < TOL[dt]
+    if S % 64 == 1 and S > 64:
+        assert rel(outs[1], outs[0]) < TOL[dt] / 2
+    else:
+        assert torch.equal(outs[1], outs[0])
