@@ -293,6 +293,12 @@ int omchat_op_mha_qnorm(int dtype, const void* qkv, int B, int Sq, int H, const 
  * attention kernel, K norm from the qkv epilogue's statistics: six launches), 0 = the eight launches of round 5;
  * key 46: 1 (default) = MHA prefill attention whose key count is a whole number of 64-key tiles + 1 (the ViT: 1025) folds the odd key into the
  * online softmax's initial state (m = q . k_last, l = 1, O = v_last) instead of giving it a tile step of its own (-5.9 % of the launch), 0 = 17 tile steps;
+ * key 47: 64-key tiles per wave of the decode attention over the e4m3 KV cache: 0 (default) = by the launch's size (one wave per tile below two
+ * one-tile waves per CU; from there a wave walks 3 tiles with the next one prefetched into registers, and four such waves share a workgroup and
+ * fold their states in LDS when that leaves <= 64 partials per head for the one-round-trip merge and still fills half the CUs: 33 k keys 21.1 ->
+ * 14.9 us per attention + merge), 1 = always one wave per tile, 2 / 3 / 4 = tiles per wave forced, 11 = 3 tiles x 4 waves forced;
+ * key 48: 1 (default) = that walking form also rotates q / k and appends + quantises the new token's k / v rows (no RoPE + append launch in front of
+ * the attention of a long-context e4m3 decode step; the same bytes), 0 = separate launch;
  * key 45: 1 (default) = sequence-parallel norms under tensor parallelism (omchat_ctx_sp_stats), 0 = one all-reduce per sub-block and replicated norms;
  * key 37: 1 (default) = the GEMM epilogues store 16 bytes per lane (two column blocks exchanged between lane pairs), 0 = 8 bytes (same bits);
  * key 38: (gate, up) pairs per wave of the batch-1 gate|up GEMV's non-loop norm form: 1 (default: thousands of small workgroups that the dispatcher
@@ -363,6 +369,17 @@ int omchat_op_layernorm(int dtype, const void* x, const void* w, const void* b, 
 size_t omchat_op_attn_decode_ws(int b, int Hq, int L);
 int omchat_op_attn_decode(int dtype, const void* q, const void* k, const void* v, void* out, int b, int Hq, int Hkv,
                           int cap, int L, const int32_t* kv_len, float scale, void* ws, size_t ws_bytes, void* stream);
+/* the same over an e4m3 KV cache (omchat_enable_fp8_kv; BASELINE configs[4]): k8 / v8 [b,Hkv,cap,128] OCP e4m3 bytes, ks / vs [b,Hkv,cap] fp32, one
+ * scale per cached row (as omchat_op_rope_kv_q8 writes them): score = (q . k8) * ks in fp32, the value scale folded into the probabilities */
+int omchat_op_attn_decode_kv8(int dtype, const void* q, const void* k8, const void* v8, const float* ks, const float* vs, void* out, int b,
+                              int Hq, int Hkv, int cap, int L, const int32_t* kv_len, float scale, void* ws, size_t ws_bytes, void* stream);
+/* one decode step's attention over the e4m3 cache INCLUDING the new token's RoPE + append + quantisation, as the decoder layer issues it: qkv
+ * [b][(Hq + 2 Hkv) * 128] raw projections; sequence i holds kv_len[i] keys counting the new one (NULL: L), whose rows go to position kv_len[i] - 1
+ * of k8 / v8 / ks / vs and of the 16-bit caches k16 / v16 [b,Hkv,cap,128]; pos = kv_len - 1 (device, NULL with kv_len).  Launches long enough for
+ * the walking form (tuning key 47) do all of it in the attention launch (key 48; omchat_op_rope_kv_q8's bytes), the others run that launch in front */
+int omchat_op_attn_decode_kv8_append(int dtype, void* qkv, float theta, void* k8, void* v8, float* ks, float* vs, void* k16, void* v16, void* out,
+                                     int b, int Hq, int Hkv, int cap, int L, const int32_t* kv_len, const int32_t* pos, float scale, void* ws,
+                                     size_t ws_bytes, void* stream);
 /* qkv [rows, (Hq+2Hkv)*128]; rows = b*S; positions pos0 + s; caches [b,Hkv,cap,128]; theta: rope base */
 int omchat_op_rope_kv(int dtype, void* qkv, int b, int S, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache,
                       int cap, void* stream);

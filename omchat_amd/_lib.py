@@ -97,6 +97,8 @@ _SIGS = {
     "omchat_op_layernorm": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "omchat_op_attn_decode_ws": (_sz, [_i, _i, _i]),
     "omchat_op_attn_decode": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _sz, _vp]),
+    "omchat_op_attn_decode_kv8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _sz, _vp]),
+    "omchat_op_attn_decode_kv8_append": (_i, [_i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _sz, _vp]),
     "omchat_op_rope_kv": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "omchat_op_rope_kv_q8": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "omchat_op_argmax": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -945,6 +945,337 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Decode attention over the e4m3 KV cache for LONG contexts (round 6; tuning key 47): one wave walks TPW consecutive 64-key tiles with the
+// NEXT tile's bytes already on their way.  An e4m3 tile is half the registers of a 16-bit one (K 32 + V 32 VGPRs as raw bytes), so two tiles
+// fit next to the running output -- the 16-bit multi-tile kernel above cannot prefetch, this one does -- and the widening to the MFMA's
+// 16-bit operands happens where a fragment is consumed.  Against one wave per tile (attn_decode_kernel<KV8>) the launch writes 1 / TPW of
+// the partials and the merge reads 1 / TPW of them: at the 33 k keys of BASELINE configs[4] that pair was the worst row of the decode layer
+// (13.2 + 6.9 us for 34 MB, profiles/r06_a_*).
+//   K: lane (fc, fg) loads bytes [64 h + 16 fg, +16) of key row key0 + 16 kt + fc (8 loads of 16 B per tile, 64 contiguous bytes per row per
+//      instruction); the MFMA's k index is a free permutation of d as long as Q is loaded the same way: step 2 h + half, k = 8 fg + j  <->
+//      d = 64 h + 16 fg + 8 half + j.
+//   V: as in the one-tile kernel (whole 128-byte rows, widened into the transposed-read image).
+//   scales: ONE float per lane per array (key0 + lane), redistributed to the score layout (key0 + 16 kt + 4 fg + r) through 512 B of LDS
+//      (the front of the V image: this wave's previous transposed reads are behind the hand-over in its LDS order, the image write after it).
+// The workgroup is a single wave: its LDS operations execute in program order, so a compiler barrier is all the hand-over needs.
+// Same arithmetic as attn_decode_tile<KV8> per tile (score * k_scale in fp32, v_scale folded into P), the running max / sum of the
+// multi-tile kernel across tiles.
+// ---------------------------------------------------------------------------------------------------------
+// NW = 4: four such waves (one per SIMD) share a workgroup and fold their running states in LDS before the partial is written -- a split is
+// NW x TPW tiles, so that 33 k keys leave 44 partials per head and the merge is the one-round-trip launch (<= 64 partials) again.
+// FUSE (round 6, tuning key 48): the RoPE + append + quantise launch in front of this one (rope_kv_kernel with the e4m3 outputs) folded in,
+// as the 16-bit one-tile kernel folds its RoPE + append: every wave rotates q in registers and -- under the tile loads already in flight --
+// rotates and quantises the new token's k / v rows (s = absmax / 448, bytes = e4m3_rne(x / s): rope_kv_kernel's arithmetic, the same bytes);
+// the wave whose tiles hold position kv_len - 1 stores them (e4m3 rows + scales, and the 16-bit rows the other cache keeps), and every tile
+// row at or beyond that position takes the new bytes from registers (those rows of the cache are stale or being written).
+template <typename T, int TPW, int NW, bool FUSE = false>
+__global__ __launch_bounds__(64 * NW, FUSE ? 1 : 2) void attn_decode_kv8_walk_kernel(AttnP p) {
+  typedef typename V8<T>::type frag_t;
+  __shared__ __attribute__((aligned(256))) char Vs_all[NW][KV_TILE * 256];
+  const int lane = threadIdx.x & 63, fc = lane & 15, fg = lane >> 4;
+  const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const Vs = Vs_all[wave];
+  float* const Ss = reinterpret_cast<float*>(Vs);      // the scale hand-over borrows the image's first 512 bytes: it is over before the image is written
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int n_rep = p.q_heads / p.kv_heads, hq0 = kvh * n_rep;
+  const int kv_len = p.kv_len ? p.kv_len[b] : p.Skv;
+  const int key_base = (split * NW + wave) * KV_TILE * TPW;
+  float* wsb = p.ws + ((size_t)(b * p.q_heads + hq0 + (fc < n_rep ? fc : 0)) * p.nsplit + split) * WS_STRIDE;
+  if (split * NW * KV_TILE * TPW >= kv_len) {                   // empty split (uniform over the workgroup): neutral partial
+    if (wave == 0 && fc < n_rep && fg == 0) { wsb[128] = NEG_BIG; wsb[129] = 0.f; }
+    return;
+  }
+  const bool wave_live = key_base < kv_len;      // NW > 1: a wave beyond the sequence contributes the neutral state (its loads are clamped, its scores masked)
+  const unsigned char* Kg = (const unsigned char*)p.K + b * p.k_sb + kvh * p.k_sh;
+  const unsigned char* Vg = (const unsigned char*)p.V + b * p.v_sb + kvh * p.v_sh;
+  const float* ksp = p.k_scale + b * p.scale_sb + kvh * p.scale_sh;
+  const float* vsp = p.v_scale + b * p.scale_sb + kvh * p.scale_sh;
+
+  frag_t qf[4];                               // step 2 h + half: d = 64 h + 16 fg + 8 half + j
+  {
+    const int hh = fc < n_rep ? fc : n_rep - 1;
+    const T* qp = (const T*)p.Q + b * p.q_sb + (hq0 + hh) * p.q_sh;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = ld8<T>(qp + (st >> 1) * 64 + fg * 16 + (st & 1) * 8);
+  }
+  // FUSE: the new token's raw k (in q's layout) and v (chunk fc) rows and the RoPE table row, requested in front of the tiles
+  const int pp = kv_len - 1;
+  frag_t knf[4], vnf;
+  float csv[2][16];
+  if constexpr (FUSE) {
+    const int pt = pp < p.rope_max ? pp : p.rope_max - 1;
+    const T* kn = (const T*)p.k_new + b * p.new_sb + kvh * 128;
+    const T* vn = (const T*)p.v_new + b * p.new_sb + kvh * 128;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) knf[st] = ld8<T>(kn + (st >> 1) * 64 + fg * 16 + (st & 1) * 8);
+    vnf = ld8<T>(vn + fc * 8);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x4* cs = reinterpret_cast<const f32x4*>(p.rope + ((size_t)pt * 64 + 16 * fg + 8 * half) * 2);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) { const f32x4 v = cs[q4]; csv[half][4 * q4] = v[0]; csv[half][4 * q4 + 1] = v[1]; csv[half][4 * q4 + 2] = v[2]; csv[half][4 * q4 + 3] = v[3]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  struct Raw { u32x4 k[4][2]; u32x2 v[16]; float ks, vs; };
+  // every load of one tile; rows beyond the sequence are clamped onto its last row (their scores are masked below) -- no branch around loads
+  auto issue = [&](Raw& r, int key0) {      // in the order of use: vector memory returns in order
+    const int kc = key0 + lane < kv_len ? key0 + lane : kv_len - 1;
+    r.ks = ksp[kc]; r.vs = vsp[kc];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = key0 + kt * 16 + fc;
+      const unsigned char* src = Kg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.k_sr + fg * 16;
+      r.k[kt][0] = *reinterpret_cast<const u32x4*>(src);
+      r.k[kt][1] = *reinterpret_cast<const u32x4*>(src + 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = key0 + i * 4 + fg;
+      r.v[i] = *reinterpret_cast<const u32x2*>(Vg + (int64_t)(key < kv_len ? key : kv_len - 1) * p.v_sr + fc * 8);
+    }
+  };
+
+  f32x4 o[8];
+#pragma unroll
+  for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int tq = fc >> 2, tp = fc & 3;
+  const int vrow_lo = 4 * fg + tq;
+  const int vswz = ((vrow_lo & 7) << 1);
+
+  Raw buf[2];
+  issue(buf[0], key_base);
+  u32x4 kq[2] = {};
+  u32x2 vq = {};
+  float sk = 1.f, sv = 1.f;
+  if constexpr (FUSE) {
+    __builtin_amdgcn_sched_barrier(0);
+    // rotate-half partner of d = 64 h + 16 fg + 8 half + j is step (h ^ 1, half) of the same lane (q and the new key alike)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const frag_t lo = qf[half], hi = qf[2 + half];
+      qf[half] = rope_chunk<T>(lo, hi, csv[half], false);
+      qf[2 + half] = rope_chunk<T>(hi, lo, csv[half], true);
+    }
+    // only a wave whose tiles reach the new position needs the new rows (uniform; no loads inside: nothing is waited for at the join)
+    if (key_base + TPW * KV_TILE > pp) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const frag_t kl = knf[half], kh = knf[2 + half];
+        knf[half] = rope_chunk<T>(kl, kh, csv[half], false);
+        knf[2 + half] = rope_chunk<T>(kh, kl, csv[half], true);
+      }
+      // quantise the rotated key row (this lane holds 32 of its 128 elements; the row's absmax over the four fg groups) and the value row
+      // (8 elements per lane; absmax over the 16 fc lanes).  The 16 fc lanes hold the same key elements and the 4 fg groups the same value
+      // elements, so every lane divides only ONE four-byte word per 16-byte piece and the words are gathered by lane shuffles
+      // (12 divisions per lane instead of 40 on the launch's critical path).
+      float mk = 0.f, mv = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mk = fmaxf(mk, fabsf(tof(knf[st][j])));
+      mk = max_xor32(max_xor16(mk));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mv = fmaxf(mv, fabsf(tof(vnf[j])));
+#pragma unroll
+      for (int o1 = 1; o1 < 16; o1 <<= 1) mv = fmaxf(mv, __shfl_xor(mv, o1, 64));
+      sk = mk > 0.f ? mk / 448.0f : 1.0f;
+      sv = mv > 0.f ? mv / 448.0f : 1.0f;
+      auto pack4 = [](float a0, float a1, float a2, float a3, float sc) {
+        const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(a0 / sc, a1 / sc, 0, false);
+        const int hi = __builtin_amdgcn_cvt_pk_fp8_f32(a2 / sc, a3 / sc, 0, false);
+        return (unsigned)(lo & 0xFFFF) | ((unsigned)(hi & 0xFFFF) << 16);
+      };
+      const int wsel = fc & 3;      // the word of a key piece this lane quantises: elements 4 wsel .. 4 wsel + 3 of d = 64 h + 16 fg + (0..15)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float e[4];      // (element-wise selects: a lane-dependent index into the fragments would send them through scratch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a0 = tof(knf[2 * h][j]), a1 = tof(knf[2 * h][4 + j]), a2 = tof(knf[2 * h + 1][j]), a3 = tof(knf[2 * h + 1][4 + j]);
+          e[j] = wsel == 0 ? a0 : (wsel == 1 ? a1 : (wsel == 2 ? a2 : a3));
+        }
+        const unsigned mine = pack4(e[0], e[1], e[2], e[3], sk);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) kq[h][w] = (unsigned)__shfl((int)mine, (lane & ~3) | w, 64);
+      }
+      {
+        const bool up = fg & 1;      // value word (fg & 1): elements 4 (fg & 1) .. + 3 of d = 8 fc + (0..7)
+        const unsigned mine = pack4(tof(up ? vnf[4] : vnf[0]), tof(up ? vnf[5] : vnf[1]), tof(up ? vnf[6] : vnf[2]), tof(up ? vnf[7] : vnf[3]), sv);
+        vq[0] = (unsigned)__shfl((int)mine, fc, 64);
+        vq[1] = (unsigned)__shfl((int)mine, fc + 16, 64);
+      }
+      // the wave whose tiles hold position pp appends: e4m3 rows + scales, and the 16-bit rows of the other cache
+      if (wave_live && pp >= key_base) {
+        const int64_t ko = b * p.k_sb + kvh * p.k_sh + (int64_t)pp * p.k_sr, vo = b * p.v_sb + kvh * p.v_sh + (int64_t)pp * p.v_sr;
+        if (fc == 0) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4*>((unsigned char*)p.K + ko + 64 * h + 16 * fg) = kq[h];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) st8<T>((T*)p.k_cache_w + ko + (st >> 1) * 64 + fg * 16 + (st & 1) * 8, knf[st]);
+        }
+        if (fg == 0) {
+          *reinterpret_cast<u32x2*>((unsigned char*)p.V + vo + fc * 8) = vq;
+          st8<T>((T*)p.v_cache_w + vo + fc * 8, vnf);
+        }
+        if (lane == 0) {
+          ((float*)p.k_scale)[b * p.scale_sb + kvh * p.scale_sh + pp] = sk;
+          ((float*)p.v_scale)[b * p.scale_sb + kvh * p.scale_sh + pp] = sv;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int key0 = key_base + tt * KV_TILE;
+    Raw& cur = buf[tt & 1];
+    if (tt + 1 < TPW) issue(buf[(tt + 1) & 1], key0 + KV_TILE);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FUSE) {
+      if (key0 + KV_TILE > pp) {      // (uniform) rows at or beyond the new position: the new bytes (rows beyond it are masked, but must stay finite)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) cur.k[kt][h] = key0 + kt * 16 + fc >= pp ? kq[h] : cur.k[kt][h];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cur.v[i] = key0 + i * 4 + fg >= pp ? vq : cur.v[i];
+        cur.ks = key0 + lane >= pp ? sk : cur.ks;
+        cur.vs = key0 + lane >= pp ? sv : cur.vs;
+      }
+    }
+
+    // ---- scales into the score layout
+    Ss[lane] = cur.ks; Ss[KV_TILE + lane] = cur.vs;
+    asm volatile("" ::: "memory");
+    f32x4 ksc[4], vsc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) ksc[kt] = *reinterpret_cast<const f32x4*>(Ss + kt * 16 + 4 * fg);
+    // ---- S^T = K Q^T, K widened fragment by fragment
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x4 w = cur.k[kt][h];
+        s[kt] = mfma16(widen8<T>((u32x2){w.x, w.y}), qf[2 * h], s[kt]);
+        s[kt] = mfma16(widen8<T>((u32x2){w.z, w.w}), qf[2 * h + 1], s[kt]);
+      }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = key0 + kt * 16 + 4 * fg + r < kv_len ? s[kt][r] * ksc[kt][r] : NEG_BIG;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    // (the value scales are fetched only now: the K tile's registers are free, and they are not live across the S^T MFMAs)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) vsc[kt] = *reinterpret_cast<const f32x4*>(Ss + KV_TILE + kt * 16 + 4 * fg);
+    mx = max_xor32(max_xor16(mx));
+    if (tt > 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      l_run *= alpha;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) o[dn] *= alpha;
+      mx = m_new;
+    }
+    m_run = mx;
+    const float mc = mx * p.c;
+    float psum = 0.f;
+    frag_t pf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typedef float f32x8 __attribute__((ext_vector_type(8)));
+      f32x8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_exp2f(fmaf(s[2 * ks + (j >> 2)][j & 3], p.c, -mc));
+        psum += e[j];
+        e[j] *= vsc[2 * ks + (j >> 2)][j & 3];      // V = scale * e4m3: the per-key scale folded into P
+      }
+      pf[ks] = __builtin_convertvector(e, frag_t);
+    }
+    l_run += psum;
+    // ---- V -> transposed-read image (behind the previous tile's reads in this wave's LDS order)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 4 + fg;
+      *reinterpret_cast<frag_t*>(Vs + row * 256 + ((fc ^ ((row & 7) << 1)) << 4)) = widen8<T>(cur.v[i]);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) {
+        const int ch = (2 * dn + (tp >> 1)) ^ vswz;
+        const char* a0 = Vs + (ks * 32 + vrow_lo) * 256 + (ch << 4) + 8 * (tp & 1);
+        const s16x4 lo = tr_read(a0);
+        const s16x4 hi = tr_read(a0 + 16 * 256);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[dn] = mfma16(__builtin_bit_cast(frag_t, cat), pf[ks], o[dn]);
+      }
+    asm volatile("" ::: "memory");
+  }
+  float l = sum_xor32(sum_xor16(l_run));
+  if constexpr (NW > 1) {
+    // the waves' states meet in LDS (each wave's own image region is dead: its last transposed reads are behind it in its LDS order):
+    // [32 O values + m + l][64 lanes] floats per wave; wave 0 folds them in wave order
+    if (!wave_live) {      // every key of this wave was masked: with a NEG_BIG maximum its exponentials were exp2(0) -- drop that state
+      m_run = NEG_BIG; l = 0.f;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float* const mg = reinterpret_cast<float*>(Vs);
+    if (wave > 0) {
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mg[(dn * 4 + r) * 64 + lane] = o[dn][r];
+      mg[32 * 64 + lane] = m_run; mg[33 * 64 + lane] = l;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float mw[NW], lw[NW];
+    mw[0] = m_run; lw[0] = l;
+    float M = m_run;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float* const g = reinterpret_cast<const float*>(Vs_all[w]);
+      mw[w] = g[32 * 64 + lane]; lw[w] = g[33 * 64 + lane];
+      M = fmaxf(M, mw[w]);
+    }
+    const float a0 = __builtin_amdgcn_exp2f((m_run - M) * p.c);
+    l = l * a0;
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) o[dn] *= a0;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float* const g = reinterpret_cast<const float*>(Vs_all[w]);
+      const float aw = __builtin_amdgcn_exp2f((mw[w] - M) * p.c);
+      l += lw[w] * aw;
+#pragma unroll
+      for (int dn = 0; dn < 8; ++dn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dn][r] += g[(dn * 4 + r) * 64 + lane] * aw;
+    }
+    m_run = M;
+  }
+  if (fc < n_rep) {
+#pragma unroll
+    for (int dn = 0; dn < 8; ++dn) *reinterpret_cast<f32x4*>(wsb + dn * 16 + fg * 4) = o[dn];
+    if (fg == 0) { wsb[128] = m_run; wsb[129] = l; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Batched decode attention with the K / V tiles brought in by LDS-DMA (round 4; tuning key 25).  attn_decode_multi_kernel above walks its
 // tiles with TWO exposed memory round trips per tile (K -> S^T -> V -> PV: K and V share one register block because both next to the
 // running output do not fit), 7.5 waves per CU at b = 32: by its own timeline the launch is 4 tiles x 2 round trips of ~5 us.  Here the
@@ -1364,6 +1695,8 @@ int launch_kv_quant(int dtype, const void* kc, const void* vc, void* k8, void* v
   return 0;
 }
 
+int g_attn_kv8_tpw = 0;     // omchat_op_set_tuning key 47: 64-key tiles per wave of the decode attention over the e4m3 cache (attn_decode_kv8_walk_kernel): 0 = by the launch's size, 1 = one wave per tile (attn_decode_kernel), 2 / 3 / 4 forced, 11 = 3 tiles per wave x 4 waves per workgroup folded in LDS
+void attn_set_kv8_tpw(int v) { g_attn_kv8_tpw = v < 0 || v > 15 ? 0 : v; }
 int g_attn_tpw = 0;     // omchat_op_set_tuning key 10: key tiles per wave of the decode attention (0 = by grid size; 1, 2, 4 force)
 void attn_set_tpw(int v) { g_attn_tpw = v < 0 ? 0 : v; }
 int g_merge_dg = 1;       // omchat_op_set_tuning key 21: split-KV merge, column groups per head: 0 = none, 1 = 4 groups beyond 256 partials (default), 2 = also 2 groups for 65..256
@@ -1537,6 +1870,35 @@ size_t attn_decode_ws_bytes(int batch, int q_heads, int max_len) {
   return (size_t)batch * q_heads * cdiv(max_len, KV_TILE) * WS_STRIDE * sizeof(float);
 }
 
+// e4m3 cache: which form a decode launch takes (round 6, tuning key 47).  From two one-tile waves per CU on, a wave walks 3 tiles with the next
+// tile prefetched (attention + merge, us, one wave per tile / 2 / 3 / 4 tiles per wave: 8.8 k keys 13.9 / 12.2 / 10.1 / 11.8, 16.5 k keys 16.7 /
+// 14.5 / 14.3 / 15.3, 33 k keys 21.1 / 18.3 / 17.6 / 18.9, 66 k keys 67.3 / 24.8 / 24.0 / 23.7, b = 4 at 8.8 k keys 23.0 / 19.1 / 15.3 / 16.9;
+// 3.7 k keys 8.5 / - / 10.8 / 11.5).  Four such waves per workgroup, folded in LDS (a split = 12 tiles), when that brings the launch under the
+// 64 partials of the one-round-trip merge and still fills half the CUs: 33 k keys 17.6 -> 14.9, b = 2 at 33 k keys 24.7 -> 22.5; 16.5 k keys
+// 14.3 / 14.6, 8.8 k keys 10.1 -> 14.1 (48 workgroups), 66 k keys 24.0 -> 25.2 (86 partials: the general merge either way) --
+// profiles/r06_q_kv8_attn_ab.txt.
+static void kv8_plan(int batch, int kv_heads, int L, bool masked, int* tpw, int* nw) {
+  *tpw = 1; *nw = 1;
+  if (masked) return;      // the masked form exists for the one-tile kernel only (a rare mode)
+  const long waves1 = (long)cdiv(L, KV_TILE) * kv_heads * batch;
+  if (g_attn_kv8_tpw > 0) { *tpw = g_attn_kv8_tpw & 7; *nw = (g_attn_kv8_tpw & 8) ? 4 : 1; }
+  else {
+    *tpw = waves1 >= 2L * device_cus() ? 3 : 1;
+    const int n4 = cdiv(L, 12 * KV_TILE);
+    if (*tpw == 3 && n4 <= 64 && (long)n4 * kv_heads * batch >= device_cus() / 2) *nw = 4;
+  }
+  if (*tpw < 1 || *tpw > 4) *tpw = 1;
+  if (*tpw != 3) *nw = 1;      // the four-wave workgroup is built for three tiles per wave only
+}
+int g_attn_kv8_fuse = 1;      // omchat_op_set_tuning key 48: 1 = the walking form also rotates q / k and appends + quantises the new token's rows (no rope_kv launch in front), 0 = separate launch
+void attn_set_kv8_fuse(int v) { g_attn_kv8_fuse = v; }
+// true: launch_attn_decode over the e4m3 cache of this shape takes `rope` / `k_new` / `v_new` / `k16_w` / `v16_w` and does the RoPE + append itself
+bool attn_decode_kv8_fuses_rope(int batch, int kv_heads, int L, bool masked) {
+  int tpw, nw;
+  kv8_plan(batch, kv_heads, L, masked, &tpw, &nw);
+  return g_attn_kv8_fuse && tpw == 3;
+}
+
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   OM_CHECK(a.q_heads % a.kv_heads == 0 && a.q_heads / a.kv_heads <= 16, "group size must be <= 16");
   OM_CHECK(a.L > 0 && a.batch > 0, "empty attention");
@@ -1546,6 +1908,8 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   const long waves1 = (long)cdiv(a.L, KV_TILE) * a.kv_heads * a.batch;
   int tpw = kv8 ? 1 : (waves1 >= 6144 ? 4 : (waves1 >= 3072 ? 2 : 1));
   if (g_attn_tpw > 0 && !kv8) tpw = g_attn_tpw;
+  int kv8_nw = 1;
+  if (kv8) kv8_plan(a.batch, a.kv_heads, a.L, a.key_mask != nullptr, &tpw, &kv8_nw);
   if (a.key_mask) tpw = 1;      // the masked form exists for the one-tile kernel only (a rare mode)
   // enough keys in the launch (round 4): the LDS-DMA ring form.  One wave per workgroup owns a ring of 32-key tiles; `slots` of them are
   // resident per CU and the split count is chosen so that the launch is one resident round of (nearly) equal splits.  Measured against the
@@ -1562,7 +1926,7 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
     const int pairs = a.kv_heads * a.batch, tpw4 = cdiv(cdiv(a.L, DMA_TILE), std::max(1, 4 * device_cus() / pairs));
     dma_slots = (pairs >= 16 && tpw4 >= 4 && tpw4 <= 8 && tiles32 < 32L * device_cus()) ? 4 : 2;
   }
-  int split_keys = KV_TILE * tpw;
+  int split_keys = KV_TILE * tpw * kv8_nw;
   if (dma) {
     const int slots = dma_slots * device_cus(), pairs = a.kv_heads * a.batch;
     const int tiles = cdiv(a.L, DMA_TILE);
@@ -1581,9 +1945,13 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
 #endif
   OM_CHECK(!a.key_mask || (((kv8 && !a.rope) || (!kv8 && a.rope && a.pos)) && !a.kv_len && a.mask_sb % 64 == 0 && a.mask_sb >= a.L),
            "masked decode: fused RoPE with explicit positions (16-bit cache) or rows appended beforehand (e4m3 cache), uniform length, mask rows padded to a multiple of 64");
-  OM_CHECK(!kv8 || (a.v_scale && !a.rope), "fp8 KV cache: both scale arrays, no fused RoPE");
+  const bool kv8_fuse = kv8 && a.rope != nullptr;
+  OM_CHECK(!kv8 || a.v_scale, "fp8 KV cache: both scale arrays");
+  OM_CHECK(!kv8_fuse || (tpw == 3 && a.k_new && a.v_new && a.k16_w && a.v16_w && !a.key_mask),
+           "fp8 KV cache with fused RoPE: the walking form only (attn_decode_kv8_fuses_rope), raw k / v rows and the 16-bit caches to append to");
   OM_CHECK(!a.rope || (a.k_new && a.v_new), "fused RoPE decode needs k_new and v_new (kv_len == null: every sequence holds exactly L keys)");
   OM_CHECK(a.o_pack_nb == 0 || (a.batch <= 16 * a.o_pack_nb && a.o_sh == 128 && a.q_heads % 1 == 0), "packed output: batch <= 16 * NB, head stride 128");
+  if (kv8_fuse) { p.k_cache_w = a.k16_w; p.v_cache_w = a.v16_w; }
   if (dma) p.causal = g_attn_dma_rot == 1;
   // LDS request of the ring form: the ring, padded so that exactly g_attn_dma_slots workgroups fit a CU's 160 KiB (the split count is sized
   // for that many; a CU that took more would leave another one short)
@@ -1594,6 +1962,12 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   if (dtype == OMCHAT_F16) {
     if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true, true>), grid, dim3(64), 0, s, p);
     else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<f16, false, true>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 2) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 2, 1>), grid, dim3(64), 0, s, p);
+    else if (kv8_fuse && kv8_nw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 3, 4, true>), grid, dim3(256), 0, s, p);
+    else if (kv8_fuse) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 3, 1, true>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 3 && kv8_nw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 3, 4>), grid, dim3(256), 0, s, p);
+    else if (kv8 && tpw == 3) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 3, 1>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<f16, 4, 1>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<f16, true>), grid, dim3(64), 0, s, p);
     else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 2>), grid, dim3(64), dma_lds, s, p);
     else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<f16, 3>), grid, dim3(64), dma_lds, s, p);
@@ -1612,6 +1986,12 @@ int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
   } else if (dtype == OMCHAT_BF16) {
     if (a.key_mask && kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true, true>), grid, dim3(64), 0, s, p);
     else if (a.key_mask) hipLaunchKernelGGL((attn_decode_kernel<bf16, false, true>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 2) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 2, 1>), grid, dim3(64), 0, s, p);
+    else if (kv8_fuse && kv8_nw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 3, 4, true>), grid, dim3(256), 0, s, p);
+    else if (kv8_fuse) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 3, 1, true>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 3 && kv8_nw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 3, 4>), grid, dim3(256), 0, s, p);
+    else if (kv8 && tpw == 3) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 3, 1>), grid, dim3(64), 0, s, p);
+    else if (kv8 && tpw == 4) hipLaunchKernelGGL((attn_decode_kv8_walk_kernel<bf16, 4, 1>), grid, dim3(64), 0, s, p);
     else if (kv8) hipLaunchKernelGGL((attn_decode_kernel<bf16, true>), grid, dim3(64), 0, s, p);
     else if (dma && g_attn_dma_stages == 2) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 2>), grid, dim3(64), dma_lds, s, p);
     else if (dma && g_attn_dma_stages == 3) hipLaunchKernelGGL((attn_decode_dma_kernel<bf16, 3>), grid, dim3(64), dma_lds, s, p);

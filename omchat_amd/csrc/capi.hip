@@ -101,6 +101,8 @@ extern "C" int omchat_op_set_tuning(int key, int value) {
   if (key == 44) { model_set_vit_fused(value); return 0; }
   if (key == 45) { model_set_tp_sp(value); return 0; }
   if (key == 46) { attn_set_peel(value); return 0; }
+  if (key == 47) { attn_set_kv8_tpw(value); return 0; }
+  if (key == 48) { attn_set_kv8_fuse(value); return 0; }
   if (key == 38) { gemv_set_gu_rr(value); return 0; }
   if (key == 39) { gemv_set_longk_direct(value); return 0; }
   if (key == 40) { norm_set_wave(value); return 0; }
@@ -216,6 +218,72 @@ extern "C" int omchat_op_attn_decode(int dtype, const void* q, const void* k, co
   return launch_attn_decode(dtype, a, S(stream));
 }
 
+extern "C" int omchat_op_attn_decode_kv8(int dtype, const void* q, const void* k8, const void* v8, const float* ks, const float* vs, void* out, int b,
+                                         int Hq, int Hkv, int cap, int L, const int32_t* kv_len, float scale, void* ws, size_t ws_bytes, void* stream) {
+  if (!k8 || !v8 || !ks || !vs) { omchat_set_error("omchat_op_attn_decode_kv8: null cache or scale pointer"); return 1; }
+  AttnDecodeArgs a{};
+  a.Q = q; a.q_sb = (int64_t)Hq * 128; a.q_sh = 128;
+  a.K = k8; a.k_sb = (int64_t)Hkv * cap * 128; a.k_sh = (int64_t)cap * 128; a.k_sr = 128;      // strides in cache elements = bytes
+  a.V = v8; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+  a.k_scale = ks; a.v_scale = vs; a.scale_sb = (int64_t)Hkv * cap; a.scale_sh = cap;
+  a.O = out; a.o_sb = a.q_sb; a.o_sh = 128;
+  a.batch = b; a.q_heads = Hq; a.kv_heads = Hkv; a.L = L; a.kv_len = kv_len; a.scale = scale; a.ws = (float*)ws; a.ws_bytes = ws_bytes;
+  return launch_attn_decode(dtype, a, S(stream));
+}
+
+static float* rope_table_device(int max_pos, float theta) {
+  std::vector<float> tab((size_t)max_pos * 128);
+  for (int i = 0; i < 64; ++i) {
+    const float inv = (float)(1.0 / pow((double)theta, (double)((float)(2 * i) / 128.0f)));
+    for (int p = 0; p < max_pos; ++p) {
+      const float ang = (float)p * inv;
+      tab[((size_t)p * 64 + i) * 2] = (float)cos((double)ang);
+      tab[((size_t)p * 64 + i) * 2 + 1] = (float)sin((double)ang);
+    }
+  }
+  float* d = nullptr;
+  if (hipMalloc(&d, tab.size() * 4) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+  return d;
+}
+
+// One decode step's attention over the e4m3 cache INCLUDING the new token's RoPE + append, as the decoder layer issues it (model.hip): qkv
+// [b][(Hq + 2 Hkv) * 128] raw projections of the new token; sequence i holds kv_len[i] keys counting the new one (NULL: L for every sequence), the
+// new row goes to position kv_len[i] - 1 of k8 / v8 / ks / vs and of the 16-bit caches k16 / v16.  Long launches take the walking form, which does
+// the rotation, the append and the quantisation itself (tuning keys 47 / 48); the others run omchat_op_rope_kv_q8's launch in front (q rotated in
+// place in qkv then).  pos = kv_len - 1 as a device array (needed by that launch when kv_len != NULL).
+extern "C" int omchat_op_attn_decode_kv8_append(int dtype, void* qkv, float theta, void* k8, void* v8, float* ks, float* vs, void* k16, void* v16,
+                                                void* out, int b, int Hq, int Hkv, int cap, int L, const int32_t* kv_len, const int32_t* pos, float scale,
+                                                void* ws, size_t ws_bytes, void* stream) {
+  OM_CHECK(qkv && k8 && v8 && ks && vs && k16 && v16 && out, "null argument");
+  OM_CHECK(L >= 1 && L <= cap, "L exceeds the cache capacity");
+  OM_CHECK((kv_len == nullptr) == (pos == nullptr), "kv_len and pos come together");
+  float* tab = rope_table_device(L, theta);
+  OM_CHECK(tab, "rope table allocation failed");
+  const int qkvd = (Hq + 2 * Hkv) * 128;
+  AttnDecodeArgs a{};
+  a.Q = qkv; a.q_sb = qkvd; a.q_sh = 128;
+  a.K = k8; a.k_sb = (int64_t)Hkv * cap * 128; a.k_sh = (int64_t)cap * 128; a.k_sr = 128;
+  a.V = v8; a.v_sb = a.k_sb; a.v_sh = a.k_sh; a.v_sr = 128;
+  a.k_scale = ks; a.v_scale = vs; a.scale_sb = (int64_t)Hkv * cap; a.scale_sh = cap;
+  a.O = out; a.o_sb = (int64_t)Hq * 128; a.o_sh = 128;
+  a.batch = b; a.q_heads = Hq; a.kv_heads = Hkv; a.L = L; a.kv_len = kv_len; a.scale = scale; a.ws = (float*)ws; a.ws_bytes = ws_bytes;
+  int rc = 0;
+  if (attn_decode_kv8_fuses_rope(b, Hkv, L, false)) {
+    a.rope = tab; a.rope_max = L;
+    a.k_new = (const char*)qkv + (size_t)Hq * 128 * 2; a.v_new = (const char*)qkv + (size_t)(Hq + Hkv) * 128 * 2; a.new_sb = qkvd;
+    a.k16_w = k16; a.v16_w = v16;
+  } else {
+    RopeArgs r{qkv, qkvd, b, 1, Hq, Hkv, pos, L - 1, tab, L, k16, v16, (int64_t)Hkv * cap * 128, (int64_t)cap * 128};
+    r.k8 = k8; r.v8 = v8; r.ks = ks; r.vs = vs; r.s_sb = (int64_t)Hkv * cap; r.s_sh = cap;
+    rc = launch_rope_kv(dtype, r, S(stream));
+  }
+  if (!rc) rc = launch_attn_decode(dtype, a, S(stream));
+  hipStreamSynchronize(S(stream));
+  hipFree(tab);
+  return rc;
+}
+
 static int op_rope_kv_impl(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
                            void* k8, void* v8, float* ks, float* vs, void* stream);
 extern "C" int omchat_op_rope_kv(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv, int pos0, float theta, void* kcache, void* vcache, int cap,
@@ -233,18 +301,8 @@ static int op_rope_kv_impl(int dtype, void* qkv, int b, int Sq, int Hq, int Hkv,
                            void* k8, void* v8, float* ks, float* vs, void* stream) {
   OM_CHECK(pos0 + Sq <= cap, "positions exceed cache capacity");
   const int max_pos = pos0 + Sq;
-  std::vector<float> tab((size_t)max_pos * 128);
-  for (int i = 0; i < 64; ++i) {
-    const float inv = (float)(1.0 / pow((double)theta, (double)((float)(2 * i) / 128.0f)));
-    for (int p = 0; p < max_pos; ++p) {
-      const float ang = (float)p * inv;
-      tab[((size_t)p * 64 + i) * 2] = (float)cos((double)ang);
-      tab[((size_t)p * 64 + i) * 2 + 1] = (float)sin((double)ang);
-    }
-  }
-  float* d = nullptr;
-  OM_HIP(hipMalloc(&d, tab.size() * 4));
-  OM_HIP(hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  float* d = rope_table_device(max_pos, theta);
+  OM_CHECK(d, "rope table allocation failed");
   RopeArgs r{qkv, (Hq + 2 * Hkv) * 128, b * Sq, Sq, Hq, Hkv, nullptr, pos0, d, max_pos, kcache, vcache, (int64_t)Hkv * cap * 128, (int64_t)cap * 128};
   r.k8 = k8; r.v8 = v8; r.ks = ks; r.vs = vs; r.s_sb = (int64_t)Hkv * cap; r.s_sh = cap;
   int rc = launch_rope_kv(dtype, r, S(stream));

@@ -197,6 +197,9 @@ void attn_set_hsplit(int v);
 void attn_set_mha_xcd(int v);
 void attn_set_kg(int v);      // tuning key 36
 void attn_set_peel(int v);    // tuning key 46
+void attn_set_kv8_tpw(int v); // tuning key 47
+void attn_set_kv8_fuse(int v); // tuning key 48
+bool attn_decode_kv8_fuses_rope(int batch, int kv_heads, int L, bool masked);
 void attn_set_merge_mid_min(int v);
 void attn_set_merge_dg(int v);
 void gemv_set_norm_loop(int v);
@@ -232,6 +235,10 @@ struct AttnDecodeArgs {
   // with one fp32 scale per (sequence, kv head, key): k_scale / v_scale [b][kv_heads][scale_cap]; rope must be null (the new token is
   // rotated, appended and quantised before the call)
   const float* k_scale; const float* v_scale; int64_t scale_sb, scale_sh;
+  // ... unless attn_decode_kv8_fuses_rope(batch, kv_heads, L, masked) (round 6): then `rope`, `k_new`, `v_new` are given as for the 16-bit cache
+  // and the launch rotates q / k itself, appends the new rows to the e4m3 cache + scales (written through K / V / k_scale / v_scale) and to the
+  // 16-bit cache k16_w / v16_w (same [b, kv_heads, L, 128] strides) -- rope_kv_kernel's bytes, no launch in front
+  void* k16_w = nullptr; void* v16_w = nullptr;
   // padded batch as the reference decodes it (omchat_decode_step_masked): key j of sequence b is visible iff key_mask[b * mask_sb + j] != 0
   // (device bytes, rows zero-padded to mask_sb % 64 == 0); `pos` then holds the RoPE positions (not kv_len - 1); kv_len must be null
   const unsigned char* key_mask; int64_t mask_sb;

@@ -1548,8 +1548,12 @@ static int decode_body(omchat_ctx* ctx, const int32_t* tokens, int b, int Lmax, 
       r.s_sb = (int64_t)c.t_kv_heads * c.max_seq; r.s_sh = c.max_seq;
       if (masked) r.slot0 = Lmax - 1;                              // padded batch: common cache slot, per-row RoPE positions from d_pos
       else if (exact_len) { r.pos = nullptr; r.pos0 = Lmax - 1; }      // the position by value: one dependent load less in front of the table read
-      TRY(launch_rope_kv(ctx->dt, r, s));
-      a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
+      // round 6: from ~9 k keys on the attention launch walks its tiles and rotates / appends / quantises the new rows itself (the same bytes)
+      if (attn_decode_kv8_fuses_rope(b, c.t_kv_heads, Lmax, masked)) { a.k16_w = kc; a.v16_w = vc; a.pos = nullptr; }
+      else {
+        TRY(launch_rope_kv(ctx->dt, r, s));
+        a.rope = nullptr; a.pos = nullptr; a.k_new = nullptr; a.v_new = nullptr;
+      }
       a.K = (char*)ctx->k8cache + off; a.V = (char*)ctx->v8cache + off;
       a.k_scale = ctx->ks8 + so; a.v_scale = ctx->vs8 + so; a.scale_sb = (int64_t)c.t_kv_heads * c.max_seq; a.scale_sh = c.max_seq;
     }

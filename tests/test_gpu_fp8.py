@@ -420,3 +420,98 @@ def test_fp8_error_attribution_per_operand_over_four_full_width_layers(gpu_lib):
     assert all(1e-3 < p < 0.2 for p in parts), parts
     quad = sum(p * p for p in parts) ** 0.5
     assert 0.6 * quad < res["all"]["decode_logits"] < 1.5 * quad, (res["all"]["decode_logits"], quad)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Hq,Hkv,cap,lens", [(1, 28, 4, 2304, [2200]), (3, 8, 2, 1024, [1000, 513, 64]), (5, 7, 1, 512, [1, 63, 65, 129, 512]),
+                                               (2, 28, 4, 1280, [1217, 255]), (1, 28, 4, 33024, [32900])])
+def test_kv8_decode_attention_walking_tiles_vs_reference_and_one_tile_form(gpu_lib, dt, b, Hq, Hkv, cap, lens):
+    """op level (round 6, tuning key 47): the decode attention over the e4m3 cache with a wave walking 2 / 3 / 4 tiles (next tile prefetched
+    into registers) against the fp32 softmax on the DE-QUANTISED cache and against the one-wave-per-tile form: ragged lengths incl. a single
+    key, tile edges, splits that end in empty tiles, a poisoned cache tail (NaN bytes and NaN scales) that must never leak."""
+    q = rnd(randn((b, Hq, 128), 1), dt); k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3) * 3.0, dt)
+    k8, ks = quant_ref(k.reshape(-1, 128)); v8, vs = quant_ref(v.reshape(-1, 128))
+    kd = (k8.float() * ks[:, None]).reshape(b, Hkv, cap, 128); vd = (v8.float() * vs[:, None]).reshape(b, Hkv, cap, 128)
+    rep, scale = Hq // Hkv, 128 ** -0.5
+    ref = torch.zeros(b, Hq, 128)
+    for i, n in enumerate(lens):
+        kk = kd[i, :, :n].repeat_interleave(rep, 0); vv = vd[i, :, :n].repeat_interleave(rep, 0)
+        pr = torch.softmax(torch.einsum("hd,hnd->hn", q[i].float(), kk) * scale, -1)
+        ref[i] = torch.einsum("hn,hnd->hd", pr, vv)
+    k8b = k8.view(torch.uint8).reshape(b, Hkv, cap, 128).clone(); v8b = v8.view(torch.uint8).reshape(b, Hkv, cap, 128).clone()
+    ksb = ks.reshape(b, Hkv, cap).clone(); vsb = vs.reshape(b, Hkv, cap).clone()
+    for i, n in enumerate(lens):
+        k8b[i, :, n:] = 0x7F; v8b[i, :, n:] = 0x7F; ksb[i, :, n:] = float("nan"); vsb[i, :, n:] = float("nan")
+    dq = dev(q, dt); dk8, dv8, dks, dvs = k8b.cuda(), v8b.cuda(), ksb.cuda(), vsb.cuda()
+    L = max(lens)
+    wsb = gpu_lib.omchat_op_attn_decode_ws(b, Hq, L)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
+    dl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    outs = {}
+    try:
+        for tpw in (1, 2, 3, 4, 11, 0):      # 11 = 3 tiles per wave, four waves per workgroup folded in LDS
+            gpu_lib.omchat_op_set_tuning(47, tpw)
+            out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda"); ws.fill_(float("nan"))
+            _lib.check(gpu_lib.omchat_op_attn_decode_kv8(CODE[dt], ptr(dq), ptr(dk8), ptr(dv8), ptr(dks), ptr(dvs), ptr(out), b, Hq, Hkv, cap, L, ptr(dl),
+                                                         scale, ptr(ws), wsb, None))
+            sync()
+            assert torch.isfinite(out.float()).all(), tpw
+            assert rel(out, ref) < TOL[dt], (tpw, rel(out, ref))
+            outs[tpw] = out.float().cpu()
+        for tpw in (2, 3, 4, 11):
+            assert rel(outs[tpw], outs[1]) < TOL[dt] / 2, (tpw, rel(outs[tpw], outs[1]))
+    finally:
+        gpu_lib.omchat_op_set_tuning(47, 0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,Hq,Hkv,cap,lens,form", [(1, 28, 4, 2304, [2200], 3), (1, 28, 4, 2304, [2113], 11), (3, 8, 2, 1024, [1000, 513, 65], 3),
+                                                    (2, 7, 1, 1024, [769, 1], 11), (1, 28, 4, 33024, [32900], 0)])
+def test_kv8_decode_attention_with_rope_append_and_quantisation_folded_in(gpu_lib, dt, b, Hq, Hkv, cap, lens, form):
+    """op level (round 6, tuning key 48): a long-context decode step over the e4m3 cache as ONE attention launch -- q / k rotated, the new
+    k / v rows quantised and appended to the e4m3 cache, its scales and the 16-bit cache inside the walking attention kernel -- against the two
+    launches it replaces (RoPE + append + quantise, then the same attention form): the same output bits, the same cache bytes and scales;
+    everything at and beyond the new position is poisoned beforehand (NaN bytes, NaN scales, NaN 16-bit rows) and nothing beyond it is touched."""
+    qkvd = (Hq + 2 * Hkv) * 128
+    qkv = rnd(randn((b, qkvd), 5), dt)
+    k = rnd(randn((b, Hkv, cap, 128), 2), dt); v = rnd(randn((b, Hkv, cap, 128), 3) * 3.0, dt)
+    k8, ks = quant_ref(k.reshape(-1, 128)); v8, vs = quant_ref(v.reshape(-1, 128))
+    k8b = k8.view(torch.uint8).reshape(b, Hkv, cap, 128).clone(); v8b = v8.view(torch.uint8).reshape(b, Hkv, cap, 128).clone()
+    ksb = ks.reshape(b, Hkv, cap).clone(); vsb = vs.reshape(b, Hkv, cap).clone()
+    k16, v16 = k.clone(), v.clone()
+    for i, n in enumerate(lens):
+        k8b[i, :, n - 1:] = 0x7F; v8b[i, :, n - 1:] = 0x7F; ksb[i, :, n - 1:] = float("nan"); vsb[i, :, n - 1:] = float("nan")
+        k16[i, :, n - 1:] = float("nan"); v16[i, :, n - 1:] = float("nan")
+    L = max(lens)
+    uniform = len(set(lens)) == 1
+    wsb = gpu_lib.omchat_op_attn_decode_ws(b, Hq, L)
+    ws = torch.empty(wsb // 4 + 4, dtype=torch.float32, device="cuda")
+    dl = None if uniform else torch.tensor(lens, dtype=torch.int32, device="cuda")
+    dp = None if uniform else torch.tensor([n - 1 for n in lens], dtype=torch.int32, device="cuda")
+    res = {}
+    try:
+        gpu_lib.omchat_op_set_tuning(47, form)
+        for fuse in (0, 1):
+            gpu_lib.omchat_op_set_tuning(48, fuse)
+            dq = dev(qkv, dt)
+            c = [k8b.cuda(), v8b.cuda(), ksb.cuda(), vsb.cuda(), dev(k16, dt), dev(v16, dt)]
+            out = torch.full((b, Hq, 128), float("nan"), dtype=DT[dt], device="cuda"); ws.fill_(float("nan"))
+            _lib.check(gpu_lib.omchat_op_attn_decode_kv8_append(CODE[dt], ptr(dq), 1e6, ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(c[5]), ptr(out),
+                                                                b, Hq, Hkv, cap, L, ptr(dl) if dl is not None else None, ptr(dp) if dp is not None else None,
+                                                                128 ** -0.5, ptr(ws), wsb, None))
+            sync()
+            assert torch.isfinite(out.float()).all(), fuse
+            res[fuse] = [out.float().cpu()] + [t.cpu() for t in c]
+        names = ["out", "k8", "v8", "k scales", "v scales", "k16", "v16"]
+        for i, n in enumerate(lens):
+            for j, name in enumerate(names):
+                if j == 0:
+                    assert torch.equal(res[0][0][i], res[1][0][i]), (i, name)
+                    continue
+                a0, a1 = res[0][j][i, :, :n], res[1][j][i, :, :n]
+                assert torch.equal(a0.view(torch.uint8) if a0.dtype != torch.float32 else a0, a1.view(torch.uint8) if a1.dtype != torch.float32 else a1), (i, name)
+                tail = res[1][j][i, :, n:]
+                if tail.numel():      # nothing beyond the new position was written
+                    assert (tail.view(torch.uint8) == 0x7F).all() if tail.dtype == torch.uint8 else torch.isnan(tail.float()).all(), (i, name)
+    finally:
+        gpu_lib.omchat_op_set_tuning(47, 0); gpu_lib.omchat_op_set_tuning(48, 1)
