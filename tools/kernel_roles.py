@@ -9,7 +9,7 @@ the template argument list) and the run of `Li<n>E` / `Lb<n>E` integer / bool ar
 # kernel families, longest / most specific first (a dispatch belongs to the first family whose name occurs in its symbol)
 FAMILIES = ("gemm8p_kernel", "gemm8_kernel", "gemm_kernel", "gemv_rows_norm_loop_kernel", "gemv_rows_norm_kernel", "gemv_rows_longk_kernel",
             "gemv_rows_kernel", "gemv_xs_split_kernel", "gemv_xs_kernel", "gemv_pk_kernel", "gemv_kernel", "attn_decode_dma_kernel",
-            "attn_decode_multi_kernel", "attn_decode_kernel", "attn_merge_kernel", "attn2_kernel", "attn_kernel", "vit_qknorm_kernel",
+            "attn_decode_multi_kernel", "attn_decode_kv8_walk_kernel", "attn_decode_kernel", "attn_merge_mid_kernel", "attn_merge_kernel", "attn2_kernel", "attn_kernel", "vit_qknorm_kernel",
             "vit_qk_sumsq_kernel", "vit_knorm_slots_kernel", "row_sumsq_kernel", "stats_finish_kernel", "fold_cols_kernel", "resid16_norm_kernel", "resid_rmsnorm_kernel", "rmsnorm_kernel", "layernorm_kernel",
             "rope_kv_kernel", "gather_rows_kernel", "argmax_stage1_kernel", "argmax_stage2_kernel", "im2col_kernel", "vit_assemble_kernel",
             "copy_rows_kernel")

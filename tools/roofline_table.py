@@ -57,10 +57,10 @@ def label(seq):
         if f == "attn2_kernel":
             ctx = "pre" if e == 1 else "vit"
             out[i] = "prefill attention (causal GQA)" if e == 1 else "ViT attention (MHA)"
-        elif f in ("attn_decode_kernel", "attn_decode_dma_kernel", "attn_decode_multi_kernel"):
+        elif f in ("attn_decode_kernel", "attn_decode_dma_kernel", "attn_decode_multi_kernel", "attn_decode_kv8_walk_kernel"):
             ctx = "dec"
             out[i] = "decode attention (split-KV)"
-        elif f == "attn_merge_kernel":
+        elif f in ("attn_merge_kernel", "attn_merge_mid_kernel"):
             out[i] = "decode attention merge"
         elif f == "vit_qknorm_kernel":
             out[i] = "ViT q/k norm"
@@ -102,7 +102,7 @@ def label(seq):
                 out[i] = "decode gate|up GEMV (+RMSNorm)"
             else:
                 out[i] = "decode qkv GEMV (+RMSNorm)" if nxt and nxt.startswith("attn_decode") else ("lm_head GEMV (+final norm)" if nxt and nxt.startswith("argmax") else None)
-        elif f == "gemv_rows_kernel" and prev == "attn_merge_kernel":
+        elif f == "gemv_rows_kernel" and prev in ("attn_merge_kernel", "attn_merge_mid_kernel"):
             out[i] = "decode o_proj GEMV"
         elif f == "rmsnorm_kernel":
             rope_ahead = "rope_kv_kernel" in fam[i + 1:i + 3]
