@@ -968,6 +968,8 @@ __global__ __launch_bounds__(64, 2) void attn_decode_multi_kernel(AttnP p) {
 // rotates and quantises the new token's k / v rows (s = absmax / 448, bytes = e4m3_rne(x / s): rope_kv_kernel's arithmetic, the same bytes);
 // the wave whose tiles hold position kv_len - 1 stores them (e4m3 rows + scales, and the 16-bit rows the other cache keeps), and every tile
 // row at or beyond that position takes the new bytes from registers (those rows of the cache are stale or being written).
+// (FUSE: the new rows' bytes and scales live across the tile loop next to two tiles of raw bytes and the running output: ~300 registers, one
+// wave per SIMD -- attn_decode_kv8_fuses_rope takes this form only while the launch is one resident round of such waves.)
 template <typename T, int TPW, int NW, bool FUSE = false>
 __global__ __launch_bounds__(64 * NW, FUSE ? 1 : 2) void attn_decode_kv8_walk_kernel(AttnP p) {
   typedef typename V8<T>::type frag_t;
@@ -1896,7 +1898,9 @@ void attn_set_kv8_fuse(int v) { g_attn_kv8_fuse = v; }
 bool attn_decode_kv8_fuses_rope(int batch, int kv_heads, int L, bool masked) {
   int tpw, nw;
   kv8_plan(batch, kv_heads, L, masked, &tpw, &nw);
-  return g_attn_kv8_fuse && tpw == 3;
+  // the folded form holds ~300 registers (one wave per SIMD): only while the launch is one resident round of such waves
+  const long waves = (long)cdiv(L, KV_TILE * tpw * nw) * nw * kv_heads * batch;
+  return g_attn_kv8_fuse && tpw == 3 && waves <= 4L * device_cus();
 }
 
 int launch_attn_decode(int dtype, const AttnDecodeArgs& a, hipStream_t s) {
