@@ -515,3 +515,37 @@ def test_kv8_decode_attention_with_rope_append_and_quantisation_folded_in(gpu_li
                     assert (tail.view(torch.uint8) == 0x7F).all() if tail.dtype == torch.uint8 else torch.isnan(tail.float()).all(), (i, name)
     finally:
         gpu_lib.omchat_op_set_tuning(47, 0); gpu_lib.omchat_op_set_tuning(48, 1)
+
+
+def test_long_context_e4m3_decode_steps_in_the_model_walking_and_folded_forms(gpu_lib):
+    """model level (round 6, tuning keys 47 / 48): two Qwen2-7B-width layers, 26 k tokens of context on the e4m3 KV cache -- long enough for the
+    launcher to take the four-wave walking form with the RoPE + append + quantise launch folded in (as BASELINE configs[4] does at 33 k keys).
+    Three greedy decode steps in three forms: (a) one wave per tile behind the RoPE launch (the path rounds 3-5 pinned to the oracle), (b) the
+    walking form behind the RoPE launch, (c) the defaults (folded).  (c) must give (b)'s logits BIT FOR BIT over all steps (same attention
+    arithmetic, same appended cache bytes) and (a)'s within half the one-op tolerance (the partial sums are grouped differently), same ids."""
+    dt, L, S = "bf16", 2, 26000
+    cfg = omchat13b(); cfg.text["num_hidden_layers"] = L; cfg.text["vocab_size"] = 2048
+    sd = {k: T32(v) for k, v in synth_state_dict(cfg, 0, lambda k: not k.startswith(synth.TOWER) and "mm_projector" not in k).items()}
+    x = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(3)) * 0.5).bfloat16().float()
+    e = Engine(cfg, dtype=dt, max_seq=S + 64, max_batch=1, vision=False)
+    e.load_state_dict(sd)
+    e.enable_fp8_kv(True)
+    res = {}
+    try:
+        for name, keys in (("a", {47: 1, 48: 1}), ("b", {47: 0, 48: 0}), ("c", {47: 0, 48: 1})):
+            for k, v in keys.items():
+                gpu_lib.omchat_op_set_tuning(k, v)
+            e.prefill(x, want_logits=False)
+            tok, lgs, ids = torch.tensor([7]), [], []
+            for _ in range(3):
+                nxt, lg = e.decode_step(tok, want_logits=True); sync()
+                lgs.append(lg[0].float().cpu()); ids.append(int(nxt[0])); tok = torch.tensor([ids[-1]])
+            res[name] = (lgs, ids)
+    finally:
+        gpu_lib.omchat_op_set_tuning(47, 0); gpu_lib.omchat_op_set_tuning(48, 1)
+        e.close()
+    for t in range(3):
+        assert torch.equal(res["c"][0][t], res["b"][0][t]), t
+        d = rel(res["c"][0][t], res["a"][0][t])
+        assert d < TOL[dt] / 2, (t, d)
+    assert res["a"][1] == res["b"][1] == res["c"][1], (res["a"][1], res["b"][1], res["c"][1])
