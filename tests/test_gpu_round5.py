@@ -302,7 +302,7 @@ def test_batched_decode_with_the_norm_in_the_gate_up_gemv_vs_eight_launches_and_
         oracle.qwen2_model(x[i:i + 1, :lens[i]], sdt, cfg.text, cache)
         o1 = oracle.decode_step(toks[i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
         o2 = oracle.decode_step(res[7][2][i:i + 1][None].long(), sdt, cfg.text, cache)[0, 0]
-        for key in (15, 11):
+        for key in (7, 3):
             assert rel(res[key][0][i], o1) < TOL_DEEP[dt], (key, i, rel(res[key][0][i], o1))
         assert rel(res[7][1][i], o2) < TOL_DEEP[dt], (i, rel(res[7][1][i], o2))
     # the two structures sum o_proj's K in different orders (one slice against two) and form the variance in different orders
@@ -372,7 +372,7 @@ def test_mha_prefill_attention_with_two_key_groups_vs_reference_and_one_group(gp
             sc[i, :, :, n:] = float("-inf")
     ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), v.float())
     assert rel(outs[(2, 1)], ref) < TOL[dt] and rel(outs[(1, 1)], ref) < TOL[dt]
-    assert rel(outs[(2, 1)], outs[(1, 1)]) < TOL[dt] / 4
+    assert rel(outs[(2, 1)], outs[(1, 1)]) < TOL[dt] / 2      # (round 6: the one-group form folds the odd key into its initial state, key 46)
 
 
 @pytest.mark.parametrize("dt", DTS)
